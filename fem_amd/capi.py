@@ -1,0 +1,457 @@
+"""ctypes binding of libfem_amd.so (include/fem_amd.h) and thin PETSc-shaped
+wrappers (Mat / Vec / KSP objects with the method names the reference calls
+from src/main.F90 and src/m_global.F90).  Plumbing only: every number is
+computed by the HIP library.  Import fails loudly if the library is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfem_amd.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+_h = C.c_void_p
+
+
+class FemError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libfem_amd error {code}: {msg}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP library is required; there is no CPU path)")
+    return C.CDLL(LIB_PATH)
+
+
+_lib = _load()
+_lib.fem_last_error.restype = C.c_char_p
+
+# (name, argtypes) for every symbol of include/fem_amd.h
+_SIGS = {
+    "fem_version": [],
+    "fem_device_count": [_ip],
+    "fem_ctx_create": [C.c_int, C.POINTER(_h)],
+    "fem_ctx_destroy": [_h],
+    "fem_ctx_synchronize": [_h],
+    "fem_ctx_timer_start": [_h],
+    "fem_ctx_timer_stop": [_h, _dp],
+    "fem_el_counts": [C.c_int, _ip, _ip, _ip, _ip, _ip],
+    "fem_el_tables": [C.c_int, _dp, _dp, _dp, _dp, _ip],
+    "fem_form_el_ke": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp],
+    "fem_calc_el_stress": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp],
+    "fem_form_el_indx": [C.c_int, C.c_int, _ip, _ip],
+    "fem_mesh_create": [_h, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp, C.c_int, _dp, C.POINTER(_h)],
+    "fem_mesh_destroy": [_h],
+    "fem_mesh_set_halo": [_h, _h, C.c_int, _ip, _ip, _ip],
+    "fem_mat_create_aij": [_h, C.POINTER(_h)],
+    "fem_mat_destroy": [_h],
+    "fem_mat_zero_entries": [_h],
+    "fem_mat_assemble_elements": [_h],
+    "fem_mat_apply_kbc": [_h, C.c_int, _ip],
+    "fem_mat_get_info": [_h, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
+    "fem_mat_get_csr": [_h, _ip, _ip, _dp],
+    "fem_mat_mult": [_h, _h, _h],
+    "fem_mat_get_diagonal": [_h, _h],
+    "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
+    "fem_vec_create": [_h, C.c_longlong, C.POINTER(_h)],
+    "fem_vec_destroy": [_h],
+    "fem_vec_get_size": [_h, C.POINTER(C.c_longlong)],
+    "fem_vec_set": [_h, C.c_double],
+    "fem_vec_set_array": [_h, _dp],
+    "fem_vec_get_array": [_h, _dp],
+    "fem_vec_device_ptr": [_h, C.POINTER(C.c_void_p)],
+    "fem_vec_copy": [_h, _h],
+    "fem_vec_axpy": [_h, C.c_double, _h],
+    "fem_vec_dot": [_h, _h, _dp],
+    "fem_vec_norm2": [_h, _dp],
+    "fem_form_rhs": [_h, C.c_int, _ip, _dp, C.c_int, _ip, _dp, C.c_int, _ip, _dp, C.c_double, C.c_double,
+                     C.c_double, _h],
+    "fem_ksp_create": [_h, C.POINTER(_h)],
+    "fem_ksp_destroy": [_h],
+    "fem_ksp_set_operators": [_h, _h],
+    "fem_ksp_set_type": [_h, C.c_char_p],
+    "fem_ksp_set_pc_type": [_h, C.c_char_p],
+    "fem_ksp_set_tolerances": [_h, C.c_double, C.c_double, C.c_double, C.c_int],
+    "fem_ksp_set_from_options": [_h, C.c_char_p],
+    "fem_ksp_set_up": [_h],
+    "fem_ksp_solve": [_h, _h, _h],
+    "fem_ksp_get_iteration_number": [_h, _ip],
+    "fem_ksp_get_residual_norm": [_h, _dp],
+    "fem_ksp_get_converged_reason": [_h, _ip],
+    "fem_ksp_get_residual_history": [_h, _dp, C.c_int, _ip],
+    "fem_ksp_set_profiling": [_h, C.c_int],
+    "fem_ksp_get_profile": [_h, _ip, _dp, _dp],
+    "fem_recover_nodal_stress": [_h, _h, _dp],
+    "fem_recover_nodal_stress_vec": [_h, _h, _h],
+    "fem_comm_create_self": [_h, C.POINTER(_h)],
+    "fem_comm_get_unique_id": [C.c_char_p],
+    "fem_comm_create_rccl": [_h, C.c_int, C.c_int, C.c_char_p, C.POINTER(_h)],
+    "fem_comm_create_local_group": [C.c_int, C.POINTER(_h), C.POINTER(_h)],
+    "fem_comm_destroy": [_h],
+    "fem_comm_rank": [_h, _ip, _ip],
+}
+EXPORTED = sorted(_SIGS) + ["fem_last_error"]
+for _n, _a in _SIGS.items():
+    _f = getattr(_lib, _n)
+    _f.argtypes = _a
+    _f.restype = C.c_int
+
+
+def _ck(rc: int):
+    if rc != 0:
+        raise FemError(rc, (_lib.fem_last_error() or b"").decode())
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+def _i32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a.reshape(shape) if shape is not None else a
+
+
+PENALTY_PARAM = float(np.float32(1.0e30))   # src/m_global.F90:15
+REFERENCE_RTOL = float(np.float32(1.0e-9))  # tol = 1.e-9, src/main.F90:349
+DEFAULT = -2.0
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    _ck(_lib.fem_device_count(C.byref(n)))
+    return n.value
+
+
+class Context:
+    """PetscInitialize / PetscFinalize (src/main.F90:26,333): device + stream."""
+
+    def __init__(self, device: int = 0):
+        self.h = _h()
+        _ck(_lib.fem_ctx_create(device, C.byref(self.h)))
+        self.device = device
+
+    def synchronize(self):
+        _ck(_lib.fem_ctx_synchronize(self.h))
+
+    def timer_start(self):
+        _ck(_lib.fem_ctx_timer_start(self.h))
+
+    def timer_stop(self) -> float:
+        ms = C.c_double(0)
+        _ck(_lib.fem_ctx_timer_stop(self.h, C.byref(ms)))
+        return ms.value
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_ctx_destroy(self.h))
+            self.h = _h()
+
+    # ---- module `local` / `elems` batched element API ----
+    def form_el_ke(self, eltype: int, ecoords, E, nu) -> np.ndarray:
+        """FormElKE (src/m_local.F90:21) for a batch: ecoords [nel, n, pdim] -> k [nel, nd, nd]."""
+        n, _, dim, _, _ = el_counts(eltype)
+        ec = _f64(ecoords, (-1, n, dim))
+        nel = ec.shape[0]
+        ecf = np.ascontiguousarray(ec.transpose(0, 2, 1))  # per element column-major (n, pdim)
+        Ea = np.ascontiguousarray(np.broadcast_to(np.asarray(E, dtype=np.float64), (nel,)))
+        na = np.ascontiguousarray(np.broadcast_to(np.asarray(nu, dtype=np.float64), (nel,)))
+        nd = n * dim
+        k = np.zeros((nel, nd, nd))
+        _ck(_lib.fem_form_el_ke(self.h, eltype, nel, _d(ecf), _d(Ea), _d(na), _d(k)))
+        return np.ascontiguousarray(k.transpose(0, 2, 1))  # column-major blocks -> k[e][i][j]
+
+    def calc_el_stress(self, eltype: int, ecoords, edisp, E, nu) -> np.ndarray:
+        """CalcElStress (src/m_local.F90:93): -> estress [nel, nip, cpdim]."""
+        n, nip, dim, _, _ = el_counts(eltype)
+        cp = 3 if dim == 2 else 6
+        ec = _f64(ecoords, (-1, n, dim))
+        nel = ec.shape[0]
+        ecf = np.ascontiguousarray(ec.transpose(0, 2, 1))
+        ed = _f64(edisp, (nel, n * dim))
+        Ea = np.ascontiguousarray(np.broadcast_to(np.asarray(E, dtype=np.float64), (nel,)))
+        na = np.ascontiguousarray(np.broadcast_to(np.asarray(nu, dtype=np.float64), (nel,)))
+        es = np.zeros((nel, cp, nip))
+        _ck(_lib.fem_calc_el_stress(self.h, eltype, nel, _d(ecf), _d(ed), _d(Ea), _d(na), _d(es)))
+        return np.ascontiguousarray(es.transpose(0, 2, 1))
+
+
+def el_counts(eltype: int):
+    v = [C.c_int(0) for _ in range(5)]
+    _ck(_lib.fem_el_counts(eltype, *[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def el_tables(eltype: int):
+    """Initialize (src/m_elems.F90:124): ipoints(nip,pdim), weights, shape(nip,n), n2inv(nip,n) or None."""
+    n, nip, dim, _, _ = el_counts(eltype)
+    ip = np.zeros(nip * dim); w = np.zeros(nip); shp = np.zeros(nip * n); inv = np.zeros(nip * n)
+    has = C.c_int(0)
+    _ck(_lib.fem_el_tables(eltype, _d(ip), _d(w), _d(shp), _d(inv), C.byref(has)))
+    return (ip.reshape(nip, dim, order="F"), w, shp.reshape(nip, n, order="F"),
+            inv.reshape(nip, n, order="F") if has.value else None)
+
+
+def form_el_indx(pdim: int, enodes) -> np.ndarray:
+    en = _i32(enodes)
+    out = np.zeros(len(en) * pdim, dtype=np.int32)
+    _ck(_lib.fem_form_el_indx(pdim, len(en), _i(en), _i(out)))
+    return out
+
+
+class Comm:
+    def __init__(self, h):
+        self.h = h
+
+    @staticmethod
+    def self_(ctx: Context) -> "Comm":
+        h = _h()
+        _ck(_lib.fem_comm_create_self(ctx.h, C.byref(h)))
+        return Comm(h)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _ck(_lib.fem_comm_get_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def rccl(ctx: Context, nranks: int, rank: int, uid: bytes) -> "Comm":
+        assert len(uid) == 128
+        h = _h()
+        _ck(_lib.fem_comm_create_rccl(ctx.h, nranks, rank, uid, C.byref(h)))
+        return Comm(h)
+
+    @staticmethod
+    def local_group(ctxs: list[Context]) -> list["Comm"]:
+        n = len(ctxs)
+        ca = (_h * n)(*[c.h for c in ctxs])
+        out = (_h * n)()
+        _ck(_lib.fem_comm_create_local_group(n, ca, out))
+        return [Comm(_h(out[i])) for i in range(n)]
+
+    def rank_size(self):
+        r, s = C.c_int(0), C.c_int(0)
+        _ck(_lib.fem_comm_rank(self.h, C.byref(r), C.byref(s)))
+        return r.value, s.value
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_comm_destroy(self.h))
+            self.h = _h()
+
+
+class DeviceMesh:
+    """One domain's mesh on the device (local_elements/coords/mat of src/m_global.F90)."""
+
+    def __init__(self, ctx: Context, mesh):
+        self.ctx = ctx
+        self.mesh = mesh
+        self.h = _h()
+        et, ep, cn, mi = _i32(mesh.eltype), _i32(mesh.eptr), _i32(mesh.conn), _i32(mesh.mat_id)
+        co, ma = _f64(mesh.coords), _f64(mesh.mats)
+        _ck(_lib.fem_mesh_create(ctx.h, mesh.pdim, mesh.nels, mesh.nnds, _i(et), _i(ep), _i(cn), _i(mi), _d(co),
+                                 ma.shape[0], _d(ma), C.byref(self.h)))
+
+    def set_halo(self, comm: Comm, neigh_rank, neigh_ptr, neigh_nodes):
+        nr, npx, nn = _i32(neigh_rank), _i32(neigh_ptr), _i32(neigh_nodes)
+        _ck(_lib.fem_mesh_set_halo(self.h, comm.h, len(nr), _i(nr), _i(npx), _i(nn)))
+
+    def form_rhs(self, F: "Vec", t_init: float, dt: float, mesh=None):
+        """FormRHS(t_init, dt) (src/m_global.F90:373)."""
+        m = mesh or self.mesh
+        bn, bv = _i32(m.bcnode), _f64(m.bcval)
+        fn, fv = _i32(m.fnode), _f64(m.fval)
+        te, tv = _i32(m.telsd), _f64(m.tval)
+        _ck(_lib.fem_form_rhs(self.h, bn.shape[0], _i(bn), _d(bv), fn.shape[0], _i(fn), _d(fv), te.shape[0], _i(te),
+                              _d(tv), m.t, t_init, dt, F.h))
+
+    def recover_nodal_stress(self, U: "Vec") -> np.ndarray:
+        """src/main.F90:253-292 -> stress_node [nnds, cpdim]."""
+        m = self.mesh
+        out = np.zeros(m.nnds * m.cpdim)
+        _ck(_lib.fem_recover_nodal_stress(self.h, U.h, _d(out)))
+        return out.reshape(m.nnds, m.cpdim, order="F")
+
+    def recover_nodal_stress_vec(self, U: "Vec", S: "Vec"):
+        _ck(_lib.fem_recover_nodal_stress_vec(self.h, U.h, S.h))
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_mesh_destroy(self.h))
+            self.h = _h()
+
+
+class Vec:
+    def __init__(self, ctx: Context, n: int):
+        self.ctx = ctx
+        self.n = int(n)
+        self.h = _h()
+        _ck(_lib.fem_vec_create(ctx.h, self.n, C.byref(self.h)))
+
+    def set(self, alpha: float):
+        _ck(_lib.fem_vec_set(self.h, alpha))
+
+    def zero_entries(self):
+        self.set(0.0)
+
+    def set_array(self, a):
+        a = _f64(a)
+        assert a.size == self.n
+        _ck(_lib.fem_vec_set_array(self.h, _d(a)))
+
+    def get_array(self) -> np.ndarray:
+        out = np.zeros(self.n)
+        _ck(_lib.fem_vec_get_array(self.h, _d(out)))
+        return out
+
+    def device_ptr(self) -> int:
+        p = C.c_void_p()
+        _ck(_lib.fem_vec_device_ptr(self.h, C.byref(p)))
+        return p.value or 0
+
+    def copy_to(self, other: "Vec"):
+        _ck(_lib.fem_vec_copy(self.h, other.h))
+
+    def axpy(self, a: float, x: "Vec"):
+        _ck(_lib.fem_vec_axpy(self.h, a, x.h))
+
+    def dot(self, y: "Vec") -> float:
+        d = C.c_double(0)
+        _ck(_lib.fem_vec_dot(self.h, y.h, C.byref(d)))
+        return d.value
+
+    def norm(self) -> float:
+        d = C.c_double(0)
+        _ck(_lib.fem_vec_norm2(self.h, C.byref(d)))
+        return d.value
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_vec_destroy(self.h))
+            self.h = _h()
+
+
+class Mat:
+    """Mat_K: MatCreateAIJ (src/main.F90:154) + the assembly loop (:157-171)."""
+
+    def __init__(self, dmesh: DeviceMesh):
+        self.dmesh = dmesh
+        self.h = _h()
+        _ck(_lib.fem_mat_create_aij(dmesh.h, C.byref(self.h)))
+
+    def zero_entries(self):
+        _ck(_lib.fem_mat_zero_entries(self.h))
+
+    def assemble_elements(self):
+        _ck(_lib.fem_mat_assemble_elements(self.h))
+
+    def apply_kbc(self, bcnode=None):
+        bn = _i32(self.dmesh.mesh.bcnode if bcnode is None else bcnode)
+        _ck(_lib.fem_mat_apply_kbc(self.h, bn.shape[0], _i(bn)))
+
+    def info(self):
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        _ck(_lib.fem_mat_get_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def get_csr(self):
+        nrows, nnz, _ = self.info()
+        rp = np.zeros(nrows + 1, dtype=np.int32); ci = np.zeros(nnz, dtype=np.int32); v = np.zeros(nnz)
+        _ck(_lib.fem_mat_get_csr(self.h, _i(rp), _i(ci), _d(v)))
+        return rp, ci, v
+
+    def mult(self, x: Vec, y: Vec):
+        _ck(_lib.fem_mat_mult(self.h, x.h, y.h))
+
+    def mult_timed(self, x: Vec, y: Vec, reps: int) -> float:
+        ms = C.c_double(0)
+        _ck(_lib.fem_mat_mult_timed(self.h, x.h, y.h, reps, C.byref(ms)))
+        return ms.value
+
+    def get_diagonal(self, d: Vec):
+        _ck(_lib.fem_mat_get_diagonal(self.h, d.h))
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_mat_destroy(self.h))
+            self.h = _h()
+
+
+class KSP:
+    """Krylov (SetupKSPSolver src/main.F90:339-403; KSPSolve :247)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.h = _h()
+        _ck(_lib.fem_ksp_create(ctx.h, C.byref(self.h)))
+
+    def set_operators(self, A: Mat):
+        _ck(_lib.fem_ksp_set_operators(self.h, A.h))
+
+    def set_type(self, t: str):
+        _ck(_lib.fem_ksp_set_type(self.h, t.encode()))
+
+    def set_pc_type(self, t: str):
+        _ck(_lib.fem_ksp_set_pc_type(self.h, t.encode()))
+
+    def set_tolerances(self, rtol=DEFAULT, abstol=DEFAULT, dtol=DEFAULT, max_it=-2):
+        _ck(_lib.fem_ksp_set_tolerances(self.h, rtol, abstol, dtol, max_it))
+
+    def set_from_options(self, options: str):
+        _ck(_lib.fem_ksp_set_from_options(self.h, options.encode()))
+
+    def set_up(self):
+        _ck(_lib.fem_ksp_set_up(self.h))
+
+    def solve(self, b: Vec, x: Vec):
+        _ck(_lib.fem_ksp_solve(self.h, b.h, x.h))
+
+    def get_iteration_number(self) -> int:
+        v = C.c_int(0)
+        _ck(_lib.fem_ksp_get_iteration_number(self.h, C.byref(v)))
+        return v.value
+
+    def get_residual_norm(self) -> float:
+        v = C.c_double(0)
+        _ck(_lib.fem_ksp_get_residual_norm(self.h, C.byref(v)))
+        return v.value
+
+    def get_converged_reason(self) -> int:
+        v = C.c_int(0)
+        _ck(_lib.fem_ksp_get_converged_reason(self.h, C.byref(v)))
+        return v.value
+
+    def get_residual_history(self, maxlen: int = 100001) -> np.ndarray:
+        out = np.zeros(maxlen); n = C.c_int(0)
+        _ck(_lib.fem_ksp_get_residual_history(self.h, _d(out), maxlen, C.byref(n)))
+        return out[:n.value]
+
+    def set_profiling(self, on: bool):
+        _ck(_lib.fem_ksp_set_profiling(self.h, int(on)))
+
+    def get_profile(self):
+        n = C.c_int(0); a = C.c_double(0); b = C.c_double(0)
+        _ck(_lib.fem_ksp_get_profile(self.h, C.byref(n), C.byref(a), C.byref(b)))
+        return n.value, a.value, b.value
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_ksp_destroy(self.h))
+            self.h = _h()

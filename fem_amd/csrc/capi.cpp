@@ -1,0 +1,595 @@
+// fem_amd/csrc/capi.cpp -- extern "C" surface of libfem_amd.so (include/fem_amd.h).
+// Every entry point converts C++ exceptions into PETSc-style integer error
+// codes; fem_last_error() returns the message of the calling thread's last failure.
+#include <cstring>
+
+#include "comm.h"
+#include "objects.h"
+
+using namespace fem;
+
+// implemented in the .hip translation units
+namespace fem { void upload_elem_tables(hipStream_t s); }
+fem_mesh mesh_create_impl(fem_ctx, int, int, int, const int*, const int*, const int*, const int*, const double*, int,
+                          const double*);
+void mesh_set_halo_impl(fem_mesh, fem_comm, int, const int*, const int*, const int*);
+fem_mat mat_create_impl(fem_mesh);
+void mat_assemble_elements_impl(fem_mat);
+void mat_apply_kbc_impl(fem_mat, int, const int*);
+void mat_get_csr_impl(fem_mat, int*, int*, double*);
+void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
+void mat_get_diagonal_raw(fem_mat, double*);
+void form_el_ke_impl(fem_ctx, int, int, const double*, const double*, const double*, double*);
+void calc_el_stress_impl(fem_ctx, int, int, const double*, const double*, const double*, const double*, double*);
+void recover_nodal_stress_dev(fem_mesh, const double*, double*);
+void form_rhs_impl(fem_mesh, int, const int*, const double*, int, const int*, const double*, int, const int*,
+                   const double*, double, double, double, double*);
+fem_ksp ksp_new(fem_ctx);
+void ksp_delete(fem_ksp);
+void ksp_set_operators(fem_ksp, fem_mat);
+void ksp_set_type(fem_ksp, const char*);
+void ksp_set_pc_type(fem_ksp, const char*);
+void ksp_set_tolerances(fem_ksp, double, double, double, int);
+void ksp_set_from_options_impl(fem_ksp, const char*);
+void ksp_set_up_impl(fem_ksp);
+void ksp_solve_impl(fem_ksp, fem_vec, fem_vec);
+void ksp_get_result(fem_ksp, int*, double*, int*);
+int ksp_get_history(fem_ksp, double*, int);
+void ksp_set_profiling(fem_ksp, int);
+void ksp_get_profile(fem_ksp, int*, double*, double*);
+void vec_fill(fem_vec, double);
+void vec_axpy(fem_vec, double, fem_vec);
+double vec_dot(fem_vec, fem_vec);
+fem_comm comm_create_self_impl(fem_ctx);
+void comm_get_unique_id_impl(char*);
+fem_comm comm_create_rccl_impl(fem_ctx, int, int, const char*);
+void comm_create_local_group_impl(int, const fem_ctx*, fem_comm*);
+
+namespace fem {
+static thread_local std::string g_last_error;
+void set_last_error(const std::string& m) { g_last_error = m; }
+}  // namespace fem
+
+#define FEM_TRY try {
+#define FEM_CATCH                                                              \
+    }                                                                          \
+    catch (const fem::Error& e) { fem::set_last_error(e.what()); return e.code ? e.code : 1; } \
+    catch (const std::exception& e) { fem::set_last_error(e.what()); return 99; }              \
+    return 0;
+
+extern "C" {
+
+int fem_version(void) { return 100; }
+const char* fem_last_error(void) { return fem::g_last_error.c_str(); }
+
+int fem_device_count(int* count)
+{
+    FEM_TRY
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count = n;
+    FEM_CATCH
+}
+
+int fem_ctx_create(int device, fem_ctx* out)
+{
+    FEM_TRY
+    int n = 0;
+    FEM_CHECK(hipGetDeviceCount(&n) == hipSuccess && n > 0, 50,
+              "fem_ctx_create: no HIP device available (libfem_amd has no CPU path)");
+    FEM_CHECK(device >= 0 && device < n, 50, "fem_ctx_create: device index out of range");
+    std::unique_ptr<fem_ctx_s> c(new fem_ctx_s);
+    c->device = device;
+    c->bind();
+    hipDeviceProp_t prop;
+    FEM_HIP(hipGetDeviceProperties(&prop, device));
+    c->num_cu = prop.multiProcessorCount;
+    FEM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    FEM_HIP(hipEventCreate(&c->t0));
+    FEM_HIP(hipEventCreate(&c->t1));
+    fem::upload_elem_tables(c->stream);
+    FEM_HIP(hipStreamSynchronize(c->stream));
+    *out = c.release();
+    FEM_CATCH
+}
+
+int fem_ctx_destroy(fem_ctx c)
+{
+    FEM_TRY
+    if (!c) return 0;
+    c->bind();
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    FEM_CATCH
+}
+
+int fem_ctx_synchronize(fem_ctx c)
+{
+    FEM_TRY
+    FEM_CHECK(c, 1, "null context");
+    c->bind();
+    FEM_HIP(hipStreamSynchronize(c->stream));
+    FEM_CATCH
+}
+
+int fem_ctx_timer_start(fem_ctx c)
+{
+    FEM_TRY
+    FEM_CHECK(c, 1, "null context");
+    c->bind();
+    FEM_HIP(hipEventRecord(c->t0, c->stream));
+    FEM_CATCH
+}
+
+int fem_ctx_timer_stop(fem_ctx c, double* ms)
+{
+    FEM_TRY
+    FEM_CHECK(c, 1, "null context");
+    c->bind();
+    FEM_HIP(hipEventRecord(c->t1, c->stream));
+    FEM_HIP(hipEventSynchronize(c->t1));
+    float f = 0;
+    FEM_HIP(hipEventElapsedTime(&f, c->t0, c->t1));
+    *ms = f;
+    FEM_CATCH
+}
+
+// ---- element library ------------------------------------------------------------------
+int fem_el_counts(int t, int* nodecount, int* nip, int* dim, int* nps, int* vtkid)
+{
+    FEM_TRY
+    FEM_CHECK(t >= FEM_TRI && t <= FEM_COH, 3, "fem_el_counts: unknown element type");
+    const ElemTable& tb = host_elem_tables()[t];
+    if (nodecount) *nodecount = tb.npe;
+    if (nip) *nip = tb.nip;
+    if (dim) *dim = tb.dim;
+    if (nps) *nps = tb.nps;
+    if (vtkid) *vtkid = tb.vtk;
+    FEM_CATCH
+}
+
+int fem_el_tables(int t, double* ipoints, double* weights, double* shape, double* n2inv, int* has_inv)
+{
+    FEM_TRY
+    FEM_CHECK(t >= FEM_TRI && t <= FEM_COH, 3, "fem_el_tables: unknown element type");
+    const ElemTable& tb = host_elem_tables()[t];
+    for (int g = 0; g < tb.nip; g++) {
+        if (ipoints) for (int d = 0; d < tb.dim; d++) ipoints[g + d * tb.nip] = tb.xi[g][d];
+        if (weights) weights[g] = tb.w[g];
+        if (shape) for (int a = 0; a < tb.npe; a++) shape[g + a * tb.nip] = tb.N[g][a];
+    }
+    if (n2inv && tb.has_inv)
+        for (int a = 0; a < tb.npe; a++)
+            for (int g = 0; g < tb.nip; g++) n2inv[a + g * tb.npe] = tb.n2inv[a][g];
+    if (has_inv) *has_inv = tb.has_inv;
+    FEM_CATCH
+}
+
+int fem_form_el_ke(fem_ctx ctx, int t, int nel, const double* ecoords, const double* E, const double* nu, double* k)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    form_el_ke_impl(ctx, t, nel, ecoords, E, nu, k);
+    FEM_CATCH
+}
+
+int fem_calc_el_stress(fem_ctx ctx, int t, int nel, const double* ecoords, const double* edisp, const double* E,
+                       const double* nu, double* estress)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    calc_el_stress_impl(ctx, t, nel, ecoords, edisp, E, nu, estress);
+    FEM_CATCH
+}
+
+int fem_form_el_indx(int pdim, int n, const int* enodes, int* indx)
+{
+    FEM_TRY
+    FEM_CHECK(pdim == 2 || pdim == 3, 2, "fem_form_el_indx: pdim must be 2 or 3");
+    for (int j = 0; j < n; j++)
+        for (int d = 0; d < pdim; d++) indx[pdim * j + d] = pdim * enodes[j] + d;
+    FEM_CATCH
+}
+
+// ---- mesh -----------------------------------------------------------------------------
+int fem_mesh_create(fem_ctx ctx, int pdim, int nels, int nnds, const int* eltype, const int* eptr, const int* conn,
+                    const int* mat_id, const double* coords, int nmats, const double* mats, fem_mesh* mesh)
+{
+    FEM_TRY
+    *mesh = mesh_create_impl(ctx, pdim, nels, nnds, eltype, eptr, conn, mat_id, coords, nmats, mats);
+    FEM_CATCH
+}
+
+int fem_mesh_destroy(fem_mesh m)
+{
+    FEM_TRY
+    if (m) { m->ctx->bind(); delete m; }
+    FEM_CATCH
+}
+
+int fem_mesh_set_halo(fem_mesh mesh, fem_comm comm, int nneigh, const int* neigh_rank, const int* neigh_ptr,
+                      const int* neigh_nodes)
+{
+    FEM_TRY
+    mesh_set_halo_impl(mesh, comm, nneigh, neigh_rank, neigh_ptr, neigh_nodes);
+    FEM_CATCH
+}
+
+// ---- Mat ---------------------------------------------------------------------------------
+int fem_mat_create_aij(fem_mesh mesh, fem_mat* mat)
+{
+    FEM_TRY
+    *mat = mat_create_impl(mesh);
+    FEM_CATCH
+}
+
+int fem_mat_destroy(fem_mat A)
+{
+    FEM_TRY
+    if (A) { A->ctx->bind(); delete A; }
+    FEM_CATCH
+}
+
+int fem_mat_zero_entries(fem_mat A)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    A->ctx->bind();
+    A->val.zero(A->ctx->stream);
+    FEM_CATCH
+}
+
+int fem_mat_assemble_elements(fem_mat A)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_assemble_elements_impl(A);
+    FEM_CATCH
+}
+
+int fem_mat_apply_kbc(fem_mat A, int nbcs, const int* bcnode)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_apply_kbc_impl(A, nbcs, bcnode);
+    FEM_CATCH
+}
+
+int fem_mat_get_info(fem_mat A, long long* nrows, long long* nnz, long long* device_bytes)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    if (nrows) *nrows = (long long)A->nbrows * A->bs;
+    if (nnz) *nnz = A->nblocks * A->bs * A->bs;
+    if (device_bytes) *device_bytes = (long long)(A->val.bytes() + A->bcol.bytes() + A->boff.bytes() + A->rowlen.bytes());
+    FEM_CATCH
+}
+
+int fem_mat_get_csr(fem_mat A, int* rowptr, int* colind, double* val)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_get_csr_impl(A, rowptr, colind, val);
+    FEM_CATCH
+}
+
+int fem_mat_mult(fem_mat A, fem_vec x, fem_vec y)
+{
+    FEM_TRY
+    FEM_CHECK(A && x && y, 1, "null handle");
+    const long long n = (long long)A->nbrows * A->bs;
+    FEM_CHECK(x->n == n && y->n == n && x != y, 8, "fem_mat_mult: vector size mismatch");
+    A->ctx->bind();
+    mat_mult_raw(A, x->d.p, y->d.p, nullptr, nullptr);
+    halo_sum(A->mesh, y->d.p, A->bs, A->bs, 1);
+    FEM_HIP(hipGetLastError());
+    FEM_CATCH
+}
+
+int fem_mat_mult_timed(fem_mat A, fem_vec x, fem_vec y, int reps, double* avg_ms)
+{
+    FEM_TRY
+    FEM_CHECK(A && x && y && reps > 0, 1, "bad arguments");
+    const long long n = (long long)A->nbrows * A->bs;
+    FEM_CHECK(x->n == n && y->n == n && x != y, 8, "fem_mat_mult_timed: vector size mismatch");
+    fem_ctx c = A->ctx;
+    c->bind();
+    mat_mult_raw(A, x->d.p, y->d.p, A->spmv_partial.p, nullptr);  // warm-up
+    FEM_HIP(hipEventRecord(c->t0, c->stream));
+    for (int i = 0; i < reps; i++) mat_mult_raw(A, x->d.p, y->d.p, A->spmv_partial.p, nullptr);
+    FEM_HIP(hipEventRecord(c->t1, c->stream));
+    FEM_HIP(hipEventSynchronize(c->t1));
+    float ms = 0;
+    FEM_HIP(hipEventElapsedTime(&ms, c->t0, c->t1));
+    *avg_ms = ms / reps;
+    FEM_CATCH
+}
+
+int fem_mat_get_diagonal(fem_mat A, fem_vec d)
+{
+    FEM_TRY
+    FEM_CHECK(A && d && d->n == (long long)A->nbrows * A->bs, 8, "fem_mat_get_diagonal: size mismatch");
+    A->ctx->bind();
+    mat_get_diagonal_raw(A, d->d.p);
+    halo_sum(A->mesh, d->d.p, A->bs, A->bs, 1);
+    FEM_HIP(hipGetLastError());
+    FEM_CATCH
+}
+
+// ---- Vec ---------------------------------------------------------------------------------
+int fem_vec_create(fem_ctx ctx, long long n, fem_vec* v)
+{
+    FEM_TRY
+    FEM_CHECK(ctx && n >= 0, 1, "fem_vec_create: bad arguments");
+    ctx->bind();
+    std::unique_ptr<fem_vec_s> x(new fem_vec_s);
+    x->ctx = ctx; x->n = n;
+    x->d.alloc((size_t)std::max<long long>(n, 1));
+    x->d.zero(ctx->stream);
+    *v = x.release();
+    FEM_CATCH
+}
+
+int fem_vec_destroy(fem_vec v)
+{
+    FEM_TRY
+    if (v) { v->ctx->bind(); delete v; }
+    FEM_CATCH
+}
+
+int fem_vec_get_size(fem_vec v, long long* n)
+{
+    FEM_TRY
+    FEM_CHECK(v, 1, "null vector");
+    *n = v->n;
+    FEM_CATCH
+}
+
+int fem_vec_set(fem_vec v, double alpha)
+{
+    FEM_TRY
+    FEM_CHECK(v, 1, "null vector");
+    vec_fill(v, alpha);
+    FEM_CATCH
+}
+
+int fem_vec_set_array(fem_vec v, const double* host)
+{
+    FEM_TRY
+    FEM_CHECK(v && host, 1, "null argument");
+    v->ctx->bind();
+    v->d.upload(host, (size_t)v->n, v->ctx->stream);
+    FEM_HIP(hipStreamSynchronize(v->ctx->stream));
+    FEM_CATCH
+}
+
+int fem_vec_get_array(fem_vec v, double* host)
+{
+    FEM_TRY
+    FEM_CHECK(v && host, 1, "null argument");
+    v->ctx->bind();
+    v->d.download(host, (size_t)v->n, v->ctx->stream);
+    FEM_HIP(hipStreamSynchronize(v->ctx->stream));
+    FEM_CATCH
+}
+
+int fem_vec_device_ptr(fem_vec v, void** dptr)
+{
+    FEM_TRY
+    FEM_CHECK(v, 1, "null vector");
+    *dptr = v->d.p;
+    FEM_CATCH
+}
+
+int fem_vec_copy(fem_vec src, fem_vec dst)
+{
+    FEM_TRY
+    FEM_CHECK(src && dst && src->n == dst->n, 8, "fem_vec_copy: size mismatch");
+    src->ctx->bind();
+    FEM_HIP(hipMemcpyAsync(dst->d.p, src->d.p, sizeof(double) * (size_t)src->n, hipMemcpyDeviceToDevice,
+                           src->ctx->stream));
+    FEM_CATCH
+}
+
+int fem_vec_axpy(fem_vec y, double a, fem_vec x)
+{
+    FEM_TRY
+    FEM_CHECK(x && y && x->n == y->n, 8, "fem_vec_axpy: size mismatch");
+    vec_axpy(y, a, x);
+    FEM_CATCH
+}
+
+int fem_vec_dot(fem_vec x, fem_vec y, double* dot)
+{
+    FEM_TRY
+    FEM_CHECK(x && y && x->n == y->n, 8, "fem_vec_dot: size mismatch");
+    *dot = vec_dot(x, y);
+    FEM_CATCH
+}
+
+int fem_vec_norm2(fem_vec x, double* nrm)
+{
+    FEM_TRY
+    FEM_CHECK(x, 1, "null vector");
+    *nrm = std::sqrt(vec_dot(x, x));
+    FEM_CATCH
+}
+
+// ---- RHS ---------------------------------------------------------------------------------
+int fem_form_rhs(fem_mesh mesh, int nbcs, const int* bcnode, const double* bcval, int nfrcs, const int* fnode,
+                 const double* fval, int ntrcs, const int* telsd, const double* tval, double t_total, double t_init,
+                 double dt, fem_vec F)
+{
+    FEM_TRY
+    FEM_CHECK(mesh && F && F->n == (long long)mesh->nnds * mesh->pdim, 8, "fem_form_rhs: vector size mismatch");
+    form_rhs_impl(mesh, nbcs, bcnode, bcval, nfrcs, fnode, fval, ntrcs, telsd, tval, t_total, t_init, dt, F->d.p);
+    FEM_CATCH
+}
+
+// ---- KSP ---------------------------------------------------------------------------------
+int fem_ksp_create(fem_ctx ctx, fem_ksp* ksp)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    *ksp = ksp_new(ctx);
+    FEM_CATCH
+}
+int fem_ksp_destroy(fem_ksp k)
+{
+    FEM_TRY
+    if (k) ksp_delete(k);
+    FEM_CATCH
+}
+int fem_ksp_set_operators(fem_ksp k, fem_mat A)
+{
+    FEM_TRY
+    FEM_CHECK(k && A, 1, "null handle");
+    ksp_set_operators(k, A);
+    FEM_CATCH
+}
+int fem_ksp_set_type(fem_ksp k, const char* t)
+{
+    FEM_TRY
+    FEM_CHECK(k, 1, "null handle");
+    ksp_set_type(k, t);
+    FEM_CATCH
+}
+int fem_ksp_set_pc_type(fem_ksp k, const char* t)
+{
+    FEM_TRY
+    FEM_CHECK(k, 1, "null handle");
+    ksp_set_pc_type(k, t);
+    FEM_CATCH
+}
+int fem_ksp_set_tolerances(fem_ksp k, double rtol, double abstol, double dtol, int maxits)
+{
+    FEM_TRY
+    FEM_CHECK(k, 1, "null handle");
+    ksp_set_tolerances(k, rtol, abstol, dtol, maxits);
+    FEM_CATCH
+}
+int fem_ksp_set_from_options(fem_ksp k, const char* options)
+{
+    FEM_TRY
+    FEM_CHECK(k, 1, "null handle");
+    ksp_set_from_options_impl(k, options);
+    FEM_CATCH
+}
+int fem_ksp_set_up(fem_ksp k)
+{
+    FEM_TRY
+    FEM_CHECK(k, 1, "null handle");
+    ksp_set_up_impl(k);
+    FEM_CATCH
+}
+int fem_ksp_solve(fem_ksp k, fem_vec b, fem_vec x)
+{
+    FEM_TRY
+    FEM_CHECK(k, 1, "null handle");
+    ksp_solve_impl(k, b, x);
+    FEM_CATCH
+}
+int fem_ksp_get_iteration_number(fem_ksp k, int* its)
+{
+    FEM_TRY
+    ksp_get_result(k, its, nullptr, nullptr);
+    FEM_CATCH
+}
+int fem_ksp_get_residual_norm(fem_ksp k, double* rnorm)
+{
+    FEM_TRY
+    ksp_get_result(k, nullptr, rnorm, nullptr);
+    FEM_CATCH
+}
+int fem_ksp_get_converged_reason(fem_ksp k, int* reason)
+{
+    FEM_TRY
+    ksp_get_result(k, nullptr, nullptr, reason);
+    FEM_CATCH
+}
+int fem_ksp_get_residual_history(fem_ksp k, double* hist, int len, int* n)
+{
+    FEM_TRY
+    *n = ksp_get_history(k, hist, len);
+    FEM_CATCH
+}
+int fem_ksp_set_profiling(fem_ksp k, int on)
+{
+    FEM_TRY
+    ksp_set_profiling(k, on);
+    FEM_CATCH
+}
+int fem_ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_ms)
+{
+    FEM_TRY
+    ksp_get_profile(k, n_spmv, spmv_ms, solve_ms);
+    FEM_CATCH
+}
+
+// ---- nodal stress -------------------------------------------------------------------------
+int fem_recover_nodal_stress_vec(fem_mesh mesh, fem_vec U, fem_vec S)
+{
+    FEM_TRY
+    FEM_CHECK(mesh && U && S, 1, "null handle");
+    FEM_CHECK(U->n == (long long)mesh->nnds * mesh->pdim && S->n == (long long)mesh->nnds * mesh->cpdim, 8,
+              "fem_recover_nodal_stress: vector size mismatch");
+    recover_nodal_stress_dev(mesh, U->d.p, S->d.p);
+    FEM_CATCH
+}
+
+int fem_recover_nodal_stress(fem_mesh mesh, fem_vec U, double* stress_node)
+{
+    FEM_TRY
+    FEM_CHECK(mesh && U && stress_node, 1, "null argument");
+    FEM_CHECK(U->n == (long long)mesh->nnds * mesh->pdim, 8, "fem_recover_nodal_stress: vector size mismatch");
+    mesh->ctx->bind();
+    DBuf<double> S((size_t)mesh->nnds * mesh->cpdim);
+    recover_nodal_stress_dev(mesh, U->d.p, S.p);
+    S.download(stress_node, S.n, mesh->ctx->stream);
+    FEM_HIP(hipStreamSynchronize(mesh->ctx->stream));
+    FEM_CATCH
+}
+
+// ---- communicators ------------------------------------------------------------------------
+int fem_comm_create_self(fem_ctx ctx, fem_comm* comm)
+{
+    FEM_TRY
+    *comm = comm_create_self_impl(ctx);
+    FEM_CATCH
+}
+int fem_comm_get_unique_id(char unique_id[128])
+{
+    FEM_TRY
+    comm_get_unique_id_impl(unique_id);
+    FEM_CATCH
+}
+int fem_comm_create_rccl(fem_ctx ctx, int nranks, int rank, const char unique_id[128], fem_comm* comm)
+{
+    FEM_TRY
+    *comm = comm_create_rccl_impl(ctx, nranks, rank, unique_id);
+    FEM_CATCH
+}
+int fem_comm_create_local_group(int n, const fem_ctx* ctxs, fem_comm* comms)
+{
+    FEM_TRY
+    comm_create_local_group_impl(n, ctxs, comms);
+    FEM_CATCH
+}
+int fem_comm_destroy(fem_comm c)
+{
+    FEM_TRY
+    if (c) { delete c->impl; delete c; }
+    FEM_CATCH
+}
+int fem_comm_rank(fem_comm c, int* rank, int* size)
+{
+    FEM_TRY
+    FEM_CHECK(c && c->impl, 1, "null communicator");
+    if (rank) *rank = c->impl->rank;
+    if (size) *size = c->impl->size;
+    FEM_CATCH
+}
+
+}  // extern "C"

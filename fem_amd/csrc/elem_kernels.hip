@@ -1,0 +1,512 @@
+// fem_amd/csrc/elem_kernels.hip -- the element hot loops as HIP kernels:
+//   * FormElKE + scatter-add into Mat_K  (src/m_local.F90:21-67, src/main.F90:157-168)
+//   * CalcElStress + RecoverNodalStress   (src/m_local.F90:93-123, src/m_global.F90:466-515)
+//   * FormRHS                             (src/m_global.F90:373-455)
+//
+// Work decomposition (one workgroup = ELB consecutive elements of one type):
+//   phase 1  thread = (element, Gauss point): gathers the element's node
+//            coordinates, forms J, det J and dN/dx (FormdNdetJ) and parks
+//            {dN/dx, w*detJ} in LDS, element index fastest (conflict-free).
+//   phase 2  thread = (element, node a): owns block row a of the element matrix,
+//            K_ab = sum_gp w detJ B_a^T D B_b, written as the closed form of the
+//            isotropic D (no explicit zeros of B are multiplied), and adds each
+//            bs x bs block into the sliced-ELL matrix through the precomputed
+//            slot map.  Lanes of a wavefront are consecutive elements, whose
+//            rows are consecutive nodes on structured numberings, so each
+//            wave-level fp64 atomic touches contiguous 256/512-byte segments.
+// The kernels are scatter-bound (fp64 atomics), not flop-bound: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include "comm.h"
+#include "objects.h"
+
+using namespace fem;
+
+namespace fem {
+
+__constant__ ElemTable c_tab[6];
+
+void upload_elem_tables(hipStream_t s)
+{
+    FEM_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(c_tab), host_elem_tables(), sizeof(ElemTable) * 6, 0,
+                                   hipMemcpyHostToDevice, s));
+}
+
+// ---- coordinate / displacement sources -----------------------------------------------
+template <int PD, int NPE>
+struct MeshSrc {  // connectivity + shared coordinate array
+    const int* conn;
+    const double* coords;
+    __device__ __forceinline__ void coordsOf(size_t e, double (&X)[NPE][PD]) const {
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+            const size_t v = (size_t)conn[e * NPE + a];
+#pragma unroll
+            for (int d = 0; d < PD; d++) X[a][d] = coords[v * PD + d];
+        }
+    }
+};
+template <int PD, int NPE>
+struct DenseSrc {  // caller-supplied ecoords(nodecount,pdim) per element, column-major
+    const double* ecoords;
+    __device__ __forceinline__ void coordsOf(size_t e, double (&X)[NPE][PD]) const {
+#pragma unroll
+        for (int a = 0; a < NPE; a++)
+#pragma unroll
+            for (int d = 0; d < PD; d++) X[a][d] = ecoords[e * NPE * PD + a + d * NPE];
+    }
+};
+
+// ---- sinks for the element matrix ---------------------------------------------------------
+template <int PD, int NPE>
+struct MatSink {  // MatSetValues(ADD_VALUES) into the sliced block-ELL Mat_K
+    const int* conn;
+    const uint16_t* slot;
+    const int* boff;
+    double* val;
+    __device__ __forceinline__ void add(size_t e, int a, int b, const double (&blk)[PD][PD]) const {
+        const int row = conn[e * NPE + a];
+        const size_t j = (size_t)boff[row >> 6] + slot[e * NPE * NPE + a * NPE + b];
+        double* p = val + j * (PD * PD) * 64 + (row & 63);
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int q = 0; q < PD; q++) unsafeAtomicAdd(p + (size_t)(i * PD + q) * 64, blk[i][q]);
+    }
+};
+template <int PD, int NPE>
+struct DenseSink {  // k(nd,nd) column-major per element (FormElKE's out-argument)
+    double* k;
+    __device__ __forceinline__ void add(size_t e, int a, int b, const double (&blk)[PD][PD]) const {
+        constexpr int ND = NPE * PD;
+        double* p = k + e * ND * ND;
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int q = 0; q < PD; q++) p[(a * PD + i) + (size_t)(b * PD + q) * ND] = blk[i][q];
+    }
+};
+
+// ---- element stiffness ----------------------------------------------------------------------
+template <int PD, int NPE, int NIP, int ELB, class Src, class Sink>
+__global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
+    k_form_ke(int type, int nel, Src src, const double* __restrict__ Ev, const double* __restrict__ nuv, Sink sink)
+{
+    constexpr int K = NPE * PD + 1;
+    __shared__ double G[NIP * K * ELB];
+    const int t = threadIdx.x, el = t % ELB, q = t / ELB;
+    const size_t e = (size_t)blockIdx.x * ELB + el;
+    const ElemTable& tab = c_tab[type];
+    if (q < NIP && e < (size_t)nel) {
+        double X[NPE][PD], dN[NPE][PD], detj;
+        src.coordsOf(e, X);
+        dndx_at_gp<PD, NPE>(tab.dNxi[q], X, dN, detj);
+#pragma unroll
+        for (int a = 0; a < NPE; a++)
+#pragma unroll
+            for (int d = 0; d < PD; d++) G[(q * K + a * PD + d) * ELB + el] = dN[a][d];
+        G[(q * K + K - 1) * ELB + el] = tab.w[q] * detj;  // weights(i)*detj, src/m_local.F90:64
+    }
+    __syncthreads();
+    if (q >= NPE || e >= (size_t)nel) return;
+    const DCoef D = dmat_coef(Ev[e], nuv[e]);
+    double da[NIP][PD];  // w*detJ * dN_a/dx at every Gauss point
+#pragma unroll
+    for (int g = 0; g < NIP; g++) {
+        const double w = G[(g * K + K - 1) * ELB + el];
+#pragma unroll
+        for (int d = 0; d < PD; d++) da[g][d] = w * G[(g * K + q * PD + d) * ELB + el];
+    }
+#pragma unroll 1
+    for (int b = 0; b < NPE; b++) {
+        double blk[PD][PD];
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int j = 0; j < PD; j++) blk[i][j] = 0.0;
+#pragma unroll
+        for (int g = 0; g < NIP; g++) {
+            double db[PD], prod[PD], dot = 0.0;
+#pragma unroll
+            for (int d = 0; d < PD; d++) {
+                db[d] = G[(g * K + b * PD + d) * ELB + el];
+                prod[d] = da[g][d] * db[d];
+                dot += prod[d];
+            }
+            // B_a^T D B_b with D = {d11 on the normal diagonal, d12 off-diagonal, d44 shear}
+#pragma unroll
+            for (int i = 0; i < PD; i++)
+#pragma unroll
+                for (int j = 0; j < PD; j++)
+                    blk[i][j] += (i == j) ? D.d11 * prod[i] + D.d44 * (dot - prod[i])
+                                          : D.d12 * da[g][i] * db[j] + D.d44 * da[g][j] * db[i];
+        }
+        sink.add(e, q, b, blk);
+    }
+}
+
+// ---- stresses --------------------------------------------------------------------------------
+template <int PD, int NPE>
+struct MeshU {  // increment displacement gathered through the connectivity (uu(indx), src/m_global.F90:483)
+    const int* conn;
+    const double* U;
+    __device__ __forceinline__ void dispOf(size_t e, double (&u)[NPE][PD]) const {
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+            const size_t v = (size_t)conn[e * NPE + a];
+#pragma unroll
+            for (int d = 0; d < PD; d++) u[a][d] = U[v * PD + d];
+        }
+    }
+};
+template <int PD, int NPE>
+struct DenseU {
+    const double* edisp;
+    __device__ __forceinline__ void dispOf(size_t e, double (&u)[NPE][PD]) const {
+#pragma unroll
+        for (int a = 0; a < NPE; a++)
+#pragma unroll
+            for (int d = 0; d < PD; d++) u[a][d] = edisp[e * NPE * PD + a * PD + d];
+    }
+};
+
+// sigma = D * (B u) at one Gauss point (CalcElStress body, src/m_local.F90:114-120)
+template <int PD, int NPE>
+__device__ __forceinline__ void gp_stress(const double (&dN)[NPE][PD], const double (&u)[NPE][PD], const DCoef& D,
+                                          double (&sig)[PD == 2 ? 3 : 6])
+{
+    if constexpr (PD == 2) {
+        double exx = 0, eyy = 0, gxy = 0;
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+            exx += dN[a][0] * u[a][0];
+            eyy += dN[a][1] * u[a][1];
+            gxy += dN[a][1] * u[a][0] + dN[a][0] * u[a][1];
+        }
+        sig[0] = D.d11 * exx + D.d12 * eyy;
+        sig[1] = D.d12 * exx + D.d11 * eyy;
+        sig[2] = D.d44 * gxy;
+    } else {  // Voigt order xx, yy, zz, xy, yz, zx (BMat, src/m_local.F90:160-168)
+        double exx = 0, eyy = 0, ezz = 0, gxy = 0, gyz = 0, gzx = 0;
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+            exx += dN[a][0] * u[a][0];
+            eyy += dN[a][1] * u[a][1];
+            ezz += dN[a][2] * u[a][2];
+            gxy += dN[a][1] * u[a][0] + dN[a][0] * u[a][1];
+            gyz += dN[a][2] * u[a][1] + dN[a][1] * u[a][2];
+            gzx += dN[a][2] * u[a][0] + dN[a][0] * u[a][2];
+        }
+        sig[0] = D.d11 * exx + D.d12 * eyy + D.d12 * ezz;
+        sig[1] = D.d12 * exx + D.d11 * eyy + D.d12 * ezz;
+        sig[2] = D.d12 * exx + D.d12 * eyy + D.d11 * ezz;
+        sig[3] = D.d44 * gxy;
+        sig[4] = D.d44 * gyz;
+        sig[5] = D.d44 * gzx;
+    }
+}
+
+// NODAL = false: write Gauss-point stresses estress(nip,cpdim) per element (CalcElStress).
+// NODAL = true : extrapolate to the nodes with N2^-1 (RecoverNodalStress) and
+//                add into stress_node(nnds,cpdim) (column-major, as the reference).
+template <int PD, int NPE, int NIP, int ELB, bool NODAL, class Src, class USrc>
+__global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
+    k_stress(int type, int nel, Src src, USrc usrc, const double* __restrict__ Ev, const double* __restrict__ nuv,
+             const int* __restrict__ conn, double* __restrict__ out, size_t nn)
+{
+    constexpr int CP = (PD == 2) ? 3 : 6;
+    __shared__ double S[NODAL ? NIP * CP * ELB : 1];
+    const int t = threadIdx.x, el = t % ELB, q = t / ELB;
+    const size_t e = (size_t)blockIdx.x * ELB + el;
+    const ElemTable& tab = c_tab[type];
+    if (q < NIP && e < (size_t)nel) {
+        double X[NPE][PD], u[NPE][PD], dN[NPE][PD], detj, sig[CP];
+        src.coordsOf(e, X);
+        usrc.dispOf(e, u);
+        dndx_at_gp<PD, NPE>(tab.dNxi[q], X, dN, detj);
+        gp_stress<PD, NPE>(dN, u, dmat_coef(Ev[e], nuv[e]), sig);
+        if constexpr (NODAL) {
+#pragma unroll
+            for (int c = 0; c < CP; c++) S[(q * CP + c) * ELB + el] = sig[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < CP; c++) out[e * NIP * CP + q + c * NIP] = sig[c];
+        }
+    }
+    if constexpr (NODAL) {
+        __syncthreads();
+        if (q >= NPE || e >= (size_t)nel) return;
+        const size_t v = (size_t)conn[e * NPE + q];
+#pragma unroll
+        for (int c = 0; c < CP; c++) {
+            double sn;
+            if constexpr (NIP == NPE) {  // sigma_node = N2^-1 sigma_gp, src/m_global.F90:506-509
+                sn = 0.0;
+#pragma unroll
+                for (int g = 0; g < NIP; g++) sn += tab.n2inv[q][g] * S[(g * CP + c) * ELB + el];
+            } else {  // nip == 1: copy, src/m_global.F90:510-513
+                sn = S[c * ELB + el];
+            }
+            unsafeAtomicAdd(out + (size_t)c * nn + v, sn);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_divide_by_valence(size_t nn, int cp, double* __restrict__ s,
+                                                           const double* __restrict__ valence)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tot = nn * cp, st = (size_t)gridDim.x * blockDim.x;
+    for (; i < tot; i += st) s[i] /= valence[i % nn];  // stress_node(i,:)/global_count_node, src/main.F90:277-279
+}
+
+// ---- FormRHS -------------------------------------------------------------------------------------
+// nodal forces ramped over [t1,t2] (src/m_global.F90:400-411, ApplyNodalForce_All :302-322)
+__global__ void __launch_bounds__(256) k_rhs_forces(int nfrcs, int pd, const int* __restrict__ fnode,
+                                                    const double* __restrict__ fval, double t_init, double t_end,
+                                                    double* __restrict__ F)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nfrcs) return;
+    const double* fv = fval + (size_t)i * (pd + 2);
+    const double t1 = fv[pd], t2 = fv[pd + 1];
+    if (t_end < t1 || t_init > t2) return;
+    const double applied = fmin(t2, t_end) - fmax(t1, t_init);
+    for (int d = 0; d < pd; d++) unsafeAtomicAdd(F + (size_t)pd * fnode[i] + d, fv[d] * applied / (t2 - t1));
+}
+
+__device__ inline double det3(double a11, double a21, double a31, double a12, double a22, double a32, double a13,
+                              double a23, double a33)
+{  // MatDet, src/m_utils.F90:60-66
+    return a11 * (a22 * a33 - a23 * a32) - a12 * (a21 * a33 - a23 * a31) + a13 * (a21 * a32 - a22 * a31);
+}
+__device__ inline double tri_area(const double* p1, const double* p2, const double* p3)
+{  // TriArea, src/m_utils.F90:25-33
+    const double d1 = det3(p1[0], p2[0], p3[0], p1[1], p2[1], p3[1], 1, 1, 1);
+    const double d2 = det3(p1[1], p2[1], p3[1], p1[2], p2[2], p3[2], 1, 1, 1);
+    const double d3 = det3(p1[2], p2[2], p3[2], p1[0], p2[0], p3[0], 1, 1, 1);
+    return 0.5 * sqrt(fabs(d1) * fabs(d1) + fabs(d2) * fabs(d2) + fabs(d3) * fabs(d3));
+}
+
+// tractions: lumped area/nps on the side's nodes (ApplyTraction src/m_global.F90:343-370,
+// EdgeAreaNodes* src/m_elems.F90:282,366,469,583).  tnodes[i][8] = the element's nodes.
+__global__ void __launch_bounds__(256) k_rhs_tractions(int ntrcs, int pd, const int* __restrict__ ttype,
+                                                       const int* __restrict__ tnodes, const int* __restrict__ tside,
+                                                       const double* __restrict__ tval,
+                                                       const double* __restrict__ coords, double t_init, double t_end,
+                                                       double dt, double* __restrict__ F)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ntrcs) return;
+    const double* tv = tval + (size_t)i * (pd + 2);
+    // the traction window is divided by dt (src/m_global.F90:414-415), the force window is not
+    const double t1 = tv[pd] / dt, t2 = tv[pd + 1] / dt;
+    if (t_end < t1 || t_init > t2) return;
+    const double applied = fmin(t2, t_end) - fmax(t1, t_init);
+    const int type = ttype[i], side = tside[i];
+    const int* en = tnodes + (size_t)i * 8;
+    int j[4] = {0, 0, 0, 0}, nps = 2;
+    if (type == FEM_TRI) { j[0] = side - 1; j[1] = side % 3; }
+    else if (type == FEM_QUA) { j[0] = side - 1; j[1] = side % 4; }
+    else if (type == FEM_TET) {
+        const int f[4][3] = {{0, 1, 3}, {1, 2, 3}, {0, 2, 3}, {0, 1, 2}};
+        nps = 3;
+        for (int k = 0; k < 3; k++) j[k] = f[side - 1][k];
+    } else {
+        const int f[6][4] = {{0, 1, 5, 4}, {1, 2, 6, 5}, {2, 3, 7, 6}, {3, 0, 4, 7}, {0, 1, 2, 3}, {4, 5, 6, 7}};
+        nps = 4;
+        for (int k = 0; k < 4; k++) j[k] = f[side - 1][k];
+    }
+    double P[4][3];
+    for (int k = 0; k < nps; k++)
+        for (int d = 0; d < 3; d++) P[k][d] = (d < pd) ? coords[(size_t)en[j[k]] * pd + d] : 0.0;
+    double area;
+    if (nps == 2) {
+        const double dx = P[0][0] - P[1][0], dy = P[0][1] - P[1][1];
+        area = sqrt(dx * dx + dy * dy);
+    } else if (nps == 3) {
+        area = tri_area(P[0], P[1], P[2]);
+    } else {  // QuadArea, src/m_utils.F90:36-42
+        area = fabs(tri_area(P[0], P[1], P[2])) + fabs(tri_area(P[0], P[2], P[3]));
+    }
+    for (int d = 0; d < pd; d++) {
+        const double vv = tv[d] * (applied / (t2 - t1)) * area / (double)nps;
+        for (int k = 0; k < nps; k++) unsafeAtomicAdd(F + (size_t)pd * en[j[k]] + d, vv);
+    }
+}
+
+// EnforceBCForce (src/m_global.F90:439-455): INSERT PENALTY*val*dt/t on constrained dofs
+__global__ void __launch_bounds__(256) k_rhs_bc(int nbcs, int pd, const int* __restrict__ bcnode,
+                                                const double* __restrict__ bcval, double dt, double t_total,
+                                                double* __restrict__ F)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbcs) return;
+    const int node = bcnode[(size_t)i * (1 + pd)];
+    for (int d = 0; d < pd; d++)
+        if (bcnode[(size_t)i * (1 + pd) + 1 + d] == 0)
+            F[(size_t)pd * node + d] = PENALTY_PARAM * bcval[(size_t)i * pd + d] * dt / t_total;  // left to right, as :451
+}
+
+}  // namespace fem
+
+// ---- launch helpers -------------------------------------------------------------------------------
+
+template <int PD, int NPE, int NIP, int ELB, class Src, class Sink>
+static void launch_ke(int type, int nel, Src src, const double* E, const double* nu, Sink sink, hipStream_t s)
+{
+    if (nel <= 0) return;
+    constexpr int TPB = ELB * (NIP > NPE ? NIP : NPE);
+    hipLaunchKernelGGL((k_form_ke<PD, NPE, NIP, ELB, Src, Sink>), dim3(cdiv(nel, ELB)), dim3(TPB), 0, s, type, nel, src, E,
+                       nu, sink);
+}
+
+template <class F>
+static void dispatch_type(int type, F&& f)
+{
+    switch (type) {
+    case FEM_TRI: f(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{},
+                    std::integral_constant<int, 64>{}); break;
+    case FEM_QUA: f(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{},
+                    std::integral_constant<int, 64>{}); break;
+    case FEM_TET: f(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{},
+                    std::integral_constant<int, 64>{}); break;
+    case FEM_HEX: f(std::integral_constant<int, 3>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{},
+                    std::integral_constant<int, 32>{}); break;
+    default: throw Error(3, "unsupported element type " + std::to_string(type));
+    }
+}
+
+// main.F90:157-168 for the whole mesh
+void mat_assemble_elements_impl(fem_mat A)
+{
+    fem_mesh m = A->mesh;
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    for (auto& g : m->groups) {
+        FEM_CHECK(g.slot.p, 5, "fem_mat_assemble_elements: matrix pattern was not built for this mesh");
+        dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto ELB) {
+            launch_ke<PD(), NPE(), NIP(), ELB()>(g.type, g.nel, MeshSrc<PD(), NPE()>{g.conn.p, m->coords.p}, g.E.p,
+                                                 g.nu.p, MatSink<PD(), NPE()>{g.conn.p, g.slot.p, A->boff.p, A->val.p},
+                                                 s);
+        });
+    }
+    FEM_HIP(hipGetLastError());
+}
+
+// FormElKE for a batch of elements given by their coordinates (host in/out)
+void form_el_ke_impl(fem_ctx ctx, int type, int nel, const double* ecoords, const double* E, const double* nu, double* k)
+{
+    if (nel <= 0) return;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int npe = type_npe(type), pd = type_dim(type), nd = npe * pd;
+    FEM_CHECK(type >= FEM_TRI && type <= FEM_HEX, 3, "fem_form_el_ke: unsupported element type");
+    DBuf<double> dX((size_t)nel * npe * pd), dE(nel), dnu(nel), dK((size_t)nel * nd * nd);
+    dX.upload(ecoords, dX.n, s); dE.upload(E, nel, s); dnu.upload(nu, nel, s);
+    dispatch_type(type, [&](auto PD, auto NPE, auto NIP, auto ELB) {
+        launch_ke<PD(), NPE(), NIP(), ELB()>(type, nel, DenseSrc<PD(), NPE()>{dX.p}, dE.p, dnu.p,
+                                             DenseSink<PD(), NPE()>{dK.p}, s);
+    });
+    FEM_HIP(hipGetLastError());
+    dK.download(k, dK.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
+void calc_el_stress_impl(fem_ctx ctx, int type, int nel, const double* ecoords, const double* edisp, const double* E,
+                         const double* nu, double* estress)
+{
+    if (nel <= 0) return;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    FEM_CHECK(type >= FEM_TRI && type <= FEM_HEX, 3, "fem_calc_el_stress: unsupported element type");
+    const int npe = type_npe(type), pd = type_dim(type), nip = type_nip(type), cp = (pd == 2) ? 3 : 6;
+    DBuf<double> dX((size_t)nel * npe * pd), dU((size_t)nel * npe * pd), dE(nel), dnu(nel), dS((size_t)nel * nip * cp);
+    dX.upload(ecoords, dX.n, s); dU.upload(edisp, dU.n, s); dE.upload(E, nel, s); dnu.upload(nu, nel, s);
+    dispatch_type(type, [&](auto PD, auto NPE, auto NIP, auto ELB) {
+        constexpr int TPB = ELB() * (NIP() > NPE() ? NIP() : NPE());
+        hipLaunchKernelGGL((k_stress<PD(), NPE(), NIP(), ELB(), false, DenseSrc<PD(), NPE()>, DenseU<PD(), NPE()>>),
+                           dim3(cdiv(nel, ELB())), dim3(TPB), 0, s, type, nel, DenseSrc<PD(), NPE()>{dX.p},
+                           DenseU<PD(), NPE()>{dU.p}, dE.p, dnu.p, (const int*)nullptr, dS.p, (size_t)0);
+    });
+    FEM_HIP(hipGetLastError());
+    dS.download(estress, dS.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
+// main.F90:253-292 on the device: S(nnds,cpdim) column-major
+void recover_nodal_stress_dev(fem_mesh m, const double* U, double* S)
+{
+    fem_ctx ctx = m->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const size_t nn = (size_t)m->nnds;
+    FEM_HIP(hipMemsetAsync(S, 0, sizeof(double) * nn * m->cpdim, s));
+    for (auto& g : m->groups) {
+        dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto ELB) {
+            constexpr int TPB = ELB() * (NIP() > NPE() ? NIP() : NPE());
+            hipLaunchKernelGGL((k_stress<PD(), NPE(), NIP(), ELB(), true, MeshSrc<PD(), NPE()>, MeshU<PD(), NPE()>>),
+                               dim3(cdiv(g.nel, ELB())), dim3(TPB), 0, s, g.type, g.nel,
+                               MeshSrc<PD(), NPE()>{g.conn.p, m->coords.p}, MeshU<PD(), NPE()>{g.conn.p, U}, g.E.p,
+                               g.nu.p, g.conn.p, S, nn);
+        });
+    }
+    // cross-domain sum of the partial nodal sums (replaces Mat_Stress ADD + assembly, src/main.F90:286-289)
+    halo_sum(m, S, m->cpdim, 1, nn);
+    hipLaunchKernelGGL(k_divide_by_valence, dim3(std::min<unsigned>(cdiv(nn * m->cpdim, 256), 8192)), dim3(256), 0, s, nn,
+                       m->cpdim, S, m->valence_d.p);
+    FEM_HIP(hipGetLastError());
+}
+
+void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval, int nfrcs, const int* fnode,
+                   const double* fval, int ntrcs, const int* telsd, const double* tval, double t_total, double t_init,
+                   double dt, double* F)
+{
+    fem_ctx ctx = m->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int pd = m->pdim;
+    const double t_end = t_init + dt;
+    FEM_HIP(hipMemsetAsync(F, 0, sizeof(double) * (size_t)m->nnds * pd, s));
+    DBuf<int> d_fnode, d_bc, d_tt, d_tn, d_ts;
+    DBuf<double> d_fval, d_bcval, d_tval;
+    if (nfrcs > 0) {
+        for (int i = 0; i < nfrcs; i++)
+            FEM_CHECK(fnode[i] >= 0 && fnode[i] < m->nnds, 3, "fem_form_rhs: force node out of range");
+        d_fnode.alloc(nfrcs); d_fnode.upload(fnode, nfrcs, s);
+        d_fval.alloc((size_t)nfrcs * (pd + 2)); d_fval.upload(fval, d_fval.n, s);
+        hipLaunchKernelGGL(k_rhs_forces, dim3(cdiv(nfrcs, 256)), dim3(256), 0, s, nfrcs, pd, d_fnode.p, d_fval.p, t_init,
+                           t_end, F);
+    }
+    if (ntrcs > 0) {
+        std::vector<int> tt(ntrcs), tn((size_t)ntrcs * 8, 0), ts(ntrcs);
+        for (int i = 0; i < ntrcs; i++) {
+            const int el = telsd[2 * i];
+            FEM_CHECK(el >= 0 && el < m->nels, 3, "fem_form_rhs: traction element out of range");
+            const int t = m->h_eltype[el], n = m->h_eptr[el + 1] - m->h_eptr[el];
+            FEM_CHECK(t >= FEM_TRI && t <= FEM_HEX, 3, "fem_form_rhs: traction on unsupported element type");
+            const int nsides = (t == FEM_TRI) ? 3 : (t == FEM_HEX ? 6 : 4);
+            FEM_CHECK(telsd[2 * i + 1] >= 1 && telsd[2 * i + 1] <= nsides, 3, "fem_form_rhs: bad side number");
+            tt[i] = t; ts[i] = telsd[2 * i + 1];
+            for (int a = 0; a < n; a++) tn[(size_t)i * 8 + a] = m->h_conn[m->h_eptr[el] + a];
+        }
+        d_tt.alloc(ntrcs); d_tt.upload(tt.data(), ntrcs, s);
+        d_tn.alloc(tn.size()); d_tn.upload(tn.data(), tn.size(), s);
+        d_ts.alloc(ntrcs); d_ts.upload(ts.data(), ntrcs, s);
+        d_tval.alloc((size_t)ntrcs * (pd + 2)); d_tval.upload(tval, d_tval.n, s);
+        hipLaunchKernelGGL(k_rhs_tractions, dim3(cdiv(ntrcs, 256)), dim3(256), 0, s, ntrcs, pd, d_tt.p, d_tn.p, d_ts.p,
+                           d_tval.p, m->coords.p, t_init, t_end, dt, F);
+        FEM_HIP(hipStreamSynchronize(s));
+    }
+    if (nbcs > 0) {
+        for (int i = 0; i < nbcs; i++)
+            FEM_CHECK(bcnode[(size_t)i * (1 + pd)] >= 0 && bcnode[(size_t)i * (1 + pd)] < m->nnds, 3,
+                      "fem_form_rhs: BC node out of range");
+        d_bc.alloc((size_t)nbcs * (1 + pd)); d_bc.upload(bcnode, d_bc.n, s);
+        d_bcval.alloc((size_t)nbcs * pd); d_bcval.upload(bcval, d_bcval.n, s);
+        hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, pd, d_bc.p, d_bcval.p, dt, t_total, F);
+    }
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));
+}

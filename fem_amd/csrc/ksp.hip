@@ -1,0 +1,434 @@
+// fem_amd/csrc/ksp.hip -- Vec operations and the Krylov solve.
+//
+// Replaces KSPSolve(Krylov,Vec_F,Vec_U) (src/main.F90:247), which on the
+// reference is a MUMPS LU (src/main.F90:355-358), by what the reference itself
+// selects through `-ksp_type cg -pc_type jacobi` when MUMPS is absent
+// (src/main.F90:354,377): PETSc's KSPCG with PCJACOBI, left preconditioning,
+// preconditioned residual norm, zero initial guess, KSPConvergedDefault
+// (PETSc 3.5 src/ksp/ksp/impls/cg/cg.c, src/ksp/ksp/interface/iterativ.c).
+//
+// Device-resident iteration: all CG scalars (alpha, beta, norms, iteration
+// count, converged reason) live in one KspState record in HBM and are produced
+// and consumed by kernels, so the host only enqueues work and polls the record
+// once per chunk of iterations -- no per-iteration host synchronisation.
+// Per iteration:  logic1 -> p = z + b p -> w = K p (+ p.w partials) -> reduce
+//                 -> logic2 -> x += a p, r -= a w, z = M^-1 r (+ z.z, z.r partials)
+//                 -> reduce.   Reductions are two-stage and deterministic.
+#include <cmath>
+#include <cstring>
+#include <sstream>
+
+#include "comm.h"
+#include "objects.h"
+
+using namespace fem;
+
+void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const int* done);
+void mat_get_diagonal_raw(fem_mat A, double* d);
+
+namespace fem {
+
+constexpr int VGRID = 1024;  // workgroups of the vector kernels = number of partials
+
+struct KspState {
+    double beta, betaold, dpi, dpiold, a, b, dp, rnorm0, ttol;
+    double red[4];  // reduced scalars: [0] z.z  [1] z.r  [2] p.w
+    int it, its, reason, done;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// ---- Vec kernels -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_fill(double* __restrict__ v, size_t n, double a)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) v[i] = a;
+}
+__global__ void __launch_bounds__(256) k_axpy(double* __restrict__ y, double a, const double* __restrict__ x, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] += a * x[i];
+}
+__global__ void __launch_bounds__(256) k_dot_partial(const double* __restrict__ x, const double* __restrict__ y, size_t n,
+                                                     int pd, const unsigned char* __restrict__ owned,
+                                                     double* __restrict__ partial)
+{
+    __shared__ double sh[4];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    double s = 0.0;
+    for (; i < n; i += st)
+        if (!owned || owned[i / pd]) s += x[i] * y[i];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// one workgroup: out[q] = sum of partial array q (fixed order -> deterministic)
+__global__ void __launch_bounds__(256) k_reduce(const double* __restrict__ p0, const double* __restrict__ p1, int n,
+                                                double* __restrict__ out, const int* __restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double sh[4];
+    double s0 = 0.0, s1 = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { s0 += p0[i]; if (p1) s1 += p1[i]; }
+    s0 = block_sum(s0, sh);
+    if (p1) s1 = block_sum(s1, sh);
+    if (threadIdx.x == 0) { out[0] = s0; if (p1) out[1] = s1; }
+}
+
+// PCJacobi set-up: reciprocal of the diagonal, zero entries -> 1 (PETSc PCSetUp_Jacobi)
+__global__ void __launch_bounds__(256) k_jacobi_setup(double* __restrict__ d, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { const double v = d[i]; d[i] = (v != 0.0) ? 1.0 / v : 1.0; }
+}
+
+// ---- CG kernels ------------------------------------------------------------------------
+// x = 0, r = b, p = 0, z = M^-1 r; partials of z.z and z.r
+__global__ void __launch_bounds__(256) k_cg_init(size_t n, int pd, const double* __restrict__ b,
+                                                 const double* __restrict__ dinv, double* __restrict__ x,
+                                                 double* __restrict__ r, double* __restrict__ p,
+                                                 const unsigned char* __restrict__ owned, double* __restrict__ pzz,
+                                                 double* __restrict__ pzr)
+{
+    __shared__ double sh[4];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    double zz = 0.0, zr = 0.0;
+    for (; i < n; i += st) {
+        const double ri = b[i], zi = dinv[i] * ri;
+        x[i] = 0.0; r[i] = ri; p[i] = 0.0;
+        if (!owned || owned[i / pd]) { zz += zi * zi; zr += zi * ri; }
+    }
+    zz = block_sum(zz, sh);
+    zr = block_sum(zr, sh);
+    if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
+}
+
+// Convergence test + beta (one thread).  `it` = iterations completed so far.
+__global__ void k_cg_logic1(KspState* __restrict__ st, double rtol, double abstol, double dtol, int maxit,
+                            double* __restrict__ hist, int hist_len)
+{
+    if (st->done) return;
+    const int i = st->it;
+    const double dp = sqrt(st->red[0]), zr = st->red[1];
+    st->dp = dp;
+    if (hist && i < hist_len) hist[i] = dp;
+    if (i == 0) { st->rnorm0 = dp; st->ttol = fmax(rtol * dp, abstol); }
+    int reason = 0;
+    if (isnan(dp) || isinf(dp)) reason = FEM_KSP_DIVERGED_NANORINF;
+    else if (dp <= st->ttol) reason = (dp < abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
+    else if (dp >= dtol * st->rnorm0) reason = FEM_KSP_DIVERGED_DTOL;
+    else if (i >= maxit) reason = FEM_KSP_DIVERGED_ITS;
+    if (reason) { st->reason = reason; st->done = 1; return; }
+    st->its = i + 1;
+    if (zr == 0.0) { st->reason = FEM_KSP_CONVERGED_ATOL; st->done = 1; return; }
+    if (i > 0 && zr * st->betaold < 0.0) { st->reason = FEM_KSP_DIVERGED_INDEFINITE_PC; st->done = 1; return; }
+    st->b = (i == 0) ? 0.0 : zr / st->betaold;
+    st->beta = zr;
+}
+
+// p = z + b p with z = M^-1 r
+__global__ void __launch_bounds__(256) k_cg_update_p(size_t n, const KspState* __restrict__ st,
+                                                     const double* __restrict__ dinv, const double* __restrict__ r,
+                                                     double* __restrict__ p)
+{
+    if (st->done) return;
+    const double b = st->b;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t str = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += str) p[i] = dinv[i] * r[i] + b * p[i];
+}
+
+// alpha from p.w (one thread)
+__global__ void k_cg_logic2(KspState* __restrict__ st)
+{
+    if (st->done) return;
+    const int i = st->it;
+    const double dpi = st->red[2];
+    if (dpi == 0.0 || (i > 0 && dpi * st->dpiold <= 0.0)) {
+        st->reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; st->done = 1; return;
+    }
+    st->a = st->beta / dpi;
+    st->betaold = st->beta;
+    st->dpiold = dpi;
+    st->dpi = dpi;
+    st->it = i + 1;
+}
+
+// x += a p ; r -= a w ; z = M^-1 r ; partials of z.z and z.r
+__global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, const KspState* __restrict__ st,
+                                                      const double* __restrict__ dinv, const double* __restrict__ p,
+                                                      const double* __restrict__ w, double* __restrict__ x,
+                                                      double* __restrict__ r, const unsigned char* __restrict__ owned,
+                                                      double* __restrict__ pzz, double* __restrict__ pzr)
+{
+    if (st->done) return;
+    __shared__ double sh[4];
+    const double a = st->a;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t str = (size_t)gridDim.x * blockDim.x;
+    double zz = 0.0, zr = 0.0;
+    for (; i < n; i += str) {
+        x[i] += a * p[i];
+        const double ri = r[i] - a * w[i];
+        r[i] = ri;
+        const double zi = dinv[i] * ri;
+        if (!owned || owned[i / pd]) { zz += zi * zi; zr += zi * ri; }
+    }
+    zz = block_sum(zz, sh);
+    zr = block_sum(zr, sh);
+    if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
+}
+
+}  // namespace fem
+
+struct fem_ksp_s {
+    fem_ctx ctx = nullptr;
+    fem_mat A = nullptr;
+    std::string type = "cg", pc = "jacobi";
+    // PETSc defaults (KSPCreate): rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 1e4
+    double rtol = 1.0e-5, abstol = 1.0e-50, dtol = 1.0e5;
+    int maxit = 10000;
+    bool setup_done = false;
+    long long n = 0;
+    DBuf<double> dinv, r, p, w, pzz, pzr, hist;
+    DBuf<KspState> state;
+    KspState* h_state = nullptr;  // pinned
+    int hist_len = 0;
+    int its = 0, reason = 0;
+    double rnorm = 0.0;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    int n_spmv = 0;
+    double spmv_ms = 0.0, solve_ms = 0.0;
+    ~fem_ksp_s() {
+        if (h_state) (void)hipHostFree(h_state);
+        for (auto e : ev) (void)hipEventDestroy(e);
+    }
+};
+
+static unsigned vgrid(size_t n) { return std::min<unsigned>(cdiv(n, 256), VGRID); }
+
+void ksp_set_from_options_impl(fem_ksp k, const char* options)
+{
+    std::istringstream is(options ? options : "");
+    std::string key, val;
+    while (is >> key) {
+        if (key == "-ksp_type") { is >> val; FEM_CHECK(val == "cg", 6, "unsupported -ksp_type " + val + " (cg)"); k->type = val; }
+        else if (key == "-pc_type") {
+            is >> val;
+            FEM_CHECK(val == "jacobi" || val == "none", 6, "unsupported -pc_type " + val + " (jacobi|none)");
+            k->pc = val;
+        }
+        else if (key == "-ksp_rtol") { is >> k->rtol; }
+        else if (key == "-ksp_atol") { is >> k->abstol; }
+        else if (key == "-ksp_divtol") { is >> k->dtol; }
+        else if (key == "-ksp_max_it") { is >> k->maxit; }
+        else if (key == "-ksp_norm_type") { is >> val; FEM_CHECK(val == "preconditioned", 6, "only -ksp_norm_type preconditioned"); }
+        else if (key == "-f") { is >> val; }
+        else throw Error(6, "fem_ksp_set_from_options: unknown option " + key);
+        FEM_CHECK(!is.fail(), 6, "fem_ksp_set_from_options: bad value for " + key);
+    }
+    k->setup_done = false;
+}
+
+void ksp_set_up_impl(fem_ksp k)
+{
+    FEM_CHECK(k->A, 7, "fem_ksp_set_up: no operator set");
+    fem_ctx ctx = k->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    fem_mat A = k->A;
+    k->n = (long long)A->nbrows * A->bs;
+    const size_t n = (size_t)k->n;
+    k->dinv.alloc(n); k->r.alloc(n); k->p.alloc(n); k->w.alloc(n);
+    k->pzz.alloc(VGRID); k->pzr.alloc(VGRID);
+    k->state.alloc(1);
+    if (!k->h_state) FEM_HIP(hipHostMalloc((void**)&k->h_state, sizeof(KspState)));
+    k->hist_len = k->maxit + 1;
+    k->hist.alloc((size_t)k->hist_len);
+    if (k->pc == "jacobi") {
+        mat_get_diagonal_raw(A, k->dinv.p);
+        halo_sum(A->mesh, k->dinv.p, A->bs, A->bs, 1);
+        hipLaunchKernelGGL(k_jacobi_setup, dim3(vgrid(n)), dim3(256), 0, s, k->dinv.p, n);
+    } else {
+        hipLaunchKernelGGL(k_fill, dim3(vgrid(n)), dim3(256), 0, s, k->dinv.p, n, 1.0);
+    }
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));
+    k->setup_done = true;
+}
+
+void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
+{
+    if (!k->setup_done) ksp_set_up_impl(k);
+    FEM_CHECK(b && x && b->n == k->n && x->n == k->n, 8, "fem_ksp_solve: vector size mismatch");
+    fem_ctx ctx = k->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    fem_mat A = k->A;
+    const size_t n = (size_t)k->n;
+    const int pd = A->bs;
+    Halo* halo = A->mesh->halo.get();
+    Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
+    const unsigned char* owned = comm ? halo->owned.p : nullptr;
+    KspState* st = k->state.p;
+    const unsigned g = vgrid(n);
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    size_t evn = 0;
+    if (k->profiling) {
+        FEM_HIP(hipEventCreate(&ev0)); FEM_HIP(hipEventCreate(&ev1));
+        FEM_HIP(hipEventRecord(ev0, s));
+    }
+    auto next_event = [&]() -> hipEvent_t {
+        if (evn == k->ev.size()) { hipEvent_t e; FEM_HIP(hipEventCreate(&e)); k->ev.push_back(e); }
+        return k->ev[evn++];
+    };
+
+    FEM_HIP(hipMemsetAsync(st, 0, sizeof(KspState), s));
+    hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, s, n, pd, b->d.p, k->dinv.p, x->d.p, k->r.p, k->p.p, owned,
+                       k->pzz.p, k->pzr.p);
+    auto reduce_zz_zr = [&] {
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, k->pzz.p, k->pzr.p, (int)g, &st->red[0], &st->done);
+        if (comm) comm->allreduce_sum(&st->red[0], 2, s);
+    };
+    reduce_zz_zr();
+
+    const int chunk = 32;
+    bool finished = false;
+    while (!finished) {
+        for (int c = 0; c < chunk; c++) {
+            hipLaunchKernelGGL(k_cg_logic1, dim3(1), dim3(1), 0, s, st, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
+                               k->hist_len);
+            hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, k->dinv.p, k->r.p, k->p.p);
+            if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+            mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
+            if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+            // p.(K p) = sum over domains of p_loc.(K_loc p_loc): the fused partials stay valid un-assembled
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, A->spmv_partial.p, (const double*)nullptr, A->spmv_grid,
+                               &st->red[2], &st->done);
+            if (comm) {
+                comm->allreduce_sum(&st->red[2], 1, s);
+                halo_sum(A->mesh, k->w.p, pd, pd, 1);
+            }
+            hipLaunchKernelGGL(k_cg_logic2, dim3(1), dim3(1), 0, s, st);
+            hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, k->dinv.p, k->p.p, k->w.p, x->d.p,
+                               k->r.p, owned, k->pzz.p, k->pzr.p);
+            reduce_zz_zr();
+        }
+        FEM_HIP(hipGetLastError());
+        FEM_HIP(hipMemcpyAsync(k->h_state, st, sizeof(KspState), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        if (k->h_state->done) { finished = true; break; }
+        // not finished after a chunk: the next logic1 decides (it also enforces maxit)
+    }
+    // the record is final once `done` is set; one more logic1 may be needed when the
+    // last chunk ended exactly on convergence of the last update -> handled by the loop
+    k->its = k->h_state->its;
+    k->reason = k->h_state->reason;
+    k->rnorm = k->h_state->dp;
+    if (k->profiling) {
+        FEM_HIP(hipEventRecord(ev1, s));
+        FEM_HIP(hipEventSynchronize(ev1));
+        float ms = 0;
+        FEM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        k->solve_ms = ms;
+        // only the launches that actually ran (before `done`) are counted
+        const int nrun = std::min<size_t>(evn / 2, (size_t)std::max(k->its, 0));
+        double tot = 0;
+        for (int i = 0; i < nrun; i++) {
+            FEM_HIP(hipEventElapsedTime(&ms, k->ev[2 * i], k->ev[2 * i + 1]));
+            tot += ms;
+        }
+        k->n_spmv = nrun; k->spmv_ms = tot;
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    }
+}
+
+// ---- Vec helpers used by the C API ---------------------------------------------------------
+void vec_fill(fem_vec v, double a)
+{
+    v->ctx->bind();
+    hipLaunchKernelGGL(k_fill, dim3(vgrid((size_t)v->n)), dim3(256), 0, v->ctx->stream, v->d.p, (size_t)v->n, a);
+    FEM_HIP(hipGetLastError());
+}
+void vec_axpy(fem_vec y, double a, fem_vec x)
+{
+    y->ctx->bind();
+    hipLaunchKernelGGL(k_axpy, dim3(vgrid((size_t)y->n)), dim3(256), 0, y->ctx->stream, y->d.p, a, x->d.p, (size_t)y->n);
+    FEM_HIP(hipGetLastError());
+}
+double vec_dot(fem_vec x, fem_vec y)
+{
+    fem_ctx ctx = x->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const unsigned g = vgrid((size_t)x->n);
+    DBuf<double> part(g + 1);
+    hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(256), 0, s, x->d.p, y->d.p, (size_t)x->n, 1,
+                       (const unsigned char*)nullptr, part.p);
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, part.p, (const double*)nullptr, (int)g, part.p + g,
+                       (const int*)nullptr);
+    double out = 0;
+    FEM_HIP(hipMemcpyAsync(&out, part.p + g, sizeof(double), hipMemcpyDeviceToHost, s));
+    FEM_HIP(hipStreamSynchronize(s));
+    return out;
+}
+
+// accessors for capi.cpp
+fem_ksp ksp_new(fem_ctx ctx) { auto* k = new fem_ksp_s; k->ctx = ctx; return k; }
+void ksp_delete(fem_ksp k) { delete k; }
+void ksp_set_operators(fem_ksp k, fem_mat A) { k->A = A; k->setup_done = false; }
+void ksp_set_type(fem_ksp k, const char* t)
+{
+    FEM_CHECK(t && std::string(t) == "cg", 6, std::string("fem_ksp_set_type: unsupported type ") + (t ? t : "(null)"));
+    k->type = t;
+}
+void ksp_set_pc_type(fem_ksp k, const char* t)
+{
+    FEM_CHECK(t && (std::string(t) == "jacobi" || std::string(t) == "none"), 6,
+              std::string("fem_ksp_set_pc_type: unsupported type ") + (t ? t : "(null)"));
+    k->pc = t; k->setup_done = false;
+}
+void ksp_set_tolerances(fem_ksp k, double rtol, double abstol, double dtol, int maxit)
+{
+    if (rtol != FEM_DEFAULT_REAL) { FEM_CHECK(rtol >= 0 && rtol < 1.0, 6, "rtol out of range"); k->rtol = rtol; }
+    if (abstol != FEM_DEFAULT_REAL) { FEM_CHECK(abstol >= 0, 6, "abstol out of range"); k->abstol = abstol; }
+    if (dtol != FEM_DEFAULT_REAL) { FEM_CHECK(dtol > 0, 6, "dtol out of range"); k->dtol = dtol; }
+    if (maxit != FEM_DEFAULT_INT) { FEM_CHECK(maxit >= 0, 6, "maxits out of range"); k->maxit = maxit; k->setup_done = false; }
+}
+void ksp_get_result(fem_ksp k, int* its, double* rnorm, int* reason)
+{
+    if (its) *its = k->its;
+    if (rnorm) *rnorm = k->rnorm;
+    if (reason) *reason = k->reason;
+}
+int ksp_get_history(fem_ksp k, double* hist, int len)
+{
+    const int n = std::min(len, std::min(k->its + 1, k->hist_len));
+    if (n > 0) {
+        k->ctx->bind();
+        FEM_HIP(hipMemcpy(hist, k->hist.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+    }
+    return std::max(n, 0);
+}
+void ksp_set_profiling(fem_ksp k, int on) { k->profiling = on != 0; }
+void ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_ms)
+{
+    if (n_spmv) *n_spmv = k->n_spmv;
+    if (spmv_ms) *spmv_ms = k->spmv_ms;
+    if (solve_ms) *solve_ms = k->solve_ms;
+}

@@ -1,0 +1,79 @@
+// fem_amd/csrc/objects.h -- the objects behind the opaque C handles.
+#pragma once
+#include <memory>
+
+#include "common.h"
+#include "elements.h"
+
+namespace fem {
+
+// Elements of one type, contiguous: conn[nel][npe] (local node ids).
+struct TypeGroup {
+    int type = 0, npe = 0, nip = 0, nel = 0;
+    DBuf<int> conn;          // [nel*npe]
+    DBuf<int> elem_id;       // [nel] position in the caller's element list
+    DBuf<double> E, nu;      // [nel] material per element (mat(el%mat,1:2), src/m_global.F90:254-255)
+    DBuf<uint16_t> slot;     // [nel*npe*npe] block-column slot of (node a, node b) in row a; filled by the Mat
+};
+
+struct Comm;  // comm.h
+
+// Interface lists of one domain (multi-domain runs).
+struct Halo {
+    Comm* comm = nullptr;
+    int nneigh = 0;
+    std::vector<int> neigh_rank, neigh_ptr;   // host copies
+    DBuf<int> neigh_nodes;                    // [neigh_ptr[nneigh]] local node ids, per neighbour
+    // canonical-order unpack: for interface node k (unique list `inodes`), the
+    // contributions sorted by contributing rank: src index into recv buffer, or
+    // -1 for "own value".
+    int ninodes = 0;
+    DBuf<int> inodes;        // [ninodes] unique interface nodes
+    DBuf<int> contrib_ptr;   // [ninodes+1]
+    DBuf<int> contrib_src;   // [contrib_ptr[ninodes]]  recv-buffer node slot or -1
+    DBuf<unsigned char> owned;  // [nnds] 1 if this domain owns the node (lowest rank among sharers)
+    DBuf<double> sendbuf, recvbuf;  // sized for max components (6) * interface nodes
+    size_t buf_nodes = 0;
+};
+
+}  // namespace fem
+
+struct fem_mesh_s {
+    fem_ctx ctx = nullptr;
+    int pdim = 0, nels = 0, nnds = 0, cpdim = 0;
+    std::vector<fem::TypeGroup> groups;
+    fem::DBuf<double> coords;     // [nnds*pdim] node-major
+    fem::DBuf<int> valence;       // [nnds] number of (non-cohesive) elements touching the node (count_node, src/main.F90:263)
+    fem::DBuf<double> valence_d;  // [nnds] global valence as double (halo-summed when multi-domain)
+    // host copies kept for the symbolic phase and for traction sides
+    std::vector<int> h_eltype, h_eptr, h_conn;
+    std::vector<int> elem_group, elem_pos;  // element -> (group index, position in group)
+    std::unique_ptr<fem::Halo> halo;
+};
+
+struct fem_vec_s {
+    fem_ctx ctx = nullptr;
+    long long n = 0;
+    fem::DBuf<double> d;
+};
+
+// Mat_K in sliced block-ELL: block rows = nodes, bs = pdim, slices of 64 rows.
+//   bcol[(boff[s]+j)*64 + lane]                      block column (node) ids
+//   val [((boff[s]+j)*bs*bs + r*bs + c)*64 + lane]   fp64 entries
+struct fem_mat_s {
+    fem_mesh mesh = nullptr;
+    fem_ctx ctx = nullptr;
+    int bs = 0, nbrows = 0, nslices = 0;
+    long long nblocks = 0;        // true (unpadded) number of bs x bs blocks
+    long long padded_blocks = 0;  // boff[nslices]*64
+    fem::DBuf<int> boff;          // [nslices+1]
+    fem::DBuf<int> bcol;
+    fem::DBuf<double> val;
+    fem::DBuf<int> rowlen;        // [nbrows] blocks per block row
+    std::vector<int> h_boff, h_rowlen;
+    fem::DBuf<double> spmv_partial;  // per-workgroup partials of the fused p.Kp
+    int spmv_grid = 0;
+    fem::DBuf<double> halo_diag_scratch;
+};
+
+struct fem_ksp_s;

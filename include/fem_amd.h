@@ -1,0 +1,206 @@
+/* include/fem_amd.h -- C ABI of libfem_amd.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the assemble-and-solve hot path of the Fortran/PETSc
+ * code srinath-chakravarthy/FEM ("defmod").  The reference has no FFI seam: its
+ * "API" is (i) the Fortran module procedures of `elems`/`local`
+ * (src/m_elems.F90, src/m_local.F90) and (ii) the PETSc Mat/Vec/KSP calls made
+ * from src/main.F90 and src/m_global.F90.  Each entry point below names the
+ * reference call site (file:line, relative to the reference root) it replaces.
+ * fortran/fem_amd_capi.F90 holds the ISO_C_BINDING interface module a
+ * maintainer of the reference would `use`; INTEGRATION.md shows the edit.
+ *
+ * Conventions
+ *   - plain C types only; all functions return 0 on success, non-zero on error
+ *     (PETSc style `ierr`; fem_last_error() gives the message).
+ *   - node / element / dof ids are 0-based int32 (as at the reference's PETSc
+ *     boundary, src/m_global.F90:294,314); dof = pdim*node + component.
+ *   - element type numbers as elTypes in src/m_elems.F90:26:
+ *     1 tri, 2 qua, 3 tet, 4 hex (8 nodes), 5 coh.
+ *   - small dense element arrays are column-major exactly as the reference
+ *     passes them: ecoords(nodecount,pdim), k(n*pdim,n*pdim), estress(nip,cpdim),
+ *     stress_node(nnds,cpdim).
+ *   - "host" pointers are caller-owned host memory; handles own device memory
+ *     and must be destroyed by the caller (PETSc object discipline,
+ *     src/main.F90:300-312).
+ *   - all arithmetic is IEEE fp64.  There is no CPU fallback: every call that
+ *     computes needs the GPU and fails loudly without it.
+ */
+#ifndef FEM_AMD_H
+#define FEM_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct fem_ctx_s *fem_ctx;   /* device + stream                          */
+typedef struct fem_comm_s *fem_comm; /* domain communicator (self / local / RCCL) */
+typedef struct fem_mesh_s *fem_mesh; /* device-resident SoA mesh of one domain   */
+typedef struct fem_mat_s *fem_mat;   /* Mat_K       (src/m_global.F90:26)        */
+typedef struct fem_vec_s *fem_vec;   /* Vec_F/Vec_U (src/m_global.F90:24)        */
+typedef struct fem_ksp_s *fem_ksp;   /* Krylov      (src/m_global.F90:27)        */
+
+#define FEM_TRI 1
+#define FEM_QUA 2
+#define FEM_TET 3
+#define FEM_HEX 4
+#define FEM_COH 5
+
+/* KSPConvergedReason values (PETSc). */
+#define FEM_KSP_CONVERGED_RTOL 2
+#define FEM_KSP_CONVERGED_ATOL 3
+#define FEM_KSP_CONVERGED_ITERATING 0
+#define FEM_KSP_DIVERGED_ITS (-3)
+#define FEM_KSP_DIVERGED_DTOL (-4)
+#define FEM_KSP_DIVERGED_INDEFINITE_PC (-8)
+#define FEM_KSP_DIVERGED_NANORINF (-9)
+#define FEM_KSP_DIVERGED_INDEFINITE_MAT (-10)
+
+/* PETSC_DEFAULT for fem_ksp_set_tolerances arguments. */
+#define FEM_DEFAULT_REAL (-2.0)
+#define FEM_DEFAULT_INT (-2)
+
+int fem_version(void);
+const char *fem_last_error(void);
+/* Number of visible GPUs; 0 means the library cannot compute. */
+int fem_device_count(int *count);
+
+/* ---- context: replaces PetscInitialize/PetscFinalize (src/main.F90:26,333) ---- */
+int fem_ctx_create(int device, fem_ctx *ctx);
+int fem_ctx_destroy(fem_ctx ctx);
+int fem_ctx_synchronize(fem_ctx ctx);
+/* HIP-event stopwatch on the context's stream (bench.py uses it for the
+ * roofline leg: events are recorded on the stream the kernels run on). */
+int fem_ctx_timer_start(fem_ctx ctx);
+int fem_ctx_timer_stop(fem_ctx ctx, double *elapsed_ms);
+
+/* ---- element library: module `elems` (src/m_elems.F90) -------------------- */
+/* getNodeCount :83, getNip :92, getDim :49, getNps :40, getVtkid :107 */
+int fem_el_counts(int eltype, int *nodecount, int *nip, int *dim, int *nps, int *vtkid);
+/* Initialize :124 -> SamPts*, ShapeFuncPrecomp*, NodalStressInv :725.  Returns
+ * the tables the kernels use: ipoints(nip,pdim), weights(nip), shape(nip,n)
+ * [N_node at each Gauss point], n2inv(nip,n) [inverse of shape]; has_inv = 0
+ * for types the reference skips (nip != nodecount). */
+int fem_el_tables(int eltype, double *ipoints, double *weights, double *shape, double *n2inv, int *has_inv);
+
+/* ---- element integration: module `local` (src/m_local.F90), batched ------- */
+/* FormElKE :21-67 for nel elements of one type.  ecoords[nel][n*pdim] (each
+ * element's block column-major (n,pdim)), E[nel], nu[nel] -> k[nel][nd*nd]
+ * (each column-major, nd = n*pdim).  Host pointers. */
+int fem_form_el_ke(fem_ctx ctx, int eltype, int nel, const double *ecoords, const double *E, const double *nu, double *k);
+/* CalcElStress :93-123.  edisp[nel][nd] -> estress[nel][nip*cpdim] (col-major (nip,cpdim)). */
+int fem_calc_el_stress(fem_ctx ctx, int eltype, int nel, const double *ecoords, const double *edisp, const double *E,
+                       const double *nu, double *estress);
+/* FormElIndx :70-78 (0-based). */
+int fem_form_el_indx(int pdim, int n, const int *enodes, int *indx);
+
+/* ---- mesh: local_elements/coords/mat (src/m_global.F90:40,22,21) ---------- */
+/* Uploads one domain's mesh as SoA.  eltype[nels], eptr[nels+1], conn[],
+ * mat_id[nels] (0-based row of mats), coords[nnds*pdim] node-major,
+ * mats[nmats*5] rows (E nu visc expn density; only E, nu are used,
+ * src/m_global.F90:254-255).  Elements of type coh are ignored here. */
+int fem_mesh_create(fem_ctx ctx, int pdim, int nels, int nnds, const int *eltype, const int *eptr, const int *conn,
+                    const int *mat_id, const double *coords, int nmats, const double *mats, fem_mesh *mesh);
+int fem_mesh_destroy(fem_mesh mesh);
+/* Multi-domain runs: attach the communicator and the interface lists.
+ * neigh_rank[nneigh] ascending; neigh_ptr[nneigh+1]; neigh_nodes[] = local node
+ * ids shared with each neighbour, in the SAME order on both sides (e.g. sorted
+ * by global node id).  Replaces the MatAssembly stash / VecScatter / AllReduce
+ * traffic of src/main.F90:167-171,185-190,274,286-289 by neighbour halo sums. */
+int fem_mesh_set_halo(fem_mesh mesh, fem_comm comm, int nneigh, const int *neigh_rank, const int *neigh_ptr,
+                      const int *neigh_nodes);
+
+/* ---- Mat: Mat_K ------------------------------------------------------------ */
+/* MatCreateAIJ src/main.F90:154 (+ the implicit pattern growth of
+ * MatSetValues): builds the sparsity from the connectivity on the device. */
+int fem_mat_create_aij(fem_mesh mesh, fem_mat *mat);
+int fem_mat_destroy(fem_mat mat);
+int fem_mat_zero_entries(fem_mat mat);
+/* The assembly loop src/main.F90:157-168: FormLocalK (src/m_global.F90:239-261)
+ * -> FormElKE -> MatSetValues(ADD_VALUES) -> MatAssemblyBegin/End, for every
+ * element of the mesh, in one pass of HIP kernels. */
+int fem_mat_assemble_elements(fem_mat mat);
+/* ApplyKBC src/main.F90:169, src/m_global.F90:264-299: INSERT the penalty on the
+ * diagonal of every constrained dof.  bcnode[nbcs*(1+pdim)] = node, flag_1..
+ * flag_pdim (0 = constrained). */
+int fem_mat_apply_kbc(fem_mat mat, int nbcs, const int *bcnode);
+/* Sizes: rows (dofs), scalar nonzeros of the AIJ pattern, bytes held on device. */
+int fem_mat_get_info(fem_mat mat, long long *nrows, long long *nnz, long long *device_bytes);
+/* AIJ export to host (MatView / MatGetRow use): rowptr[nrows+1], colind[nnz],
+ * val[nnz]; columns ascending.  Any pointer may be NULL. */
+int fem_mat_get_csr(fem_mat mat, int *rowptr, int *colind, double *val);
+/* MatMult: y = K x (sub-assembled product + halo sum when a halo is attached). */
+int fem_mat_mult(fem_mat mat, fem_vec x, fem_vec y);
+int fem_mat_get_diagonal(fem_mat mat, fem_vec d);
+/* Runs `reps` back-to-back MatMult launches between two HIP events recorded on
+ * the context's stream; returns the average launch time. */
+int fem_mat_mult_timed(fem_mat mat, fem_vec x, fem_vec y, int reps, double *avg_ms);
+
+/* ---- Vec: Vec_F / Vec_U ------------------------------------------------------ */
+int fem_vec_create(fem_ctx ctx, long long n, fem_vec *v); /* VecCreateMPI src/main.F90:138 */
+int fem_vec_destroy(fem_vec v);
+int fem_vec_get_size(fem_vec v, long long *n);
+int fem_vec_set(fem_vec v, double alpha);                /* VecSet / VecZeroEntries */
+int fem_vec_set_array(fem_vec v, const double *host);    /* VecSetValues(INSERT) of all entries */
+int fem_vec_get_array(fem_vec v, double *host);          /* GetVec_U src/m_global.F90:549-564 */
+int fem_vec_device_ptr(fem_vec v, void **dptr);
+int fem_vec_copy(fem_vec src, fem_vec dst);
+int fem_vec_axpy(fem_vec y, double a, fem_vec x);        /* y += a x */
+int fem_vec_dot(fem_vec x, fem_vec y, double *dot);
+int fem_vec_norm2(fem_vec x, double *nrm);
+
+/* ---- RHS: FormRHS src/m_global.F90:373-436 + EnforceBCForce :439-455 -------- */
+/* fval[nfrcs*(pdim+2)] rows f_1..f_pdim t1 t2 (t1,t2 already clamped to t as
+ * ReadDistForces does, src/m_io.F90:357-358); telsd[ntrcs*2] = element
+ * (0-based), side (1-based); tval like fval.  t_total is the deck's `t`. */
+int fem_form_rhs(fem_mesh mesh, int nbcs, const int *bcnode, const double *bcval, int nfrcs, const int *fnode,
+                 const double *fval, int ntrcs, const int *telsd, const double *tval, double t_total, double t_init,
+                 double dt, fem_vec F);
+
+/* ---- KSP: SetupKSPSolver src/main.F90:339-403, KSPSolve :247 ----------------- */
+int fem_ksp_create(fem_ctx ctx, fem_ksp *ksp);
+int fem_ksp_destroy(fem_ksp ksp);
+int fem_ksp_set_operators(fem_ksp ksp, fem_mat A);          /* KSPSetOperators :348 */
+int fem_ksp_set_type(fem_ksp ksp, const char *type);        /* "cg" */
+int fem_ksp_set_pc_type(fem_ksp ksp, const char *type);     /* "jacobi" | "none" */
+/* KSPSetTolerances :350; FEM_DEFAULT_* keeps the PETSc default
+ * (rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 10000). */
+int fem_ksp_set_tolerances(fem_ksp ksp, double rtol, double abstol, double dtol, int maxits);
+/* KSPSetFromOptions :377: parses "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-12
+ * -ksp_atol .. -ksp_divtol .. -ksp_max_it .." */
+int fem_ksp_set_from_options(fem_ksp ksp, const char *options);
+int fem_ksp_set_up(fem_ksp ksp);                            /* KSPSetUp :378 */
+int fem_ksp_solve(fem_ksp ksp, fem_vec b, fem_vec x);       /* KSPSolve :247 (zero initial guess) */
+int fem_ksp_get_iteration_number(fem_ksp ksp, int *its);
+int fem_ksp_get_residual_norm(fem_ksp ksp, double *rnorm);
+int fem_ksp_get_converged_reason(fem_ksp ksp, int *reason);
+/* KSPSetResidualHistory / KSPGetResidualHistory: copies min(len, its+1) norms. */
+int fem_ksp_get_residual_history(fem_ksp ksp, double *hist, int len, int *n);
+/* Per-solve HIP-event profile on the solve's stream: number of MatMult launches
+ * and their summed duration, total solve duration. */
+int fem_ksp_set_profiling(fem_ksp ksp, int on);
+int fem_ksp_get_profile(fem_ksp ksp, int *n_spmv, double *spmv_ms, double *solve_ms);
+
+/* ---- nodal stress: src/main.F90:253-292 -------------------------------------- */
+/* RecoverStress (src/m_global.F90:466) + RecoverNodalStress (:488) + valence
+ * averaging (+ halo sums instead of MPI_AllReduce/Mat_Stress) for the
+ * increment displacement U.  stress_node(nnds,cpdim) column-major, host. */
+int fem_recover_nodal_stress(fem_mesh mesh, fem_vec U, double *stress_node);
+/* Same, result left on the device in S (length nnds*cpdim, same layout). */
+int fem_recover_nodal_stress_vec(fem_mesh mesh, fem_vec U, fem_vec S);
+
+/* ---- communicators ------------------------------------------------------------ */
+int fem_comm_create_self(fem_ctx ctx, fem_comm *comm);
+/* RCCL over xGMI: one process per GPU; `unique_id` (128 bytes) comes from
+ * fem_comm_get_unique_id on rank 0 and is broadcast by the launcher. */
+int fem_comm_get_unique_id(char unique_id[128]);
+int fem_comm_create_rccl(fem_ctx ctx, int nranks, int rank, const char unique_id[128], fem_comm *comm);
+/* In-process group of `n` domains driven by `n` host threads (one fem_ctx
+ * each, any mix of GPUs): used to exercise the halo path on a single GPU. */
+int fem_comm_create_local_group(int n, const fem_ctx *ctxs, fem_comm *comms);
+int fem_comm_destroy(fem_comm comm);
+int fem_comm_rank(fem_comm comm, int *rank, int *size);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FEM_AMD_H */

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: DOF/s of assemble+solve on the 149^3 hex8
+linear-elastic cube (config 3 of BASELINE.json / SURVEY.md section 8d), one brick
+per GPU, plus the SpMV roofline line and the CPU (oracle port) baseline.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one synthetic mesh already resident in
+HBM: symbolic phase (sparsity from connectivity) + element integration and
+scatter-add + penalty BCs + Jacobi set-up + FormRHS + CG solve to the
+reference's rtol (1e-9), ending with the converged displacement on the device.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:
+    """scalar CSR, fp64 values, int32 indices, x read once, y written once."""
+    return nnz * 12.0 + (nrows + 1) * 4.0 + nrows * 16.0
+
+
+def cpu_baseline(n: int, gpu_its: int, threads: int) -> dict:
+    """Oracle (C port of the reference algorithm, OpenMP) on this box's host
+    cores: full symbolic + numeric assembly of the same mesh, and a bounded
+    number of CG iterations whose per-iteration time is extrapolated to the
+    iteration count the GPU run needed."""
+    from fem_amd.mesh import structured_hex
+    from oracle.oracle import Oracle, build
+    build(ref=False)
+    o = Oracle()
+    m = structured_hex(n)
+    nnz = len(o.csr_pattern(m)[1])          # untimed counting pass (PETSc would preallocate)
+    t0 = time.perf_counter()
+    rp, ci = o.csr_pattern(m, nnz=nnz)
+    t1 = time.perf_counter()
+    val = o.assemble(m, rp, ci, nthreads=threads, apply_bc=True)
+    t2 = time.perf_counter()
+    F = o.form_rhs(m, 0.0, m.dt)
+    nit = 20
+    t3 = time.perf_counter()
+    o.ksp_cg_jacobi(rp, ci, val, F, rtol=1e-30, maxit=nit, nthreads=threads)
+    t4 = time.perf_counter()
+    per_it = (t4 - t3) / nit
+    t_total = (t2 - t0) + gpu_its * per_it
+    return {"value": m.ndof / t_total, "unit": "DOF/s", "cores": threads, "kind": "port",
+            "sample": f"same {n}^3 hex8 mesh: symbolic {t1 - t0:.2f}s + assembly {t2 - t1:.2f}s measured in full; "
+                      f"{nit} CG iterations measured ({per_it * 1e3:.1f} ms each), solve extrapolated to the GPU "
+                      f"run's {gpu_its} iterations",
+            "t_assemble_s": t2 - t0, "ms_per_cg_iteration": per_it * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=149, help="hex elements per brick edge (149 = config 3)")
+    ap.add_argument("--rtol", type=float, default=float(np.float32(1e-9)))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--jitter", type=float, default=0.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from fem_amd import capi, driver, partition
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = capi.Context(local_rank)
+    grid = partition.brick_grid(world)
+    npr = (args.n, args.n, args.n)
+    mesh = partition.brick_mesh(rank, grid, npr, jitter=args.jitter)
+    comm = halo = None
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        comm = capi.Comm.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
+        halo = partition.brick_halo(rank, grid, npr)
+    prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r}", comm=comm, halo=halo)
+    prob.ksp.set_profiling(True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step():
+        if prob.K is not None:
+            prob.K.destroy(); prob.K = None
+        ta = time.perf_counter()
+        prob.assemble()                      # symbolic + numeric + BC (main.F90:151-171)
+        prob.ksp.set_up()
+        tb = time.perf_counter()
+        prob.dmesh.form_rhs(prob.F, 0.0, mesh.dt)
+        prob.ksp.solve(prob.F, prob.U)       # KSPSolve (main.F90:247)
+        ctx.synchronize()
+        return tb - ta, time.perf_counter() - tb
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    t_asm = t_sol = 0.0
+    n_spmv, spmv_ms = 0, 0.0
+    for _ in range(args.steps):
+        a, s = one_step()
+        t_asm += a; t_sol += s
+        k, ms, _ = prob.ksp.get_profile()
+        n_spmv += k; spmv_ms += ms
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    its = prob.ksp.get_iteration_number()
+    reason = prob.ksp.get_converged_reason()
+    nrows, nnz, dev_bytes = prob.K.info()
+    # global DOF count of the whole job (shared interface nodes counted once)
+    gn = [grid[d] * args.n + 1 for d in range(3)]
+    ndof_global = 3 * gn[0] * gn[1] * gn[2]
+    ms_per_step = elapsed / args.steps * 1e3
+    value = ndof_global * args.steps / elapsed
+
+    if rank == 0:
+        alg = spmv_algorithmic_bytes(nnz, nrows)
+        avg_ms = spmv_ms / max(n_spmv, 1)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        fmt_bytes = dev_bytes + nrows * 16.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                tj = json.load(f)
+            if tj.get("n") == args.n:
+                traffic = tj.get("hbm_bytes_per_launch")
+        out = {
+            "metric": "DOF/sec assemble+solve (3D hex linear elastic); CG SpMV GB/s vs HBM roofline",
+            "value": value, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config 3: {args.n}^3 hex8 cube per GPU, E=3e10 nu=0.25, z=0 clamped, "
+                                   f"top face u_z=-0.01*n by penalty, CG/Jacobi rtol={args.rtol:.3g}",
+                       "bricks": list(grid), "dof_global": ndof_global, "dof_per_gpu": nrows, "nnz_per_gpu": nnz,
+                       "cg_iterations": its, "converged_reason": reason,
+                       "t_assemble_ms": t_asm / args.steps * 1e3, "t_solve_ms": t_sol / args.steps * 1e3},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv_sell<3> (MatMult inside KSPCG)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes": alg, "avg_launch_ms": avg_ms, "launches": n_spmv,
+                         "format_bytes": fmt_bytes, "format_GBs": fmt_bytes / (avg_ms * 1e-3) / 1e9},
+        }
+        if world == 1 and not args.no_cpu:
+            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+            out["cpu_baseline"] = cpu_baseline(args.n, its, threads)
+            out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    prob.destroy()
+    if comm is not None:
+        comm.destroy()
+    ctx.destroy()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -162,11 +162,13 @@ class Oracle:
         return a.value, sn
 
     # ---- global level ----
-    def csr_pattern(self, m):
+    def csr_pattern(self, m, nnz=None):
+        """nnz=None: a counting pass first; pass a known nnz to run the fill pass only."""
         p, keep = make_problem(m)
         N = p.nnds * p.pdim
         rowptr = np.zeros(N + 1, dtype=np.int32)
-        nnz = self.L.dm_csr_pattern(C.byref(p), _i(rowptr), None)
+        if nnz is None:
+            nnz = self.L.dm_csr_pattern(C.byref(p), _i(rowptr), None)
         colind = np.zeros(max(nnz, 1), dtype=np.int32)
         self.L.dm_csr_pattern(C.byref(p), _i(rowptr), _i(colind))
         return rowptr, colind[:nnz]

@@ -45,6 +45,19 @@ __device__ __forceinline__ double block_sum(double v, double* sh)
     __syncthreads();
     return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
+// same for a 1024-thread workgroup (16 waves), fixed summation order
+__device__ __forceinline__ double block_sum16(double v, double* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) s += sh[k];
+    return s;
+}
 
 // ---- Vec kernels -----------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_fill(double* __restrict__ v, size_t n, double a)
@@ -115,13 +128,27 @@ __global__ void __launch_bounds__(256) k_cg_init(size_t n, int pd, const double*
     if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
 }
 
-// Convergence test + beta (one thread).  `it` = iterations completed so far.
-__global__ void k_cg_logic1(KspState* __restrict__ st, double rtol, double abstol, double dtol, int maxit,
-                            double* __restrict__ hist, int hist_len)
+// Convergence test + beta.  `it` = iterations completed so far.  Launched with
+// 1024 threads; when pzz/pzr are given (single domain) the workgroup first
+// reduces the npart partials of z.z and z.r itself, otherwise the already
+// reduced (and all-reduced) scalars are read from st->red.
+__global__ void __launch_bounds__(1024) k_cg_logic1(KspState* __restrict__ st, const double* __restrict__ pzz,
+                                                    const double* __restrict__ pzr, int npart, double rtol,
+                                                    double abstol, double dtol, int maxit, double* __restrict__ hist,
+                                                    int hist_len)
 {
     if (st->done) return;
+    __shared__ double sh[16];
+    double zz, zr;
+    if (pzz) {
+        double a = 0.0, b = 0.0;
+        for (int k = threadIdx.x; k < npart; k += 1024) { a += pzz[k]; b += pzr[k]; }
+        zz = block_sum16(a, sh);
+        zr = block_sum16(b, sh);
+    } else { zz = st->red[0]; zr = st->red[1]; }
+    if (threadIdx.x != 0) return;
     const int i = st->it;
-    const double dp = sqrt(st->red[0]), zr = st->red[1];
+    const double dp = sqrt(zz);
     st->dp = dp;
     if (hist && i < hist_len) hist[i] = dp;
     if (i == 0) { st->rnorm0 = dp; st->ttol = fmax(rtol * dp, abstol); }
@@ -150,12 +177,19 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, const KspState* _
     for (; i < n; i += str) p[i] = dinv[i] * r[i] + b * p[i];
 }
 
-// alpha from p.w (one thread)
-__global__ void k_cg_logic2(KspState* __restrict__ st)
+// alpha from p.w (same launch shape and reduction convention as logic1)
+__global__ void __launch_bounds__(1024) k_cg_logic2(KspState* __restrict__ st, const double* __restrict__ ppw, int npart)
 {
     if (st->done) return;
+    __shared__ double sh[16];
+    double dpi;
+    if (ppw) {
+        double a = 0.0;
+        for (int k = threadIdx.x; k < npart; k += 1024) a += ppw[k];
+        dpi = block_sum16(a, sh);
+    } else dpi = st->red[2];
+    if (threadIdx.x != 0) return;
     const int i = st->it;
-    const double dpi = st->red[2];
     if (dpi == 0.0 || (i > 0 && dpi * st->dpiold <= 0.0)) {
         st->reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; st->done = 1; return;
     }
@@ -204,7 +238,9 @@ struct fem_ksp_s {
     long long n = 0;
     DBuf<double> dinv, r, p, w, pzz, pzr, hist;
     DBuf<KspState> state;
-    KspState* h_state = nullptr;  // pinned
+    KspState* h_state = nullptr;  // pinned, two poll slots
+    hipEvent_t poll_ev[2] = {nullptr, nullptr};
+    int final_slot = -1;
     int hist_len = 0;
     int its = 0, reason = 0;
     double rnorm = 0.0;
@@ -215,6 +251,7 @@ struct fem_ksp_s {
     double spmv_ms = 0.0, solve_ms = 0.0;
     ~fem_ksp_s() {
         if (h_state) (void)hipHostFree(h_state);
+        for (auto e : poll_ev) if (e) (void)hipEventDestroy(e);
         for (auto e : ev) (void)hipEventDestroy(e);
     }
 };
@@ -256,7 +293,11 @@ void ksp_set_up_impl(fem_ksp k)
     k->dinv.alloc(n); k->r.alloc(n); k->p.alloc(n); k->w.alloc(n);
     k->pzz.alloc(VGRID); k->pzr.alloc(VGRID);
     k->state.alloc(1);
-    if (!k->h_state) FEM_HIP(hipHostMalloc((void**)&k->h_state, sizeof(KspState)));
+    if (!k->h_state) {
+        FEM_HIP(hipHostMalloc((void**)&k->h_state, 2 * sizeof(KspState)));
+        FEM_HIP(hipEventCreate(&k->poll_ev[0]));
+        FEM_HIP(hipEventCreate(&k->poll_ev[1]));
+    }
     k->hist_len = k->maxit + 1;
     k->hist.alloc((size_t)k->hist_len);
     if (k->pc == "jacobi") {
@@ -301,45 +342,76 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     FEM_HIP(hipMemsetAsync(st, 0, sizeof(KspState), s));
     hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, s, n, pd, b->d.p, k->dinv.p, x->d.p, k->r.p, k->p.p, owned,
                        k->pzz.p, k->pzr.p);
+    // multi-domain: reduce -> all-reduce -> logic reads st->red;  single domain: logic reduces the partials itself
     auto reduce_zz_zr = [&] {
+        if (!comm) return;
         hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, k->pzz.p, k->pzr.p, (int)g, &st->red[0], &st->done);
-        if (comm) comm->allreduce_sum(&st->red[0], 2, s);
+        comm->allreduce_sum(&st->red[0], 2, s);
     };
     reduce_zz_zr();
-
-    const int chunk = 32;
-    bool finished = false;
-    while (!finished) {
-        for (int c = 0; c < chunk; c++) {
-            hipLaunchKernelGGL(k_cg_logic1, dim3(1), dim3(1), 0, s, st, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
-                               k->hist_len);
-            hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, k->dinv.p, k->r.p, k->p.p);
-            if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
-            mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
-            if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+    auto one_iteration = [&] {
+        hipLaunchKernelGGL(k_cg_logic1, dim3(1), dim3(1024), 0, s, st, comm ? nullptr : k->pzz.p,
+                           comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
+                           k->hist_len);
+        hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, k->dinv.p, k->r.p, k->p.p);
+        if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+        mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
+        if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+        if (comm) {
             // p.(K p) = sum over domains of p_loc.(K_loc p_loc): the fused partials stay valid un-assembled
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, A->spmv_partial.p, (const double*)nullptr, A->spmv_grid,
-                               &st->red[2], &st->done);
-            if (comm) {
-                comm->allreduce_sum(&st->red[2], 1, s);
-                halo_sum(A->mesh, k->w.p, pd, pd, 1);
-            }
-            hipLaunchKernelGGL(k_cg_logic2, dim3(1), dim3(1), 0, s, st);
-            hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, k->dinv.p, k->p.p, k->w.p, x->d.p,
-                               k->r.p, owned, k->pzz.p, k->pzr.p);
-            reduce_zz_zr();
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, A->spmv_partial.p, (const double*)nullptr,
+                               A->spmv_grid, &st->red[2], &st->done);
+            comm->allreduce_sum(&st->red[2], 1, s);
+            halo_sum(A->mesh, k->w.p, pd, pd, 1);
         }
+        hipLaunchKernelGGL(k_cg_logic2, dim3(1), dim3(1024), 0, s, st, comm ? nullptr : A->spmv_partial.p,
+                           A->spmv_grid);
+        hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, k->dinv.p, k->p.p, k->w.p, x->d.p,
+                           k->r.p, owned, k->pzz.p, k->pzr.p);
+        reduce_zz_zr();
+    };
+    // The host runs ahead of the device: chunk c+1 is enqueued before chunk c's
+    // status record is examined, so the GPU never idles on a poll.  The chunk
+    // length shrinks as the (log-linear) residual history approaches the target,
+    // which keeps the number of no-op launches after convergence to a handful.
+    // Multi-domain runs use a fixed schedule: every domain must enqueue the same
+    // collectives in the same order.
+    int chunk = comm ? 16 : 8;
+    int slot = 0, prev_it = -1;
+    double prev_dp = 0.0;
+    bool have_pending = false, finished = false;
+    auto enqueue_chunk = [&](int len, int sl) {
+        for (int c = 0; c < len; c++) one_iteration();
         FEM_HIP(hipGetLastError());
-        FEM_HIP(hipMemcpyAsync(k->h_state, st, sizeof(KspState), hipMemcpyDeviceToHost, s));
-        FEM_HIP(hipStreamSynchronize(s));
-        if (k->h_state->done) { finished = true; break; }
-        // not finished after a chunk: the next logic1 decides (it also enforces maxit)
+        FEM_HIP(hipMemcpyAsync(&k->h_state[sl], st, sizeof(KspState), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipEventRecord(k->poll_ev[sl], s));
+    };
+    while (!finished) {
+        enqueue_chunk(chunk, slot);
+        if (have_pending) {
+            const int ps = slot ^ 1;
+            FEM_HIP(hipEventSynchronize(k->poll_ev[ps]));
+            const KspState& hs = k->h_state[ps];
+            if (hs.done) { finished = true; k->final_slot = ps; break; }
+            if (!comm && prev_it >= 0 && hs.it > prev_it && hs.dp > 0 && prev_dp > hs.dp && hs.ttol > 0) {
+                const double rate = std::log(prev_dp / hs.dp) / (hs.it - prev_it);   // decades per iteration (ln)
+                const double remaining = std::log(hs.dp / hs.ttol) / rate - chunk;   // beyond what is already queued
+                chunk = (int)std::fmin(32.0, std::fmax(1.0, 0.4 * remaining));
+            }
+            prev_it = hs.it; prev_dp = hs.dp;
+        }
+        have_pending = true;
+        slot ^= 1;
     }
-    // the record is final once `done` is set; one more logic1 may be needed when the
-    // last chunk ended exactly on convergence of the last update -> handled by the loop
-    k->its = k->h_state->its;
-    k->reason = k->h_state->reason;
-    k->rnorm = k->h_state->dp;
+    if (!finished || k->final_slot < 0) {
+        FEM_HIP(hipStreamSynchronize(s));
+    }
+    // drain whatever was queued behind the deciding poll (no-ops on the device)
+    FEM_HIP(hipStreamSynchronize(s));
+    FEM_HIP(hipMemcpy(&k->h_state[0], st, sizeof(KspState), hipMemcpyDeviceToHost));
+    k->its = k->h_state[0].its;
+    k->reason = k->h_state[0].reason;
+    k->rnorm = k->h_state[0].dp;
     if (k->profiling) {
         FEM_HIP(hipEventRecord(ev1, s));
         FEM_HIP(hipEventSynchronize(ev1));

@@ -1,0 +1,283 @@
+! fortran/fem_amd_capi.F90 -- ISO_C_BINDING interface to libfem_amd.so
+! (include/fem_amd.h).  This is the module a maintainer of the reference adds
+! to src/ and `use`s from main.F90 / m_global.F90 in place of the PETSc
+! Mat/Vec/KSP calls; INTEGRATION.md lists the call-site edits.
+!
+! Handles are type(c_ptr) (the reference's PETSc handles are opaque 8-byte
+! integers, src/m_global.F90:24-29); every function returns the PETSc-style
+! integer error code that the reference keeps in `ierr` (src/m_global.F90:42).
+! Indices are 0-based at this boundary, as at the reference's PETSc boundary.
+module fem_amd_capi
+  use iso_c_binding
+  implicit none
+
+  integer(c_int), parameter :: FEM_TRI = 1, FEM_QUA = 2, FEM_TET = 3, FEM_HEX = 4, FEM_COH = 5
+  real(c_double), parameter :: FEM_DEFAULT_REAL = -2.0d0
+  integer(c_int), parameter :: FEM_DEFAULT_INT = -2
+
+  interface
+    function fem_last_error() bind(C, name="fem_last_error") result(msg)
+      import :: c_ptr
+      type(c_ptr) :: msg
+    end function
+    function fem_ctx_create(device, ctx) bind(C, name="fem_ctx_create") result(ierr)
+      import :: c_int, c_ptr
+      integer(c_int), value :: device
+      type(c_ptr), intent(out) :: ctx
+      integer(c_int) :: ierr
+    end function
+    function fem_ctx_destroy(ctx) bind(C, name="fem_ctx_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int) :: ierr
+    end function
+    function fem_ctx_synchronize(ctx) bind(C, name="fem_ctx_synchronize") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int) :: ierr
+    end function
+    function fem_el_counts(eltype, nodecount, nip, dim, nps, vtkid) bind(C, name="fem_el_counts") result(ierr)
+      import :: c_int
+      integer(c_int), value :: eltype
+      integer(c_int), intent(out) :: nodecount, nip, dim, nps, vtkid
+      integer(c_int) :: ierr
+    end function
+    function fem_el_tables(eltype, ipoints, weights, shape, n2inv, has_inv) bind(C, name="fem_el_tables") result(ierr)
+      import :: c_int, c_double
+      integer(c_int), value :: eltype
+      real(c_double), intent(out) :: ipoints(*), weights(*), shape(*), n2inv(*)
+      integer(c_int), intent(out) :: has_inv
+      integer(c_int) :: ierr
+    end function
+    function fem_form_el_ke(ctx, eltype, nel, ecoords, E, nu, k) bind(C, name="fem_form_el_ke") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: eltype, nel
+      real(c_double), intent(in) :: ecoords(*), E(*), nu(*)
+      real(c_double), intent(out) :: k(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_calc_el_stress(ctx, eltype, nel, ecoords, edisp, E, nu, estress) &
+        bind(C, name="fem_calc_el_stress") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: eltype, nel
+      real(c_double), intent(in) :: ecoords(*), edisp(*), E(*), nu(*)
+      real(c_double), intent(out) :: estress(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_form_el_indx(pdim, n, enodes, indx) bind(C, name="fem_form_el_indx") result(ierr)
+      import :: c_int
+      integer(c_int), value :: pdim, n
+      integer(c_int), intent(in) :: enodes(*)
+      integer(c_int), intent(out) :: indx(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_mesh_create(ctx, pdim, nels, nnds, eltype, eptr, conn, mat_id, coords, nmats, mats, mesh) &
+        bind(C, name="fem_mesh_create") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: pdim, nels, nnds, nmats
+      integer(c_int), intent(in) :: eltype(*), eptr(*), conn(*), mat_id(*)
+      real(c_double), intent(in) :: coords(*), mats(*)
+      type(c_ptr), intent(out) :: mesh
+      integer(c_int) :: ierr
+    end function
+    function fem_mesh_destroy(mesh) bind(C, name="fem_mesh_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mesh
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_create_aij(mesh, mat) bind(C, name="fem_mat_create_aij") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mesh
+      type(c_ptr), intent(out) :: mat
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_destroy(mat) bind(C, name="fem_mat_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_zero_entries(mat) bind(C, name="fem_mat_zero_entries") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_assemble_elements(mat) bind(C, name="fem_mat_assemble_elements") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_apply_kbc(mat, nbcs, bcnode) bind(C, name="fem_mat_apply_kbc") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat
+      integer(c_int), value :: nbcs
+      integer(c_int), intent(in) :: bcnode(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_get_info(mat, nrows, nnz, device_bytes) bind(C, name="fem_mat_get_info") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: mat
+      integer(c_long_long), intent(out) :: nrows, nnz, device_bytes
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_mult(mat, x, y) bind(C, name="fem_mat_mult") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat, x, y
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_create(ctx, n, v) bind(C, name="fem_vec_create") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: ctx
+      integer(c_long_long), value :: n
+      type(c_ptr), intent(out) :: v
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_destroy(v) bind(C, name="fem_vec_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: v
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_set(v, alpha) bind(C, name="fem_vec_set") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: v
+      real(c_double), value :: alpha
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_set_array(v, host) bind(C, name="fem_vec_set_array") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: v
+      real(c_double), intent(in) :: host(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_get_array(v, host) bind(C, name="fem_vec_get_array") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: v
+      real(c_double), intent(out) :: host(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_form_rhs(mesh, nbcs, bcnode, bcval, nfrcs, fnode, fval, ntrcs, telsd, tval, t_total, t_init, dt, F) &
+        bind(C, name="fem_form_rhs") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mesh, F
+      integer(c_int), value :: nbcs, nfrcs, ntrcs
+      integer(c_int), intent(in) :: bcnode(*), fnode(*), telsd(*)
+      real(c_double), intent(in) :: bcval(*), fval(*), tval(*)
+      real(c_double), value :: t_total, t_init, dt
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_create(ctx, ksp) bind(C, name="fem_ksp_create") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      type(c_ptr), intent(out) :: ksp
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_destroy(ksp) bind(C, name="fem_ksp_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_operators(ksp, A) bind(C, name="fem_ksp_set_operators") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp, A
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_type(ksp, t) bind(C, name="fem_ksp_set_type") result(ierr)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ksp
+      character(kind=c_char), intent(in) :: t(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_pc_type(ksp, t) bind(C, name="fem_ksp_set_pc_type") result(ierr)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ksp
+      character(kind=c_char), intent(in) :: t(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_tolerances(ksp, rtol, abstol, dtol, maxits) bind(C, name="fem_ksp_set_tolerances") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ksp
+      real(c_double), value :: rtol, abstol, dtol
+      integer(c_int), value :: maxits
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_from_options(ksp, options) bind(C, name="fem_ksp_set_from_options") result(ierr)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ksp
+      character(kind=c_char), intent(in) :: options(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_up(ksp) bind(C, name="fem_ksp_set_up") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_solve(ksp, b, x) bind(C, name="fem_ksp_solve") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp, b, x
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_get_iteration_number(ksp, its) bind(C, name="fem_ksp_get_iteration_number") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp
+      integer(c_int), intent(out) :: its
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_get_residual_norm(ksp, rnorm) bind(C, name="fem_ksp_get_residual_norm") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ksp
+      real(c_double), intent(out) :: rnorm
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_get_converged_reason(ksp, reason) bind(C, name="fem_ksp_get_converged_reason") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp
+      integer(c_int), intent(out) :: reason
+      integer(c_int) :: ierr
+    end function
+    function fem_recover_nodal_stress(mesh, U, stress_node) bind(C, name="fem_recover_nodal_stress") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mesh, U
+      real(c_double), intent(out) :: stress_node(*)
+      integer(c_int) :: ierr
+    end function
+  end interface
+
+contains
+
+  ! The reference never checks ierr (src/m_global.F90:42); this wrapper does.
+  subroutine fem_check(ierr, where)
+    integer(c_int), intent(in) :: ierr
+    character(*), intent(in) :: where
+    character(kind=c_char), pointer :: cmsg(:)
+    type(c_ptr) :: p
+    integer :: i
+    if (ierr == 0) return
+    p = fem_last_error()
+    write(*, '(A,A,A,I0)', advance='no') " libfem_amd error in ", where, ": code ", ierr
+    if (c_associated(p)) then
+      call c_f_pointer(p, cmsg, (/512/))
+      write(*, '(A)', advance='no') " : "
+      do i = 1, 512
+        if (cmsg(i) == c_null_char) exit
+        write(*, '(A)', advance='no') cmsg(i)
+      end do
+    end if
+    write(*, *)
+    error stop 1
+  end subroutine fem_check
+
+  integer(c_int) function fem_type_no(eltype) result(t)
+    character(*), intent(in) :: eltype
+    t = 0
+    select case (trim(eltype))
+    case ("tri"); t = FEM_TRI
+    case ("qua"); t = FEM_QUA
+    case ("tet"); t = FEM_TET
+    case ("hex"); t = FEM_HEX
+    case ("coh"); t = FEM_COH
+    end select
+  end function fem_type_no
+
+end module fem_amd_capi

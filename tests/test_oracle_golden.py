@@ -1,0 +1,133 @@
+"""CPU: the oracle (C restatement) against the committed golden vectors that
+were generated from the REFERENCE's own element routines
+(tests/golden/element_golden.json, made by tests/golden/gen_golden.py from
+oracle/_ref), against the numbers the reference's own examples hold
+(tests/golden/reference_examples.json), and -- where oracle/_ref has been
+built -- directly against the reference library."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from fem_amd.inp import read_inp
+from oracle.oracle import RefLib, TRI, QUA, TET, HEX
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "element_golden.json")))
+EX = json.load(open(os.path.join(HERE, "golden", "reference_examples.json")))
+TYPES = {"tri": TRI, "qua": QUA, "tet": TET, "hex": HEX}
+RT = 1e-13
+
+
+def _close(a, b, rt=RT):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return np.abs(a - b).max() <= rt * max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_tables_match_reference(oracle, name):
+    t, g = TYPES[name], GOLD["types"][name]
+    assert oracle.counts(t) == (g["nodecount"], g["nip"], g["dim"], g["nps"], g["vtkid"])
+    ip, w, shp, inv = oracle.tables(t, g["dim"])
+    assert _close(ip, g["ipoints"]) and _close(w, g["weights"]) and _close(shp, g["shape"])
+    if g["n2inv"] is None:
+        assert inv is None
+    else:
+        assert _close(inv, g["n2inv"], 1e-12)
+
+
+@pytest.mark.parametrize("name", list(TYPES))
+def test_element_routines_match_reference(oracle, name):
+    t, g = TYPES[name], GOLD["types"][name]
+    for c in g["cases"]:
+        ec = np.array(c["ecoords"])
+        assert _close(oracle.form_el_ke(t, ec, c["E"], c["nu"]), c["k"])
+        assert _close(oracle.calc_el_stress(t, ec, c["edisp"], c["E"], c["nu"]), c["estress"])
+        dN, detj = oracle.form_dn_detj(t, c["xi"], ec)
+        assert _close(dN, c["dN"]) and abs(detj - c["detj"]) <= RT * abs(c["detj"])
+        assert _close(oracle.dmat(g["dim"], c["E"], c["nu"]), c["dmat"])
+        for s in c["sides"]:
+            a, sn = oracle.edge_area_nodes(t, c["enodes"], ec, s["side"])
+            assert abs(a - s["area"]) <= RT * s["area"] and list(sn) == s["snodes"]
+
+
+def test_known_answers_quoted_in_survey(oracle):
+    """unit elements with E=3640, nu=0.3 (values the reference's examples/tmp.txt also holds)."""
+    k = oracle.form_el_ke(QUA, [[0, 0], [1, 0], [1, 1], [0, 1]], 3640.0, 0.3)
+    assert np.allclose(k[0], [2100, 875, -1400, 175, -1050, -875, 350, -175], rtol=0, atol=1e-9)
+    k = oracle.form_el_ke(HEX, [[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], 3640.0, 0.3)
+    assert np.allclose(k[0, :6], [855.5556, 291.6667, 291.6667, -388.8889, 58.3333, 58.3333], atol=1e-3)
+    assert np.abs(k - k.T).max() < 1e-10 and np.abs(k.sum(1)).max() < 1e-9   # symmetric, rigid-body null space
+    k = oracle.form_el_ke(TET, [[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], 3640.0, 0.3)
+    assert np.allclose(k[0, :6], [1283.33, 583.33, 583.33, -816.67, -233.33, -233.33], atol=1e-2)
+    k = oracle.form_el_ke(TRI, [[0, 0], [1, 0], [0, 1]], 3640.0, 0.3)
+    assert np.allclose(k[0], [3150, 1750, -2450, -700, -700, -1050], atol=1e-9)
+
+
+def test_assembled_rows_of_reference_matview(oracle):
+    """examples/tmp.txt: MatView rows of the assembled Jacobian (elastic block + 1e30 penalties)."""
+    ex = EX["tmp_txt_jacobian"]
+    conn = ex["conn"]
+    nn = 5
+    coords = np.zeros((nn, 2))
+    for a, v in enumerate(conn):
+        coords[v] = ex["coords"][a]
+    coords[2] = [5.0, 5.0]   # node 2 does not belong to this element
+    m = dict(pdim=2, eltype=[QUA], eptr=[0, 4], conn=conn, mat_id=[0], coords=coords,
+             mats=[[ex["E"], ex["nu"], 0, 0, 0]], bcnode=[[0, 0, 0], [1, 0, 0]], bcval=[[0, 0], [0, 0]],
+             fnode=[], fval=np.zeros((0, 4)), telsd=np.zeros((0, 2)), tval=np.zeros((0, 4)), t=1.0, dt=1.0)
+    rp, ci = oracle.csr_pattern(m)
+    v = oracle.assemble(m, rp, ci, apply_bc=True)
+    for r, cols in ex["rows"].items():
+        r = int(r)
+        got = {int(ci[k]): v[k] for k in range(rp[r], rp[r + 1])}
+        for c, val in cols.items():
+            if val >= 1e29:
+                assert got[int(c)] == float(np.float32(1e30))   # PENALTY_PARAM is a default-real literal
+            else:
+                assert abs(got[int(c)] - val) <= 1e-9, (r, c, got[int(c)], val)
+
+
+def test_elastic_example_displacements_and_stress(oracle):
+    """examples/SNES_test/elastic/*.vtk: u_y = 0.05 / 0.10, nodal stress (105, 245, 0) after 10 increments."""
+    ex = EX["elastic_vtk"]
+    m = read_inp(os.path.join(HERE, "golden", "decks", "elastic_test.inp"))
+    assert m.nsteps == 10
+    for ksp in ("lu", "cg"):
+        u, s, its = oracle.run(m, ksp, rtol=1e-14)
+        assert len(its) == 10
+        assert np.abs(u.reshape(-1, 2) - np.array(ex["displacements"])).max() < 1e-12
+        assert np.abs(s - np.array(ex["stress"])[None]).max() < 1e-9
+        # and to the 6 decimals the reference wrote
+        assert np.array_equal(np.round(u.reshape(-1, 2), 6) + 0.0, np.array(ex["displacements"]))
+    assert np.allclose(m.coords, ex["points"])
+
+
+def test_cg_against_dense_lu_on_force_loaded_mixed_deck(oracle):
+    """examples/lin_two_quads_qs.inp (tri+qua, nodal forces): no reference output exists; the
+    KSPCG restatement must agree with the dense LU of the same assembled system."""
+    m = read_inp(os.path.join(HERE, "golden", "decks", "lin_two_quads_qs.inp"))
+    u1, s1, _ = oracle.run(m, "lu")
+    u2, s2, its = oracle.run(m, "cg", rtol=1e-14)
+    assert np.abs(u1 - u2).max() <= 1e-10 * np.abs(u1).max()
+    assert np.abs(s1 - s2).max() <= 1e-9 * np.abs(s1).max()
+    assert np.abs(u1).max() > 0
+
+
+@pytest.mark.skipif(not RefLib.available(), reason="oracle/_ref not built (reference absent)")
+@pytest.mark.parametrize("name", list(TYPES))
+def test_oracle_against_live_reference_library(oracle, name):
+    t = TYPES[name]
+    r = RefLib()
+    base = np.array(GOLD["types"][name]["cases"][0]["ecoords"])
+    pd = base.shape[1]
+    rng = np.random.default_rng(11 + t)
+    for _ in range(25):
+        ec = base * rng.uniform(0.5, 2) + rng.uniform(-0.25, 0.25, base.shape)
+        E, nu = rng.uniform(1, 1e12), rng.uniform(0, 0.49)
+        u = rng.standard_normal(base.size)
+        assert _close(oracle.form_el_ke(t, ec, E, nu), r.form_el_ke(t, ec, E, nu, pd), 2e-13)
+        assert _close(oracle.calc_el_stress(t, ec, u, E, nu), r.calc_el_stress(t, ec, u, E, nu, pd), 2e-13)
+    assert np.array_equal(r.form_el_indx(np.array([4, 9, 2], dtype=np.int32) + 1, pd) - 1,
+                          np.concatenate([[pd * v + d for d in range(pd)] for v in (4, 9, 2)]))

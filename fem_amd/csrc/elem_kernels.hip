@@ -471,15 +471,17 @@ void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval,
     FEM_HIP(hipMemsetAsync(F, 0, sizeof(double) * (size_t)m->nnds * pd, s));
     DBuf<int> d_fnode, d_bc, d_tt, d_tn, d_ts;
     DBuf<double> d_fval, d_bcval, d_tval;
-    if (nfrcs > 0) {
+    auto add_forces = [&] {
+        if (nfrcs <= 0) return;
         for (int i = 0; i < nfrcs; i++)
             FEM_CHECK(fnode[i] >= 0 && fnode[i] < m->nnds, 3, "fem_form_rhs: force node out of range");
         d_fnode.alloc(nfrcs); d_fnode.upload(fnode, nfrcs, s);
         d_fval.alloc((size_t)nfrcs * (pd + 2)); d_fval.upload(fval, d_fval.n, s);
         hipLaunchKernelGGL(k_rhs_forces, dim3(cdiv(nfrcs, 256)), dim3(256), 0, s, nfrcs, pd, d_fnode.p, d_fval.p, t_init,
                            t_end, F);
-    }
-    if (ntrcs > 0) {
+    };
+    auto add_tractions = [&] {
+        if (ntrcs <= 0) return;
         std::vector<int> tt(ntrcs), tn((size_t)ntrcs * 8, 0), ts(ntrcs);
         for (int i = 0; i < ntrcs; i++) {
             const int el = telsd[2 * i];
@@ -497,7 +499,17 @@ void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval,
         d_tval.alloc((size_t)ntrcs * (pd + 2)); d_tval.upload(tval, d_tval.n, s);
         hipLaunchKernelGGL(k_rhs_tractions, dim3(cdiv(ntrcs, 256)), dim3(256), 0, s, ntrcs, pd, d_tt.p, d_tn.p, d_ts.p,
                            d_tval.p, m->coords.p, t_init, t_end, dt, F);
-        FEM_HIP(hipStreamSynchronize(s));
+        FEM_HIP(hipStreamSynchronize(s));  // host staging vectors die at scope end
+    };
+    if (m->halo && m->halo->comm->size > 1) {
+        // multi-domain: tractions are per-element (additive) contributions -> halo sum;
+        // nodal forces and BC values are applied in full by every domain holding the node
+        add_tractions();
+        halo_sum(m, F, pd, pd, 1);
+        add_forces();
+    } else {  // the reference's order (src/m_global.F90:400-426)
+        add_forces();
+        add_tractions();
     }
     if (nbcs > 0) {
         for (int i = 0; i < nbcs; i++)

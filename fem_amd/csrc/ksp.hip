@@ -11,10 +11,12 @@
 // count, converged reason) live in one KspState record in HBM and are produced
 // and consumed by kernels, so the host only enqueues work and polls the record
 // once per chunk of iterations -- no per-iteration host synchronisation.
-// Per iteration:  logic1 -> p = z + b p -> w = K p (+ p.w partials) -> reduce
-//                 -> logic2 -> x += a p, r -= a w, z = M^-1 r (+ z.z, z.r partials)
-//                 -> reduce.   Reductions are two-stage and deterministic.
+// Per iteration three kernels: [convergence test, beta, p = z + b p] ->
+// [w = K p + p.w partials] -> [alpha, x += a p, r -= a w, z = M^-1 r, z.z / z.r partials]
+// (+ a one-workgroup reduction of the p.w partials when the SpMV grid is large).
+// Reductions are two-stage with a fixed order: solves are bitwise reproducible.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 
@@ -31,8 +33,9 @@ namespace fem {
 constexpr int VGRID = 1024;  // workgroups of the vector kernels = number of partials
 
 struct KspState {
-    double beta, betaold, dpi, dpiold, a, b, dp, rnorm0, ttol;
-    double red[4];  // reduced scalars: [0] z.z  [1] z.r  [2] p.w
+    double beta, betaold, a, b, dp, rnorm0, ttol;
+    double dpi2[2];  // p.w of the last two iterations (ping-pong: see the field table below)
+    double red[4];   // reduced scalars: [0] z.z  [1] z.r  [2] p.w
     int it, its, reason, done;
 };
 
@@ -86,15 +89,15 @@ __global__ void __launch_bounds__(256) k_dot_partial(const double* __restrict__ 
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 // one workgroup: out[q] = sum of partial array q (fixed order -> deterministic)
-__global__ void __launch_bounds__(256) k_reduce(const double* __restrict__ p0, const double* __restrict__ p1, int n,
-                                                double* __restrict__ out, const int* __restrict__ done)
+__global__ void __launch_bounds__(1024) k_reduce(const double* __restrict__ p0, const double* __restrict__ p1, int n,
+                                                 double* __restrict__ out, const int* __restrict__ done)
 {
     if (done && *done) return;
-    __shared__ double sh[4];
+    __shared__ double sh[16];
     double s0 = 0.0, s1 = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) { s0 += p0[i]; if (p1) s1 += p1[i]; }
-    s0 = block_sum(s0, sh);
-    if (p1) s1 = block_sum(s1, sh);
+    for (int i = threadIdx.x; i < n; i += 1024) { s0 += p0[i]; if (p1) s1 += p1[i]; }
+    s0 = block_sum16(s0, sh);
+    if (p1) s1 = block_sum16(s1, sh);
     if (threadIdx.x == 0) { out[0] = s0; if (p1) out[1] = s1; }
 }
 
@@ -128,80 +131,69 @@ __global__ void __launch_bounds__(256) k_cg_init(size_t n, int pd, const double*
     if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
 }
 
-// Convergence test + beta.  `it` = iterations completed so far.  Launched with
-// 1024 threads; when pzz/pzr are given (single domain) the workgroup first
-// reduces the npart partials of z.z and z.r itself, otherwise the already
-// reduced (and all-reduced) scalars are read from st->red.
-__global__ void __launch_bounds__(1024) k_cg_logic1(KspState* __restrict__ st, const double* __restrict__ pzz,
-                                                    const double* __restrict__ pzr, int npart, double rtol,
-                                                    double abstol, double dtol, int maxit, double* __restrict__ hist,
-                                                    int hist_len)
-{
-    if (st->done) return;
-    __shared__ double sh[16];
-    double zz, zr;
-    if (pzz) {
-        double a = 0.0, b = 0.0;
-        for (int k = threadIdx.x; k < npart; k += 1024) { a += pzz[k]; b += pzr[k]; }
-        zz = block_sum16(a, sh);
-        zr = block_sum16(b, sh);
-    } else { zz = st->red[0]; zr = st->red[1]; }
-    if (threadIdx.x != 0) return;
-    const int i = st->it;
-    const double dp = sqrt(zz);
-    st->dp = dp;
-    if (hist && i < hist_len) hist[i] = dp;
-    if (i == 0) { st->rnorm0 = dp; st->ttol = fmax(rtol * dp, abstol); }
-    int reason = 0;
-    if (isnan(dp) || isinf(dp)) reason = FEM_KSP_DIVERGED_NANORINF;
-    else if (dp <= st->ttol) reason = (dp < abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
-    else if (dp >= dtol * st->rnorm0) reason = FEM_KSP_DIVERGED_DTOL;
-    else if (i >= maxit) reason = FEM_KSP_DIVERGED_ITS;
-    if (reason) { st->reason = reason; st->done = 1; return; }
-    st->its = i + 1;
-    if (zr == 0.0) { st->reason = FEM_KSP_CONVERGED_ATOL; st->done = 1; return; }
-    if (i > 0 && zr * st->betaold < 0.0) { st->reason = FEM_KSP_DIVERGED_INDEFINITE_PC; st->done = 1; return; }
-    st->b = (i == 0) ? 0.0 : zr / st->betaold;
-    st->beta = zr;
-}
+// ---- the two fused CG kernels ---------------------------------------------------------------
+// Every workgroup evaluates the scalar logic of PETSc's KSPSolve_CG redundantly
+// from the same inputs (so all agree); workgroup 0 / thread 0 records the result
+// in the KspState.  Fields are arranged so that no field is both read and written
+// inside one kernel (except `done`, where every reader reaches the same verdict):
+//   k_cg_update_p  reads it, betaold, rnorm0, ttol      writes dp, rnorm0/ttol (it==0), its, b, beta, reason, done
+//   k_cg_update_xr reads its, beta, dpi2[(i+1)&1]       writes a, betaold, dpi2[i&1], it, reason, done
+// Scalars z.z, z.r (and p.w) arrive either as per-workgroup partials that each
+// workgroup sums in a fixed order, or already reduced in st->red (after k_reduce
+// and, multi-domain, the all-reduce).
 
-// p = z + b p with z = M^-1 r
-__global__ void __launch_bounds__(256) k_cg_update_p(size_t n, const KspState* __restrict__ st,
+// Convergence test (KSPConvergedDefault) + beta, then p = M^-1 r + b p.
+// `it` = iterations completed so far.
+__global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restrict__ st,
+                                                     const double* __restrict__ pzz, const double* __restrict__ pzr,
+                                                     int npart, double rtol, double abstol, double dtol, int maxit,
+                                                     double* __restrict__ hist, int hist_len,
                                                      const double* __restrict__ dinv, const double* __restrict__ r,
                                                      double* __restrict__ p)
 {
     if (st->done) return;
-    const double b = st->b;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t str = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += str) p[i] = dinv[i] * r[i] + b * p[i];
-}
-
-// alpha from p.w (same launch shape and reduction convention as logic1)
-__global__ void __launch_bounds__(1024) k_cg_logic2(KspState* __restrict__ st, const double* __restrict__ ppw, int npart)
-{
-    if (st->done) return;
-    __shared__ double sh[16];
-    double dpi;
-    if (ppw) {
-        double a = 0.0;
-        for (int k = threadIdx.x; k < npart; k += 1024) a += ppw[k];
-        dpi = block_sum16(a, sh);
-    } else dpi = st->red[2];
-    if (threadIdx.x != 0) return;
+    __shared__ double sh[4];
+    double zz, zr;
+    if (pzz) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = threadIdx.x; k < npart; k += 256) { s0 += pzz[k]; s1 += pzr[k]; }
+        zz = block_sum(s0, sh);
+        zr = block_sum(s1, sh);
+    } else { zz = st->red[0]; zr = st->red[1]; }
+    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
     const int i = st->it;
-    if (dpi == 0.0 || (i > 0 && dpi * st->dpiold <= 0.0)) {
-        st->reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; st->done = 1; return;
+    const double dp = sqrt(zz);
+    const double rnorm0 = (i == 0) ? dp : st->rnorm0;
+    const double ttol = (i == 0) ? fmax(rtol * dp, abstol) : st->ttol;
+    int reason = 0;
+    if (isnan(dp) || isinf(dp)) reason = FEM_KSP_DIVERGED_NANORINF;
+    else if (dp <= ttol) reason = (dp < abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
+    else if (dp >= dtol * rnorm0) reason = FEM_KSP_DIVERGED_DTOL;
+    else if (i >= maxit) reason = FEM_KSP_DIVERGED_ITS;
+    int its = -1;
+    if (!reason) {
+        its = i + 1;   // PETSc sets ksp->its = i+1 before the beta checks
+        if (zr == 0.0) reason = FEM_KSP_CONVERGED_ATOL;
+        else if (i > 0 && zr * st->betaold < 0.0) reason = FEM_KSP_DIVERGED_INDEFINITE_PC;
     }
-    st->a = st->beta / dpi;
-    st->betaold = st->beta;
-    st->dpiold = dpi;
-    st->dpi = dpi;
-    st->it = i + 1;
+    const double b = (i == 0) ? 0.0 : zr / st->betaold;
+    if (writer) {
+        st->dp = dp;
+        if (hist && i < hist_len) hist[i] = dp;
+        if (i == 0) { st->rnorm0 = rnorm0; st->ttol = ttol; }
+        if (its >= 0) st->its = its;
+        if (reason) { st->reason = reason; st->done = 1; }
+        else { st->b = b; st->beta = zr; }
+    }
+    if (reason) return;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t str = (size_t)gridDim.x * blockDim.x;
+    for (; q < n; q += str) p[q] = dinv[q] * r[q] + b * p[q];
 }
 
-// x += a p ; r -= a w ; z = M^-1 r ; partials of z.z and z.r
-__global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, const KspState* __restrict__ st,
+// alpha = beta / p.w, then x += a p ; r -= a w ; z = M^-1 r ; partials of z.z and z.r
+__global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState* __restrict__ st,
+                                                      const double* __restrict__ ppw, int npart,
                                                       const double* __restrict__ dinv, const double* __restrict__ p,
                                                       const double* __restrict__ w, double* __restrict__ x,
                                                       double* __restrict__ r, const unsigned char* __restrict__ owned,
@@ -209,16 +201,31 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, const Ks
 {
     if (st->done) return;
     __shared__ double sh[4];
-    const double a = st->a;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double dpi;
+    if (ppw) {
+        double s0 = 0.0;
+        for (int k = threadIdx.x; k < npart; k += 256) s0 += ppw[k];
+        dpi = block_sum(s0, sh);
+    } else dpi = st->red[2];
+    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
+    const int i = st->its - 1;   // iteration in progress (its was set by k_cg_update_p)
+    const bool bad = (dpi == 0.0) || (i > 0 && dpi * st->dpi2[(i + 1) & 1] <= 0.0);
+    const double beta = st->beta;
+    const double a = beta / dpi;
+    if (writer) {
+        if (bad) { st->reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; st->done = 1; }
+        else { st->a = a; st->betaold = beta; st->dpi2[i & 1] = dpi; st->it = i + 1; }
+    }
+    if (bad) return;
+    size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t str = (size_t)gridDim.x * blockDim.x;
     double zz = 0.0, zr = 0.0;
-    for (; i < n; i += str) {
-        x[i] += a * p[i];
-        const double ri = r[i] - a * w[i];
-        r[i] = ri;
-        const double zi = dinv[i] * ri;
-        if (!owned || owned[i / pd]) { zz += zi * zi; zr += zi * ri; }
+    for (; q < n; q += str) {
+        x[q] += a * p[q];
+        const double ri = r[q] - a * w[q];
+        r[q] = ri;
+        const double zi = dinv[q] * ri;
+        if (!owned || owned[q / pd]) { zz += zi * zi; zr += zi * ri; }
     }
     zz = block_sum(zz, sh);
     zr = block_sum(zr, sh);
@@ -323,7 +330,10 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     const size_t n = (size_t)k->n;
     const int pd = A->bs;
     Halo* halo = A->mesh->halo.get();
-    Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
+    // FEM_AMD_FORCE_COLLECTIVES=1 routes a single-domain solve through the communicator
+    // as well (lets a 1-GPU box exercise the RCCL all-reduce path)
+    static const bool force_coll = std::getenv("FEM_AMD_FORCE_COLLECTIVES") != nullptr;
+    Comm* comm = (halo && (halo->comm->size > 1 || force_coll)) ? halo->comm : nullptr;
     const unsigned char* owned = comm ? halo->owned.p : nullptr;
     KspState* st = k->state.p;
     const unsigned g = vgrid(n);
@@ -345,29 +355,31 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // multi-domain: reduce -> all-reduce -> logic reads st->red;  single domain: logic reduces the partials itself
     auto reduce_zz_zr = [&] {
         if (!comm) return;
-        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, k->pzz.p, k->pzr.p, (int)g, &st->red[0], &st->done);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, k->pzz.p, k->pzr.p, (int)g, &st->red[0], &st->done);
         comm->allreduce_sum(&st->red[0], 2, s);
     };
     reduce_zz_zr();
+    // p.w partials of a large SpMV grid are summed by one small kernel first; small grids
+    // (and z.z / z.r, at most 1024 partials) are summed inside the consuming kernel
+    const bool reduce_pw_first = comm || A->spmv_grid > 2048;
     auto one_iteration = [&] {
-        hipLaunchKernelGGL(k_cg_logic1, dim3(1), dim3(1024), 0, s, st, comm ? nullptr : k->pzz.p,
+        hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
-                           k->hist_len);
-        hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, k->dinv.p, k->r.p, k->p.p);
+                           k->hist_len, k->dinv.p, k->r.p, k->p.p);
         if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
         mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
         if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+        if (reduce_pw_first)
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr,
+                               A->spmv_grid, &st->red[2], &st->done);
         if (comm) {
             // p.(K p) = sum over domains of p_loc.(K_loc p_loc): the fused partials stay valid un-assembled
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, A->spmv_partial.p, (const double*)nullptr,
-                               A->spmv_grid, &st->red[2], &st->done);
             comm->allreduce_sum(&st->red[2], 1, s);
             halo_sum(A->mesh, k->w.p, pd, pd, 1);
         }
-        hipLaunchKernelGGL(k_cg_logic2, dim3(1), dim3(1024), 0, s, st, comm ? nullptr : A->spmv_partial.p,
-                           A->spmv_grid);
-        hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, k->dinv.p, k->p.p, k->w.p, x->d.p,
-                           k->r.p, owned, k->pzz.p, k->pzr.p);
+        hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st,
+                           reduce_pw_first ? nullptr : A->spmv_partial.p, A->spmv_grid, k->dinv.p, k->p.p, k->w.p,
+                           x->d.p, k->r.p, owned, k->pzz.p, k->pzr.p);
         reduce_zz_zr();
     };
     // The host runs ahead of the device: chunk c+1 is enqueued before chunk c's
@@ -452,7 +464,7 @@ double vec_dot(fem_vec x, fem_vec y)
     DBuf<double> part(g + 1);
     hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(256), 0, s, x->d.p, y->d.p, (size_t)x->n, 1,
                        (const unsigned char*)nullptr, part.p);
-    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, s, part.p, (const double*)nullptr, (int)g, part.p + g,
+    hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, part.p, (const double*)nullptr, (int)g, part.p + g,
                        (const int*)nullptr);
     double out = 0;
     FEM_HIP(hipMemcpyAsync(&out, part.p + g, sizeof(double), hipMemcpyDeviceToHost, s));

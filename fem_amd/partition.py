@@ -101,3 +101,60 @@ def general_halo(rank: int, nl2g_all: list[np.ndarray]):
         ranks.append(q); nodes.append(loc.astype(np.int32)); ptr.append(ptr[-1] + len(loc))
     return (np.array(ranks, dtype=np.int32), np.array(ptr, dtype=np.int32),
             np.concatenate(nodes) if nodes else np.zeros(0, dtype=np.int32))
+
+
+# ---- general (unstructured) element partition ------------------------------------------------------
+def rcb_partition(mesh: Mesh, nparts: int) -> np.ndarray:
+    """Element -> part by recursive coordinate bisection of the element centroids
+    (stands in for METIS_PartMeshNodal, src/m_io.F90:137, which is not in the image).
+    Deterministic; parts differ in size by at most one element per split."""
+    cent = np.zeros((mesh.nels, mesh.pdim))
+    for e in range(mesh.nels):
+        cent[e] = mesh.coords[mesh.element_nodes(e)].mean(axis=0)
+    epart = np.zeros(mesh.nels, dtype=np.int32)
+
+    def split(idx, p0, np_):
+        if np_ == 1 or len(idx) == 0:
+            epart[idx] = p0
+            return
+        nl = np_ // 2
+        c = cent[idx]
+        ax = int(np.argmax(c.max(axis=0) - c.min(axis=0)))
+        order = idx[np.lexsort((idx, c[:, ax]))]
+        cut = (len(idx) * nl) // np_
+        split(order[:cut], p0, nl)
+        split(order[cut:], p0 + nl, np_ - nl)
+
+    split(np.arange(mesh.nels), 0, nparts)
+    return epart
+
+
+def split_mesh(mesh: Mesh, epart: np.ndarray, rank: int):
+    """The local mesh of one part, numbered as the reference does after
+    DistributeElements (src/main.F90:49-96): local nodes in ascending global id.
+    Returns (local Mesh, nl2g).  BCs and nodal forces are kept on every part that
+    holds the node (consistent RHS); tractions follow their element."""
+    els = np.nonzero(epart == rank)[0]
+    conn_g = np.concatenate([mesh.element_nodes(e) for e in els]) if len(els) else np.zeros(0, dtype=np.int32)
+    nl2g = np.unique(conn_g)
+    g2l = -np.ones(mesh.nnds, dtype=np.int64)
+    g2l[nl2g] = np.arange(len(nl2g))
+    eptr = np.zeros(len(els) + 1, dtype=np.int32)
+    for k, e in enumerate(els):
+        eptr[k + 1] = eptr[k] + (mesh.eptr[e + 1] - mesh.eptr[e])
+    keep_bc = g2l[mesh.bcnode[:, 0]] >= 0 if mesh.bcnode.shape[0] else np.zeros(0, dtype=bool)
+    keep_f = g2l[mesh.fnode] >= 0 if mesh.fnode.shape[0] else np.zeros(0, dtype=bool)
+    e2l = -np.ones(mesh.nels, dtype=np.int64)
+    e2l[els] = np.arange(len(els))
+    keep_t = e2l[mesh.telsd[:, 0]] >= 0 if mesh.telsd.shape[0] else np.zeros(0, dtype=bool)
+    bcnode = mesh.bcnode[keep_bc].copy()
+    if bcnode.shape[0]:
+        bcnode[:, 0] = g2l[bcnode[:, 0]]
+    telsd = mesh.telsd[keep_t].copy()
+    if telsd.shape[0]:
+        telsd[:, 0] = e2l[telsd[:, 0]]
+    loc = Mesh(pdim=mesh.pdim, eltype=mesh.eltype[els], eptr=eptr, conn=g2l[conn_g], mat_id=mesh.mat_id[els],
+               coords=mesh.coords[nl2g], mats=mesh.mats, bcnode=bcnode, bcval=mesh.bcval[keep_bc],
+               fnode=g2l[mesh.fnode[keep_f]], fval=mesh.fval[keep_f], telsd=telsd, tval=mesh.tval[keep_t],
+               t=mesh.t, dt=mesh.dt)
+    return loc, nl2g.astype(np.int64)

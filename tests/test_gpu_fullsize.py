@@ -1,0 +1,135 @@
+"""GPU, BASELINE.json's full sizes (config 2: 707^2 quad4, config 3: 149^3 hex8):
+size-independent properties of the hot path, where the oracle would take minutes.
+
+* rigid-body translations lie in the null space of the assembled K (before BCs),
+* symmetry:  x.(K y) == y.(K x),
+* patch test on the DISTORTED mesh: a linear displacement field imposed on every
+  boundary node through the penalty is reproduced exactly in the interior, and
+  the recovered nodal stress is the uniform D*eps (isoparametric elements pass
+  the patch test for any element shape) -- this exercises assembly, BCs, RHS,
+  the CG solve and stress recovery end to end at full size,
+* two solves with the same assembled matrix are bitwise identical (deterministic
+  two-stage reductions).
+"""
+import numpy as np
+import pytest
+
+from fem_amd import capi, driver
+from fem_amd.mesh import structured_hex, structured_quad
+
+pytestmark = pytest.mark.gpu
+
+
+def _boundary_nodes(m, n):
+    c = np.rint(m.coords_unjittered).astype(np.int64)
+    return np.nonzero(((c == 0) | (c == n)).any(axis=1))[0]
+
+
+def _mesh(kind, n, jitter):
+    if kind == "hex":
+        m0 = structured_hex(n)
+        m = structured_hex(n, jitter=jitter)
+    else:
+        m0 = structured_quad(n)
+        m = structured_quad(n, jitter=jitter)
+    m.coords_unjittered = m0.coords
+    return m
+
+
+def _dmat(pd, E, nu):
+    c = E / ((1 + nu) * (1 - 2 * nu))
+    if pd == 2:
+        return c * np.array([[1 - nu, nu, 0], [nu, 1 - nu, 0], [0, 0, (1 - 2 * nu) / 2]])
+    D = np.zeros((6, 6))
+    D[:3, :3] = c * nu
+    D[np.arange(3), np.arange(3)] = c * (1 - nu)
+    D[np.arange(3, 6), np.arange(3, 6)] = c * (1 - 2 * nu) / 2
+    return D
+
+
+@pytest.mark.parametrize("kind,n", [("quad", 707), ("hex", 149)])
+def test_full_size_properties(gpu_ctx, kind, n):
+    m = _mesh(kind, n, 0.2)
+    pd = m.pdim
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K = capi.Mat(dm)
+    K.assemble_elements()
+    nrows, nnz, _ = K.info()
+    assert nrows == m.ndof
+    if kind == "hex":
+        assert nnz == 809238528
+    else:
+        assert nnz == 18011536
+    X, Y, Z = (capi.Vec(gpu_ctx, m.ndof) for _ in range(3))
+    D = capi.Vec(gpu_ctx, m.ndof)
+    K.get_diagonal(D)
+    dmax = np.abs(D.get_array()).max()
+    # rigid translations
+    for d in range(pd):
+        t = np.zeros((m.nnds, pd)); t[:, d] = 1.0
+        X.set_array(t.ravel())
+        K.mult(X, Y)
+        assert np.abs(Y.get_array()).max() <= 1e-10 * dmax
+    # symmetry
+    ids = np.arange(m.ndof, dtype=np.float64)
+    x, y = np.sin(0.37 * ids) + 0.1, np.cos(0.11 * ids * 1.3)
+    X.set_array(x); Z.set_array(y)
+    K.mult(X, Y); xKy_a = float(np.dot(y, Y.get_array()))
+    K.mult(Z, Y); xKy_b = float(np.dot(x, Y.get_array()))
+    assert abs(xKy_a - xKy_b) <= 1e-11 * max(abs(xKy_a), dmax)
+    for o in (X, Y, Z, D, K, dm):
+        o.destroy()
+
+    # patch test on the distorted mesh
+    A = np.array([[1.0e-3, 2.0e-4, -1.0e-4], [-3.0e-4, 5.0e-4, 2.5e-4], [1.5e-4, -2.0e-4, -7.0e-4]])[:pd, :pd]
+    b = _boundary_nodes(m, n)
+    m.bcnode = np.concatenate([b[:, None], np.zeros((len(b), pd), dtype=np.int64)], axis=1).astype(np.int32)
+    m.bcval = m.coords[b] @ A.T
+    m.fnode = np.zeros(0, dtype=np.int32); m.fval = np.zeros((0, pd + 2))
+    res = driver.run(m, "-ksp_rtol 1e-13 -ksp_max_it 20000", ctx=gpu_ctx)
+    assert res.reasons[-1] > 0
+    u = res.aggregate_u.reshape(-1, pd)
+    uex = m.coords @ A.T
+    assert np.abs(u - uex).max() <= 1e-9 * np.abs(uex).max()
+    eps = 0.5 * (A + A.T)
+    voigt = (np.array([eps[0, 0], eps[1, 1], 2 * eps[0, 1]]) if pd == 2 else
+             np.array([eps[0, 0], eps[1, 1], eps[2, 2], 2 * eps[0, 1], 2 * eps[1, 2], 2 * eps[2, 0]]))
+    sig = _dmat(pd, m.mats[0, 0], m.mats[0, 1]) @ voigt
+    assert np.abs(res.aggregate_stress - sig[None]).max() <= 1e-7 * np.abs(sig).max()
+    # determinism: with the SAME assembled Mat two solves are bitwise identical (fixed-order
+    # two-stage reductions); a re-assembly may differ in the last bits (fp64 atomics commute
+    # but do not associate), like PETSc's off-process stash order
+    prob = driver.Problem(gpu_ctx, m, "-ksp_rtol 1e-13 -ksp_max_it 20000")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U); u1 = prob.U.get_array(); it1 = prob.ksp.get_iteration_number()
+    prob.ksp.solve(prob.F, prob.U); u2 = prob.U.get_array(); it2 = prob.ksp.get_iteration_number()
+    assert it1 == it2 and np.array_equal(u1, u2)
+    assert np.abs(u1 - res.aggregate_u).max() <= 1e-11 * np.abs(u1).max()
+    prob.destroy()
+
+
+def test_config3_headline_solve_residual(gpu_ctx):
+    """Config 3 exactly as benchmarked (rtol 1e-9, reference default): converged, and
+    the true preconditioned residual |D^-1 (F - K u)| meets the PETSc test."""
+    m = structured_hex(149)
+    prob = driver.Problem(gpu_ctx, m)
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == 2          # KSP_CONVERGED_RTOL
+    its = prob.ksp.get_iteration_number()
+    hist = prob.ksp.get_residual_history()
+    assert len(hist) == its + 1 and hist[-1] <= capi.REFERENCE_RTOL * hist[0] < hist[-2]
+    R, Dg = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof)
+    prob.K.mult(prob.U, R)
+    prob.K.get_diagonal(Dg)
+    r = (prob.F.get_array() - R.get_array()) / Dg.get_array()
+    f0 = prob.F.get_array() / Dg.get_array()
+    assert np.linalg.norm(r) <= 5 * capi.REFERENCE_RTOL * np.linalg.norm(f0)
+    # penalty dofs carry the prescribed values
+    u = prob.U.get_array().reshape(-1, 3)
+    top = m.bcnode[m.bcnode[:, 3] == 0][:, 0]
+    top = top[m.coords[top, 2] == 149]
+    assert np.abs(u[top, 2] + 1.49).max() < 1e-9
+    R.destroy(); Dg.destroy(); prob.destroy()

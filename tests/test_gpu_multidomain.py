@@ -79,3 +79,102 @@ def test_multidomain_matches_serial_oracle(oracle, world, npr):
             common, ir, iq = np.intersect1d(out[r][5], out[q][5], return_indices=True)
             if common.size:
                 assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])
+
+
+def test_rccl_single_rank_collectives(oracle):
+    """RCCL back end on the one GPU of this box: librccl is dlopen'ed, a 1-rank communicator is
+    created from a unique id, and (FEM_AMD_FORCE_COLLECTIVES) every CG scalar goes through
+    ncclAllReduce on the solve's stream.  Only ncclSend/ncclRecv need a second GPU."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from fem_amd import capi, driver
+from fem_amd.mesh import structured_hex
+from oracle.oracle import Oracle
+ctx = capi.Context(0)
+comm = capi.Comm.rccl(ctx, 1, 0, capi.Comm.unique_id())
+assert comm.rank_size() == (0, 1)
+m = structured_hex(6, 5, 4, jitter=0.2)
+empty = (np.zeros(0, np.int32), np.zeros(1, np.int32), np.zeros(0, np.int32))
+prob = driver.Problem(ctx, m, "-ksp_rtol 1e-13", comm=comm, halo=empty)
+prob.assemble(); prob.ksp.set_up(); prob.dmesh.form_rhs(prob.F, 0.0, m.dt); prob.ksp.solve(prob.F, prob.U)
+u = prob.U.get_array(); s = prob.dmesh.recover_nodal_stress(prob.U)
+uo, so, its = Oracle().run(m, "cg", rtol=1e-13)
+assert prob.ksp.get_converged_reason() > 0 and abs(prob.ksp.get_iteration_number() - its[0]) <= 2
+assert np.abs(u - uo).max() <= 1e-10 * np.abs(uo).max() and np.abs(s - so).max() <= 1e-9 * np.abs(so).max()
+prob.destroy(); comm.destroy(); ctx.destroy()
+print("RCCL_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEM_AMD_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def _unstructured_case(kind):
+    """A deck-like mesh with every load type: clamped edge, nodal forces over a time window, tractions."""
+    from fem_amd.mesh import hex_to_tets, quad_to_mixed, structured_quad
+    if kind == "mixed2d":
+        m = quad_to_mixed(structured_quad(9, 6, jitter=0.15))
+        pd = 2
+    else:
+        m = hex_to_tets(structured_hex(4, 3, 3, jitter=0.1))
+        m.fnode = np.array([m.nnds - 1, m.nnds - 2], dtype=np.int32)
+        m.fval = np.array([[1.0e6, -2.0e6, 5.0e5, 0.0, 1.0], [0.0, 3.0e6, 0.0, 0.0, 0.5]])
+        pd = 3
+    # tractions on one side of several elements (side numbering src/m_elems.F90:286,370,473)
+    els = np.arange(0, m.nels, max(1, m.nels // 7))[:6]
+    m.telsd = np.stack([els, 1 + (els % 3)], axis=1).astype(np.int32)
+    tv = np.zeros((len(els), pd + 2)); tv[:, 0] = 2.0e5; tv[:, 1] = -1.0e5; tv[:, pd] = 0.0; tv[:, pd + 1] = 1.0
+    m.tval = tv
+    m.t, m.dt = 1.0, 0.5        # two increments
+    return m
+
+
+@pytest.mark.parametrize("kind,world", [("mixed2d", 3), ("tet3d", 4)])
+def test_general_partition_matches_serial_oracle(oracle, kind, world):
+    """RCB element partition of an unstructured mixed mesh (the reference's METIS step), interface
+    lists from the local->global maps, all load types, two increments; vs the serial oracle."""
+    m = _unstructured_case(kind)
+    epart = partition.rcb_partition(m, world)
+    parts = [partition.split_mesh(m, epart, r) for r in range(world)]
+    nl2g = [p[1] for p in parts]
+    ctxs = [capi.Context(0) for _ in range(world)]
+    comms = capi.Comm.local_group(ctxs)
+    out, err = [None] * world, []
+
+    def work(r):
+        try:
+            lm = parts[r][0]
+            prob = driver.Problem(ctxs[r], lm, "-ksp_rtol 1e-13", comm=comms[r], halo=partition.general_halo(r, nl2g))
+            prob.assemble(); prob.ksp.set_up()
+            u = np.zeros(lm.ndof); s = np.zeros((lm.nnds, lm.cpdim))
+            for step in range(2):
+                prob.dmesh.form_rhs(prob.F, lm.dt * step, lm.dt)
+                prob.ksp.solve(prob.F, prob.U)
+                assert prob.ksp.get_converged_reason() > 0
+                u += prob.U.get_array()
+                s += prob.dmesh.recover_nodal_stress(prob.U)
+            out[r] = (u, s)
+            prob.destroy()
+        except Exception as e:  # noqa: BLE001
+            err.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(timeout=300) for t in th]
+    assert not err, err
+    assert all(o is not None for o in out)
+    ug, sg, its = oracle.run(m, "cg", rtol=1e-13)
+    assert len(its) == 2
+    pd = m.pdim
+    for r in range(world):
+        u, s = out[r]
+        assert np.abs(u.reshape(-1, pd) - ug.reshape(-1, pd)[nl2g[r]]).max() <= 1e-10 * np.abs(ug).max()
+        assert np.abs(s - sg[nl2g[r]]).max() <= 1e-9 * np.abs(sg).max()
+    for c in comms:
+        c.destroy()
+    for c in ctxs:
+        c.destroy()

@@ -132,3 +132,33 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"\boracle[/.]|liboracle|defmod_oracle|libdefmod_ref", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("nparts", [2, 3, 5])
+def test_rcb_partition_and_split(nparts):
+    m = quad_to_mixed(structured_quad(9, 6, jitter=0.1))
+    m.telsd = np.array([[3, 1], [40, 2]], dtype=np.int32)
+    m.tval = np.array([[1.0, 0.0, 0.0, 1.0], [0.0, 2.0, 0.0, 1.0]])
+    epart = partition.rcb_partition(m, nparts)
+    counts = np.bincount(epart, minlength=nparts)
+    assert counts.sum() == m.nels and counts.max() - counts.min() <= nparts
+    parts = [partition.split_mesh(m, epart, r) for r in range(nparts)]
+    assert sum(p[0].nels for p in parts) == m.nels
+    assert sum(p[0].telsd.shape[0] for p in parts) == 2          # each traction follows its element
+    for lm, nl2g in parts:
+        assert np.array_equal(nl2g, np.sort(nl2g))                # ascending global ids (main.F90:78-96)
+        assert np.array_equal(lm.coords, m.coords[nl2g])
+        for e in range(lm.nels):                                  # connectivity survives the renumbering
+            assert lm.coords[lm.element_nodes(e)].shape[1] == 2
+        if lm.bcnode.shape[0]:
+            assert set(nl2g[lm.bcnode[:, 0]]) <= set(m.bcnode[:, 0])
+    nl2g = [p[1] for p in parts]
+    seen = np.zeros(m.nnds, dtype=int)
+    for r in range(nparts):
+        nr, ptr, nodes = partition.general_halo(r, nl2g)
+        seen[nl2g[r]] += 1
+        for i, q in enumerate(nr):
+            qnr, qptr, qnodes = partition.general_halo(q, nl2g)
+            j = list(qnr).index(r)
+            assert np.array_equal(nl2g[r][nodes[ptr[i]:ptr[i + 1]]], nl2g[q][qnodes[qptr[j]:qptr[j + 1]]])
+    assert (seen >= 1).all()

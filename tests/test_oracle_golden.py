@@ -131,3 +131,30 @@ def test_oracle_against_live_reference_library(oracle, name):
         assert _close(oracle.calc_el_stress(t, ec, u, E, nu), r.calc_el_stress(t, ec, u, E, nu, pd), 2e-13)
     assert np.array_equal(r.form_el_indx(np.array([4, 9, 2], dtype=np.int32) + 1, pd) - 1,
                           np.concatenate([[pd * v + d for d in range(pd)] for v in (4, 9, 2)]))
+
+
+def _vtk_numbers(text):
+    """(header tokens, numeric rows) -- trailing blanks and the sign of a printed zero are not significant."""
+    rows = []
+    for ln in text.splitlines():
+        t = ln.split()
+        try:
+            rows.append([float(x) + 0.0 for x in t])
+        except ValueError:
+            rows.append(t)
+    return rows
+
+
+def test_vtk_writer_reproduces_reference_rank_files(oracle):
+    """examples/SNES_test/elastic/{0,1}_output_000000.vtk (2-rank run: rank 0 holds element 2,
+    rank 1 element 1, nodes renumbered locally) from the oracle solution of the same deck."""
+    from fem_amd.vtk import vtk_text
+    m = read_inp(os.path.join(HERE, "golden", "decks", "elastic_test.inp"))
+    u, s, _ = oracle.run(m, "lu")
+    for rank, elems in ((0, [1]), (1, [0])):
+        ref = open(os.path.join(HERE, "golden", "vtk", f"elastic_rank{rank}_output_000000.vtk")).read()
+        got = vtk_text(m, u, s, elements=elems)
+        assert _vtk_numbers(got) == _vtk_numbers(ref)
+        # layout (line count, keywords, formats) is textually the reference's
+        assert [ln.split()[0] for ln in got.splitlines()] != [] and len(got.splitlines()) == len(ref.splitlines())
+        assert got.splitlines()[:5] == ref.splitlines()[:5]

@@ -96,6 +96,54 @@ __global__ void __launch_bounds__(256) k_sym(int nslices, int nrows, const int* 
     if (row < nrows) { y[3 * (size_t)row] = y0; y[3 * (size_t)row + 1] = y1; y[3 * (size_t)row + 2] = y2; }
 }
 
+// same, but workgroup b processes the slices sched[4*pos .. 4*pos+3] where pos is
+// the XCD-chunked position of b: each XCD walks a contiguous part of a tiled sweep
+// so that the previous plane's upper blocks are still in ITS 4 MiB L2.
+__global__ void __launch_bounds__(256) k_sym_sched(int nslices, int nrows, const int* __restrict__ sched,
+                                                   const int* __restrict__ uoff, const int* __restrict__ ucol,
+                                                   const double* __restrict__ uval, const int* __restrict__ loff,
+                                                   const int* __restrict__ lcol, const int* __restrict__ lbase,
+                                                   const double* __restrict__ x, double* __restrict__ y) {
+    int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int b = blockIdx.x;
+    { int nb = gridDim.x; int q = nb >> 3, r = nb & 7; int xcd = b & 7, i = b >> 3;
+      b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i; }
+    int pos = b * 4 + wave;
+    if (pos >= nslices) return;
+    int s = sched[pos];
+    double y0 = 0, y1 = 0, y2 = 0;
+    {
+        int o0 = loff[s], W = loff[s + 1] - o0;
+        const int* lc = lcol + (size_t)o0 * 64 + lane;
+        const int* lb = lbase + (size_t)o0 * 64 + lane;
+        for (int j = 0; j < W; j++) {
+            int c = lc[(size_t)j * 64];
+            int base = lb[(size_t)j * 64];
+            if (base < 0) continue;
+            double x0 = x[3 * (size_t)c], x1 = x[3 * (size_t)c + 1], x2 = x[3 * (size_t)c + 2];
+            const double* a = uval + base;
+            y0 += a[0] * x0 + a[192] * x1 + a[384] * x2;
+            y1 += a[64] * x0 + a[256] * x1 + a[448] * x2;
+            y2 += a[128] * x0 + a[320] * x1 + a[512] * x2;
+        }
+    }
+    {
+        int o0 = uoff[s], W = uoff[s + 1] - o0;
+        const int* bc = ucol + (size_t)o0 * 64 + lane;
+        const double* v = uval + (size_t)o0 * 9 * 64 + lane;
+        for (int j = 0; j < W; j++) {
+            int c = bc[(size_t)j * 64];
+            double x0 = x[3 * (size_t)c], x1 = x[3 * (size_t)c + 1], x2 = x[3 * (size_t)c + 2];
+            const double* a = v + (size_t)j * 9 * 64;
+            y0 += a[0] * x0 + a[64] * x1 + a[128] * x2;
+            y1 += a[192] * x0 + a[256] * x1 + a[320] * x2;
+            y2 += a[384] * x0 + a[448] * x1 + a[512] * x2;
+        }
+    }
+    int row = s * 64 + lane;
+    if (row < nrows) { y[3 * (size_t)row] = y0; y[3 * (size_t)row + 1] = y1; y[3 * (size_t)row + 2] = y2; }
+}
+
 template <typename F>
 static double time_ms(F f, int reps) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -217,6 +265,20 @@ int main(int argc, char** argv) {
         ms = time_ms([&] { k_sym<true><<<(nsl + 3) / 4, 256>>>(nsl, (int)nn, duoff, duc, duv, dloff, dlc, dlb, dx, dy); }, reps);
         printf("%-22s %.3f ms  csr-alg %.2f TB/s\n", "symmetric gather xcd", ms, csr_bytes / ms / 1e9);
         check("sym xcd");
+        int* dsched; CK(hipMalloc(&dsched, (size_t)nsl * 4));
+        for (int TJ : {5, 10, 19, 38, 150}) {
+            std::vector<long long> key(nsl); std::vector<int> sched(nsl);
+            for (int s = 0; s < nsl; s++) {
+                size_t v0 = (size_t)s * 64; int i = (int)(v0 % n), j = (int)((v0 / n) % n), k = (int)(v0 / ((size_t)n * n));
+                key[s] = (((long long)(j / TJ) * n + k) * n + j) * n + i; sched[s] = s;
+            }
+            std::sort(sched.begin(), sched.end(), [&](int a, int b) { return key[a] < key[b]; });
+            CK(hipMemcpy(dsched, sched.data(), (size_t)nsl * 4, hipMemcpyHostToDevice));
+            ms = time_ms([&] { k_sym_sched<<<(nsl + 3) / 4, 256>>>(nsl, (int)nn, dsched, duoff, duc, duv, dloff, dlc, dlb, dx, dy); }, reps);
+            char nm[64]; snprintf(nm, 64, "sym tiled TJ=%d", TJ);
+            printf("%-22s %.3f ms  csr-alg %.2f TB/s\n", nm, ms, csr_bytes / ms / 1e9);
+            check(nm);
+        }
     }
     return 0;
 }

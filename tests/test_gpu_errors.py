@@ -1,0 +1,109 @@
+"""GPU: error behaviour of the C-ABI (PETSc-style non-zero ierr + message, never a crash or a
+silent fallback) and degenerate inputs (empty element list, isolated nodes, ragged fans)."""
+import numpy as np
+import pytest
+
+from fem_amd import capi
+from fem_amd.mesh import Mesh, TRI, QUA, structured_quad
+
+pytestmark = pytest.mark.gpu
+
+
+def _tri_fan(k):
+    """k triangles around node 0: node 0 has k+1 neighbour nodes."""
+    ang = np.linspace(0, 2 * np.pi, k, endpoint=False)
+    coords = np.concatenate([[[0.0, 0.0]], np.stack([np.cos(ang), np.sin(ang)], axis=1)])
+    conn = np.array([[0, 1 + i, 1 + (i + 1) % k] for i in range(k)])
+    return Mesh(pdim=2, eltype=np.full(k, TRI), eptr=np.arange(k + 1) * 3, conn=conn.ravel(), mat_id=np.zeros(k),
+                coords=coords, mats=[[1.0e5, 0.3, 0, 0, 0]], bcnode=[[1, 0, 0], [2, 0, 0]], bcval=[[0, 0], [0, 0]],
+                fnode=[0], fval=[[1.0, 2.0, 0.0, 1.0]])
+
+
+def test_bad_mesh_inputs(gpu_ctx):
+    m = structured_quad(3, 3)
+    bad = Mesh(pdim=2, eltype=m.eltype, eptr=m.eptr, conn=np.where(m.conn == 5, 99, m.conn), mat_id=m.mat_id,
+               coords=m.coords, mats=m.mats)
+    with pytest.raises(capi.FemError, match="node id out of range"):
+        capi.DeviceMesh(gpu_ctx, bad)
+    bad = Mesh(pdim=2, eltype=m.eltype, eptr=m.eptr, conn=m.conn, mat_id=m.mat_id + 3, coords=m.coords, mats=m.mats)
+    with pytest.raises(capi.FemError, match="material id"):
+        capi.DeviceMesh(gpu_ctx, bad)
+    bad = Mesh(pdim=2, eltype=np.full(m.nels, 4), eptr=m.eptr, conn=m.conn, mat_id=m.mat_id, coords=m.coords, mats=m.mats)
+    with pytest.raises(capi.FemError, match="wrong node count"):
+        capi.DeviceMesh(gpu_ctx, bad)
+
+
+def test_vector_and_solver_misuse(gpu_ctx):
+    m = structured_quad(4, 4)
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K = capi.Mat(dm)
+    x, y = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof + 1)
+    with pytest.raises(capi.FemError, match="size mismatch"):
+        K.mult(x, y)
+    ksp = capi.KSP(gpu_ctx)
+    with pytest.raises(capi.FemError, match="no operator"):
+        ksp.set_up()
+    with pytest.raises(capi.FemError, match="unsupported"):
+        ksp.set_type("gmres")
+    with pytest.raises(capi.FemError, match="unsupported"):
+        ksp.set_pc_type("lu")
+    with pytest.raises(capi.FemError, match="unknown option"):
+        ksp.set_from_options("-ksp_foo 3")
+    with pytest.raises(capi.FemError, match="bad value"):
+        ksp.set_from_options("-ksp_rtol abc")
+    ksp.set_from_options("-ksp_type cg -pc_type none -ksp_rtol 1e-8 -ksp_atol 1e-40 -ksp_divtol 1e6 -ksp_max_it 77")
+    m2 = Mesh(pdim=2, eltype=m.eltype, eptr=m.eptr, conn=m.conn, mat_id=m.mat_id, coords=m.coords, mats=m.mats,
+              telsd=[[0, 7]], tval=[[1.0, 0.0, 0.0, 1.0]])
+    with pytest.raises(capi.FemError, match="bad side"):
+        dm.form_rhs(x, 0.0, 1.0, mesh=m2)
+    for o in (ksp, x, y, K, dm):
+        o.destroy()
+
+
+def test_max_iterations_and_unpreconditioned(gpu_ctx, oracle):
+    m = structured_quad(12, 9, jitter=0.1)
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K = capi.Mat(dm); K.assemble_elements(); K.apply_kbc()
+    F, U = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof)
+    dm.form_rhs(F, 0.0, m.dt)
+    ksp = capi.KSP(gpu_ctx); ksp.set_operators(K)
+    ksp.set_tolerances(rtol=1e-12, max_it=7)
+    ksp.solve(F, U)
+    assert ksp.get_converged_reason() == -3 and ksp.get_iteration_number() == 7      # KSP_DIVERGED_ITS
+    rp, ci = oracle.csr_pattern(m); val = oracle.assemble(m, rp, ci)
+    xo, its, reason, rn, hist = oracle.ksp_cg_jacobi(rp, ci, val, oracle.form_rhs(m, 0.0, m.dt), rtol=1e-12, maxit=7,
+                                                     hist_len=16)
+    assert reason == -3 and its == 7
+    h = ksp.get_residual_history()
+    assert len(h) == 8 and np.allclose(h, hist, rtol=1e-9)
+    assert np.abs(U.get_array() - xo).max() <= 1e-9 * np.abs(xo).max()
+    # zero right-hand side: converged at iteration 0 (PETSc: rnorm <= ttol with ttol = abstol -> CONVERGED_ATOL)
+    F.set(0.0)
+    ksp.set_tolerances(max_it=1000)
+    ksp.solve(F, U)
+    assert ksp.get_iteration_number() == 0 and ksp.get_converged_reason() == 3 and U.norm() == 0.0
+    for o in (ksp, F, U, K, dm):
+        o.destroy()
+
+
+def test_degenerate_meshes(gpu_ctx, oracle):
+    # no elements at all: every node is isolated, the Mat holds empty diagonal blocks
+    m = Mesh(pdim=2, eltype=np.zeros(0), eptr=[0], conn=np.zeros(0), mat_id=np.zeros(0),
+             coords=np.random.default_rng(0).random((70, 2)), mats=[[1.0, 0.3, 0, 0, 0]])
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K = capi.Mat(dm); K.assemble_elements()
+    rp, ci, v = K.get_csr()
+    assert len(v) == 70 * 4 and not v.any()
+    K.destroy(); dm.destroy()
+    # a fan of 40 triangles: one long row (41 neighbours) among short ones; solve against the oracle
+    f = _tri_fan(40)
+    from fem_amd import driver
+    res = driver.run(f, "-ksp_rtol 1e-13", ctx=gpu_ctx)
+    u, s, _ = oracle.run(f, "cg", rtol=1e-13)
+    assert np.abs(res.aggregate_u - u).max() <= 1e-10 * np.abs(u).max()
+    # more neighbours than the symbolic phase supports: loud error, not corruption
+    big = _tri_fan(120)
+    dm = capi.DeviceMesh(gpu_ctx, big)
+    with pytest.raises(capi.FemError, match="neighbour nodes"):
+        capi.Mat(dm)
+    dm.destroy()

@@ -162,3 +162,34 @@ def test_rcb_partition_and_split(nparts):
             j = list(qnr).index(r)
             assert np.array_equal(nl2g[r][nodes[ptr[i]:ptr[i + 1]]], nl2g[q][qnodes[qptr[j]:qptr[j + 1]]])
     assert (seen >= 1).all()
+
+
+def test_product_element_tables_match_reference_goldens():
+    """fem_el_counts / fem_el_tables are host-side (no GPU needed): the constants the kernels read
+    from __constant__ memory, pinned against the reference-generated goldens."""
+    import json
+    from fem_amd import capi
+    gold = json.load(open(os.path.join(HERE, "golden", "element_golden.json")))["types"]
+    for name, t in (("tri", 1), ("qua", 2), ("tet", 3), ("hex", 4)):
+        g = gold[name]
+        assert capi.el_counts(t) == (g["nodecount"], g["nip"], g["dim"], g["nps"], g["vtkid"])
+        ip, w, shp, inv = capi.el_tables(t)
+        assert np.abs(ip - np.array(g["ipoints"])).max() < 1e-15
+        assert np.abs(w - np.array(g["weights"])).max() < 1e-15
+        assert np.abs(shp - np.array(g["shape"])).max() < 1e-15
+        if g["n2inv"] is None:
+            assert inv is None
+        else:
+            assert np.abs(inv - np.array(g["n2inv"])).max() < 1e-13
+    assert capi.el_counts(5) == (4, 2, 2, 2, 9)                       # coh
+    assert list(capi.form_el_indx(3, [4, 9, 2])) == [12, 13, 14, 27, 28, 29, 6, 7, 8]
+
+
+def test_capi_error_codes_without_gpu():
+    from fem_amd import capi
+    with pytest.raises(capi.FemError, match="unknown element type"):
+        capi.el_counts(9)
+    import ctypes as C
+    out = (C.c_int * 4)()
+    assert capi._lib.fem_form_el_indx(4, 1, out, out) != 0            # pdim must be 2 or 3
+    assert b"pdim" in capi._lib.fem_last_error()

@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--jitter", type=float, default=0.0)
+    ap.add_argument("--force-comm", action="store_true",
+                    help="diagnostic: also at N=1 create the RCCL communicator and route the CG scalars through it")
     args = ap.parse_args()
 
     import torch
@@ -87,7 +89,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_comm = world > 1 or args.force_comm
+    if args.force_comm:
+        os.environ["FEM_AMD_FORCE_COLLECTIVES"] = "1"
+    if use_comm and "MASTER_ADDR" in os.environ:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = capi.Context(local_rank)
@@ -95,11 +100,12 @@ def main():
     npr = (args.n, args.n, args.n)
     mesh = partition.brick_mesh(rank, grid, npr, jitter=args.jitter)
     comm = halo = None
-    if world > 1:
+    if use_comm:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
+        if dist.is_initialized():
+            dist.broadcast(uid, 0)
         comm = capi.Comm.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
         halo = partition.brick_halo(rank, grid, npr)
     prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r}", comm=comm, halo=halo)
@@ -186,7 +192,7 @@ def main():
     if comm is not None:
         comm.destroy()
     ctx.destroy()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

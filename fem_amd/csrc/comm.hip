@@ -43,10 +43,16 @@ static RcclApi& rccl()
     static RcclApi api;
     static std::once_flag once;
     std::call_once(once, [] {
+        // prefer a copy the process already holds (PyTorch-ROCm links its own librccl), so that
+        // a launcher using torch.distributed and this library share one RCCL instance
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* n : names) {
-            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
             if (api.lib) break;
+        }
+        for (const char* n : names) {
+            if (api.lib) break;
+            api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!api.lib) return;
         api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");

@@ -261,7 +261,6 @@ void mesh_set_halo_impl(fem_mesh mesh, fem_comm comm, int nneigh, const int* nei
     h->contrib_ptr.alloc(cptr.size()); h->contrib_ptr.upload(cptr.data(), cptr.size(), s);
     h->contrib_src.alloc(std::max<size_t>(csrc.size(), 1)); h->contrib_src.upload(csrc.data(), csrc.size(), s);
     h->owned.alloc(mesh->nnds); h->owned.upload(owned.data(), owned.size(), s);
-    h->buf_nodes = nslots;
     h->sendbuf.alloc(std::max<size_t>((size_t)nslots * 6, 1));
     h->recvbuf.alloc(std::max<size_t>((size_t)nslots * 6, 1));
     FEM_HIP(hipStreamSynchronize(s));

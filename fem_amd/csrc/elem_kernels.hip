@@ -60,7 +60,11 @@ struct DenseSrc {  // caller-supplied ecoords(nodecount,pdim) per element, colum
 // ---- sinks for the element matrix ---------------------------------------------------------
 template <int PD, int NPE>
 struct MatSink {  // MatSetValues(ADD_VALUES) into the sliced block-ELL Mat_K
+    static constexpr bool PAIR = (NPE == 8 || (NPE == 4 && PD == 2));  // hex8 / quad4: x-adjacent elements share a face
     const int* conn;
+    __device__ __forceinline__ long long pair_key(size_t e, int a, int b) const {
+        return ((long long)conn[e * NPE + a] << 32) | (long long)(unsigned)conn[e * NPE + b];
+    }
     const uint16_t* slot;
     const int* boff;
     double* val;
@@ -76,6 +80,7 @@ struct MatSink {  // MatSetValues(ADD_VALUES) into the sliced block-ELL Mat_K
 };
 template <int PD, int NPE>
 struct DenseSink {  // k(nd,nd) column-major per element (FormElKE's out-argument)
+    static constexpr bool PAIR = false;
     double* k;
     __device__ __forceinline__ void add(size_t e, int a, int b, const double (&blk)[PD][PD]) const {
         constexpr int ND = NPE * PD;
@@ -86,6 +91,58 @@ struct DenseSink {  // k(nd,nd) column-major per element (FormElKE's out-argumen
             for (int q = 0; q < PD; q++) p[(a * PD + i) + (size_t)(b * PD + q) * ND] = blk[i][q];
     }
 };
+
+// ---- wavefront pre-reduction of shared-node contributions ----------------------------------
+// A wavefront of phase 2 holds 32 consecutive elements x 2 local nodes.  On
+// structured numberings the +x face node of element e and the -x face node of
+// element e+1 are the same global node, and they sit 33 lanes apart
+// (receiver = donor + 33 mod 64).  Instead of two atomics on the same address,
+// the donor hands its value to the receiver with a cross-lane move and stays
+// silent.  The pairing is decided at run time from the node ids (and, for the
+// stiffness, the column node ids), so any mesh is handled: without a match every
+// lane simply issues its own atomic.  A lane that receives never donates (no chains).
+struct WavePair {
+    int donor_lane, recv_lane;
+    bool donate, recv;
+};
+__device__ __forceinline__ WavePair wave_pair(long long key)
+{
+    const int lane = threadIdx.x & 63;
+    WavePair p;
+    p.donor_lane = (lane + 31) & 63;
+    p.recv_lane = (lane + 33) & 63;
+    const long long kd = __shfl(key, p.donor_lane), kr = __shfl(key, p.recv_lane);
+    const bool recv_raw = (kd == key) && key >= 0, donate_raw = (kr == key) && key >= 0;
+    p.donate = donate_raw && !recv_raw;
+    // every lane must execute the cross-lane read (no short-circuit in front of it): a
+    // masked-off source lane would deliver garbage
+    const int donor_donates = __shfl((int)p.donate, p.donor_lane);
+    p.recv = recv_raw && (donor_donates != 0);
+    return p;
+}
+
+// local nodes on the +x face (quad4: 1,2; hex8: 1,2,5,6) and the column visiting order
+template <int NPE, int PD>
+__device__ __forceinline__ bool is_plus_x(int a)
+{
+    if constexpr (NPE == 8) return a == 1 || a == 2 || a == 5 || a == 6;
+    else if constexpr (NPE == 4 && PD == 2) return a == 1 || a == 2;
+    else return false;
+}
+template <int NPE, int PD>
+__device__ __forceinline__ int column_order(bool plus, int k)
+{
+    if constexpr (NPE == 8) {
+        // pairs (+x, -x): (1,0) (2,3) (5,4) (6,7)
+        const int p[4] = {1, 2, 5, 6}, m[4] = {0, 3, 4, 7};
+        return plus ? (k < 4 ? p[k] : m[k - 4]) : (k < 4 ? m[k] : p[k - 4]);
+    } else if constexpr (NPE == 4 && PD == 2) {
+        const int p[2] = {1, 2}, m[2] = {0, 3};
+        return plus ? (k < 2 ? p[k] : m[k - 2]) : (k < 2 ? m[k] : p[k - 2]);
+    } else {
+        return k;
+    }
+}
 
 // ---- element stiffness ----------------------------------------------------------------------
 template <int PD, int NPE, int NIP, int ELB, class Src, class Sink>
@@ -108,17 +165,25 @@ __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
         G[(q * K + K - 1) * ELB + el] = tab.w[q] * detj;  // weights(i)*detj, src/m_local.F90:64
     }
     __syncthreads();
-    if (q >= NPE || e >= (size_t)nel) return;
-    const DCoef D = dmat_coef(Ev[e], nuv[e]);
+    const bool active = (q < NPE && e < (size_t)nel);
+    if (!Sink::PAIR && !active) return;   // with pairing every lane must reach the cross-lane moves
+    const size_t es = active ? e : 0;
+    const int qa = active ? q : 0;
+    const DCoef D = dmat_coef(Ev[es], nuv[es]);
     double da[NIP][PD];  // w*detJ * dN_a/dx at every Gauss point
 #pragma unroll
     for (int g = 0; g < NIP; g++) {
         const double w = G[(g * K + K - 1) * ELB + el];
 #pragma unroll
-        for (int d = 0; d < PD; d++) da[g][d] = w * G[(g * K + q * PD + d) * ELB + el];
+        for (int d = 0; d < PD; d++) da[g][d] = w * G[(g * K + qa * PD + d) * ELB + el];
     }
+    // Column order: rows on the +x face visit the +x face columns first, rows on the -x face
+    // the matching -x face columns, so that the two lanes holding the same (row node, column
+    // node) pair of x-adjacent elements reach it in the same trip and can be paired.
+    const bool plus = is_plus_x<NPE, PD>(qa);
 #pragma unroll 1
-    for (int b = 0; b < NPE; b++) {
+    for (int k = 0; k < NPE; k++) {
+        const int b = column_order<NPE, PD>(plus, k);
         double blk[PD][PD];
 #pragma unroll
         for (int i = 0; i < PD; i++)
@@ -141,7 +206,22 @@ __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
                     blk[i][j] += (i == j) ? D.d11 * prod[i] + D.d44 * (dot - prod[i])
                                           : D.d12 * da[g][i] * db[j] + D.d44 * da[g][j] * db[i];
         }
-        sink.add(e, q, b, blk);
+        if constexpr (Sink::PAIR) {
+            const long long key = active ? sink.pair_key(es, qa, b) : -1 - (long long)threadIdx.x;
+            const WavePair wp = wave_pair(key);
+            if (__any(wp.recv)) {
+#pragma unroll
+                for (int i = 0; i < PD; i++)
+#pragma unroll
+                    for (int j = 0; j < PD; j++) {
+                        const double in = __shfl(blk[i][j], wp.donor_lane);
+                        if (wp.recv) blk[i][j] += in;
+                    }
+            }
+            if (active && !wp.donate) sink.add(es, qa, b, blk);
+        } else {
+            sink.add(es, qa, b, blk);
+        }
     }
 }
 
@@ -235,19 +315,23 @@ __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
     }
     if constexpr (NODAL) {
         __syncthreads();
-        if (q >= NPE || e >= (size_t)nel) return;
-        const size_t v = (size_t)conn[e * NPE + q];
+        const bool active = (q < NPE && e < (size_t)nel);
+        const long long v = active ? (long long)conn[e * NPE + q] : -1 - (long long)threadIdx.x;
+        const WavePair wp = wave_pair(v);   // all lanes take part in the cross-lane moves
 #pragma unroll
         for (int c = 0; c < CP; c++) {
-            double sn;
-            if constexpr (NIP == NPE) {  // sigma_node = N2^-1 sigma_gp, src/m_global.F90:506-509
-                sn = 0.0;
+            double sn = 0.0;
+            if (active) {
+                if constexpr (NIP == NPE) {  // sigma_node = N2^-1 sigma_gp, src/m_global.F90:506-509
 #pragma unroll
-                for (int g = 0; g < NIP; g++) sn += tab.n2inv[q][g] * S[(g * CP + c) * ELB + el];
-            } else {  // nip == 1: copy, src/m_global.F90:510-513
-                sn = S[c * ELB + el];
+                    for (int g = 0; g < NIP; g++) sn += tab.n2inv[q][g] * S[(g * CP + c) * ELB + el];
+                } else {  // nip == 1: copy, src/m_global.F90:510-513
+                    sn = S[c * ELB + el];
+                }
             }
-            unsafeAtomicAdd(out + (size_t)c * nn + v, sn);
+            const double from_donor = __shfl(sn, wp.donor_lane);
+            if (wp.recv) sn += from_donor;
+            if (active && !wp.donate) unsafeAtomicAdd(out + (size_t)c * nn + (size_t)v, sn);
         }
     }
 }
@@ -368,7 +452,7 @@ static void dispatch_type(int type, F&& f)
     case FEM_TRI: f(std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 1>{},
                     std::integral_constant<int, 64>{}); break;
     case FEM_QUA: f(std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{},
-                    std::integral_constant<int, 64>{}); break;
+                    std::integral_constant<int, 32>{}); break;
     case FEM_TET: f(std::integral_constant<int, 3>{}, std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{},
                     std::integral_constant<int, 64>{}); break;
     case FEM_HEX: f(std::integral_constant<int, 3>{}, std::integral_constant<int, 8>{}, std::integral_constant<int, 8>{},

@@ -247,7 +247,6 @@ struct fem_ksp_s {
     DBuf<KspState> state;
     KspState* h_state = nullptr;  // pinned, two poll slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
-    int final_slot = -1;
     int hist_len = 0;
     int its = 0, reason = 0;
     double rnorm = 0.0;
@@ -404,7 +403,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
             const int ps = slot ^ 1;
             FEM_HIP(hipEventSynchronize(k->poll_ev[ps]));
             const KspState& hs = k->h_state[ps];
-            if (hs.done) { finished = true; k->final_slot = ps; break; }
+            if (hs.done) { finished = true; break; }
             if (!comm && prev_it >= 0 && hs.it > prev_it && hs.dp > 0 && prev_dp > hs.dp && hs.ttol > 0) {
                 const double rate = std::log(prev_dp / hs.dp) / (hs.it - prev_it);   // decades per iteration (ln)
                 const double remaining = std::log(hs.dp / hs.ttol) / rate - chunk;   // beyond what is already queued
@@ -414,9 +413,6 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
         }
         have_pending = true;
         slot ^= 1;
-    }
-    if (!finished || k->final_slot < 0) {
-        FEM_HIP(hipStreamSynchronize(s));
     }
     // drain whatever was queued behind the deciding poll (no-ops on the device)
     FEM_HIP(hipStreamSynchronize(s));

@@ -5,7 +5,6 @@
 // connectivity conn[nel][npe] per element type, coords[nnds][pdim] once, and
 // (E, nu) per element.
 #include "objects.h"
-#include "scan.h"
 
 using namespace fem;
 

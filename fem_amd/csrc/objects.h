@@ -33,7 +33,6 @@ struct Halo {
     DBuf<int> contrib_src;   // [contrib_ptr[ninodes]]  recv-buffer node slot or -1
     DBuf<unsigned char> owned;  // [nnds] 1 if this domain owns the node (lowest rank among sharers)
     DBuf<double> sendbuf, recvbuf;  // sized for max components (6) * interface nodes
-    size_t buf_nodes = 0;
 };
 
 }  // namespace fem
@@ -73,7 +72,6 @@ struct fem_mat_s {
     std::vector<int> h_boff, h_rowlen;
     fem::DBuf<double> spmv_partial;  // per-workgroup partials of the fused p.Kp
     int spmv_grid = 0;
-    fem::DBuf<double> halo_diag_scratch;
 };
 
 struct fem_ksp_s;

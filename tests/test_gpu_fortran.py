@@ -61,3 +61,20 @@ def test_fortran_driver_mixed_deck_matches_oracle(tmp_path, oracle):
     uo, so, _ = oracle.run(read_inp(deck), "lu")
     assert np.abs(full[:, :2].ravel() - uo).max() <= 1e-10 * np.abs(uo).max()
     assert np.abs(full[:, 2:] - so).max() <= 1e-9 * np.abs(so).max()
+
+
+def test_plain_c_client_of_the_abi(tmp_path):
+    """include/fem_amd.h consumed by gcc as C99 (no C++ types leak through the boundary)."""
+    exe = tmp_path / "abi_smoke"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe),
+                           "-L", os.path.join(ROOT, "fem_amd", "lib"), "-lfem_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "fem_amd", "lib")])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    rows = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("NODE")]
+    assert "STEPS 10" in p.stdout and len(rows) == 6
+    got = np.array([[float(x) for x in r[2:]] for r in rows])
+    expect_u = np.array([[0, .1], [0, .05], [0, 0], [0, .1], [0, .05], [0, 0]])
+    assert np.abs(got[:, :2] - expect_u).max() < 1e-12
+    assert np.abs(got[:, 2:] - np.array([105.0, 245.0, 0.0])).max() < 1e-9

@@ -193,3 +193,18 @@ def test_capi_error_codes_without_gpu():
     out = (C.c_int * 4)()
     assert capi._lib.fem_form_el_indx(4, 1, out, out) != 0            # pdim must be 2 or 3
     assert b"pdim" in capi._lib.fem_last_error()
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/fem_amd.h compiles as strict C99 and the plain-C client links against the library."""
+    import subprocess
+    obj = tmp_path / "abi_smoke.o"
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-c",
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(obj)])
+    exe = tmp_path / "abi_smoke"
+    subprocess.check_call(["gcc", str(obj), "-o", str(exe), "-L", os.path.join(ROOT, "fem_amd", "lib"), "-lfem_amd",
+                           "-Wl,-rpath," + os.path.join(ROOT, "fem_amd", "lib")])
+    from fem_amd import capi
+    if capi.device_count() == 0:
+        p = subprocess.run([str(exe)], capture_output=True, text=True)
+        assert p.returncode != 0 and "no HIP device" in p.stderr       # loud failure, no fallback

@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--jitter", type=float, default=0.0)
+    ap.add_argument("--pc", default="jacobi", help="preconditioner of the timed (headline) solve: jacobi (north_star) | mg")
+    ap.add_argument("--no-mg", action="store_true", help="skip the extra -pc_type mg measurement at N=1")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: also at N=1 create the RCCL communicator and route the CG scalars through it")
     args = ap.parse_args()
@@ -108,7 +110,8 @@ def main():
             dist.broadcast(uid, 0)
         comm = capi.Comm.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
         halo = partition.brick_halo(rank, grid, npr)
-    prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r}", comm=comm, halo=halo)
+    pc_opts = {"jacobi": "-pc_type jacobi", "mg": "-pc_type mg -pc_mg_type additive"}[args.pc]
+    prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} {pc_opts}", comm=comm, halo=halo)
     prob.ksp.set_profiling(True)
 
     def barrier():
@@ -156,6 +159,27 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = ndof_global * args.steps / elapsed
 
+    # second measurement (N=1): the same step with the box-aggregation multigrid preconditioner
+    #  behind the same KSP surface -- reported beside the CG/Jacobi headline
+    mg_line = None
+    if world == 1 and args.pc == "jacobi" and not args.no_mg:
+        prob.ksp.set_from_options("-pc_type mg -pc_mg_type additive")
+        for _ in range(args.warmup):
+            one_step()
+        barrier()
+        t1 = time.perf_counter()
+        ma = ms_ = 0.0
+        for _ in range(args.steps):
+            a, s_ = one_step()
+            ma += a; ms_ += s_
+        barrier()
+        el = time.perf_counter() - t1
+        mg_line = {"options": "-ksp_type cg -pc_type mg -pc_mg_type additive", "value": ndof_global * args.steps / el,
+                   "unit": "DOF/s", "ms_per_step": el / args.steps * 1e3, "cg_iterations": prob.ksp.get_iteration_number(),
+                   "converged_reason": prob.ksp.get_converged_reason(),
+                   "t_assemble_ms": ma / args.steps * 1e3, "t_solve_ms": ms_ / args.steps * 1e3,
+                   "speedup_over_jacobi": (elapsed / args.steps) / (el / args.steps)}
+
     if rank == 0:
         alg = spmv_algorithmic_bytes(nnz, nrows)
         avg_ms = spmv_ms / max(n_spmv, 1)
@@ -174,7 +198,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config 3: {args.n}^3 hex8 cube per GPU, E=3e10 nu=0.25, z=0 clamped, "
-                                   f"top face u_z=-0.01*n by penalty, CG/Jacobi rtol={args.rtol:.3g}",
+                                   f"top face u_z=-0.01*n by penalty, CG/{args.pc} rtol={args.rtol:.3g}",
                        "bricks": list(grid), "dof_global": ndof_global, "dof_per_gpu": nrows, "nnz_per_gpu": nnz,
                        "cg_iterations": its, "converged_reason": reason,
                        "t_assemble_ms": t_asm / args.steps * 1e3, "t_solve_ms": t_sol / args.steps * 1e3},
@@ -183,6 +207,8 @@ def main():
                          "algorithmic_bytes": alg, "avg_launch_ms": avg_ms, "launches": n_spmv,
                          "format_bytes": fmt_bytes, "format_GBs": fmt_bytes / (avg_ms * 1e-3) / 1e9},
         }
+        if mg_line is not None:
+            out["config"]["pc_mg"] = mg_line
         if world == 1 and not args.no_cpu:
             threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
             out["cpu_baseline"] = cpu_baseline(args.n, its, threads)

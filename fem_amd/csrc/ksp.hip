@@ -21,6 +21,7 @@
 #include <sstream>
 
 #include "comm.h"
+#include "mg.h"
 #include "objects.h"
 
 using namespace fem;
@@ -131,6 +132,30 @@ __global__ void __launch_bounds__(256) k_cg_init(size_t n, int pd, const double*
     if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
 }
 
+// partials of z.z and z.r for an externally applied preconditioner
+__global__ void __launch_bounds__(256) k_dot2(size_t n, int pd, const double* __restrict__ z, const double* __restrict__ r,
+                                              const unsigned char* __restrict__ owned, double* __restrict__ pzz,
+                                              double* __restrict__ pzr, const int* __restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double sh[4];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    double zz = 0.0, zr = 0.0;
+    for (; i < n; i += st)
+        if (!owned || owned[i / pd]) { zz += z[i] * z[i]; zr += z[i] * r[i]; }
+    zz = block_sum(zz, sh);
+    zr = block_sum(zr, sh);
+    if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
+}
+__global__ void __launch_bounds__(256) k_cg_init_ext(size_t n, const double* __restrict__ b, double* __restrict__ x,
+                                                     double* __restrict__ r, double* __restrict__ p)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { x[i] = 0.0; r[i] = b[i]; p[i] = 0.0; }
+}
+
 // ---- the two fused CG kernels ---------------------------------------------------------------
 // Every workgroup evaluates the scalar logic of PETSc's KSPSolve_CG redundantly
 // from the same inputs (so all agree); workgroup 0 / thread 0 records the result
@@ -149,7 +174,7 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
                                                      int npart, double rtol, double abstol, double dtol, int maxit,
                                                      double* __restrict__ hist, int hist_len,
                                                      const double* __restrict__ dinv, const double* __restrict__ r,
-                                                     double* __restrict__ p)
+                                                     double* __restrict__ p, const double* __restrict__ zext)
 {
     if (st->done) return;
     __shared__ double sh[4];
@@ -188,7 +213,8 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
     if (reason) return;
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t str = (size_t)gridDim.x * blockDim.x;
-    for (; q < n; q += str) p[q] = dinv[q] * r[q] + b * p[q];
+    if (zext) { for (; q < n; q += str) p[q] = zext[q] + b * p[q]; }   // z = M^-1 r applied by a separate PC
+    else { for (; q < n; q += str) p[q] = dinv[q] * r[q] + b * p[q]; }
 }
 
 // alpha = beta / p.w, then x += a p ; r -= a w ; z = M^-1 r ; partials of z.z and z.r
@@ -220,6 +246,10 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t str = (size_t)gridDim.x * blockDim.x;
     double zz = 0.0, zr = 0.0;
+    if (!dinv) {   // external preconditioner: z and its dot products come from later kernels
+        for (; q < n; q += str) { x[q] += a * p[q]; r[q] -= a * w[q]; }
+        return;
+    }
     for (; q < n; q += str) {
         x[q] += a * p[q];
         const double ri = r[q] - a * w[q];
@@ -243,7 +273,10 @@ struct fem_ksp_s {
     int maxit = 10000;
     bool setup_done = false;
     long long n = 0;
-    DBuf<double> dinv, r, p, w, pzz, pzr, hist;
+    DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
+    std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
+    bool mg_additive = false;
+    double mg_alpha = 1.0, mg_omega = 0.7;
     DBuf<KspState> state;
     KspState* h_state = nullptr;  // pinned, two poll slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -272,9 +305,17 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         if (key == "-ksp_type") { is >> val; FEM_CHECK(val == "cg", 6, "unsupported -ksp_type " + val + " (cg)"); k->type = val; }
         else if (key == "-pc_type") {
             is >> val;
-            FEM_CHECK(val == "jacobi" || val == "none", 6, "unsupported -pc_type " + val + " (jacobi|none)");
-            k->pc = val;
+            FEM_CHECK(val == "jacobi" || val == "none" || val == "mg" || val == "gamg", 6,
+                      "unsupported -pc_type " + val + " (jacobi|none|mg)");
+            k->pc = (val == "gamg") ? "mg" : val;
         }
+        else if (key == "-pc_mg_type") {
+            is >> val;
+            FEM_CHECK(val == "multiplicative" || val == "additive", 6, "unsupported -pc_mg_type " + val);
+            k->mg_additive = (val == "additive");
+        }
+        else if (key == "-pc_mg_alpha") { is >> k->mg_alpha; }     // coarse-correction scaling (over-correction)
+        else if (key == "-pc_mg_omega") { is >> k->mg_omega; }     // Jacobi damping of the smoother
         else if (key == "-ksp_rtol") { is >> k->rtol; }
         else if (key == "-ksp_atol") { is >> k->abstol; }
         else if (key == "-ksp_divtol") { is >> k->dtol; }
@@ -306,7 +347,15 @@ void ksp_set_up_impl(fem_ksp k)
     }
     k->hist_len = k->maxit + 1;
     k->hist.alloc((size_t)k->hist_len);
-    if (k->pc == "jacobi") {
+    k->mg.reset();
+    if (k->pc == "mg") {
+        k->mg.reset(new fem::Multigrid);
+        k->mg->fine_additive = k->mg_additive;
+        k->mg->alpha = k->mg_alpha; k->mg->omega = k->mg_omega;
+        k->mg->setup(A);
+        k->z.alloc(n);
+    }
+    if (k->pc == "jacobi" || k->pc == "mg") {
         mat_get_diagonal_raw(A, k->dinv.p);
         halo_sum(A->mesh, k->dinv.p, A->bs, A->bs, 1);
         hipLaunchKernelGGL(k_jacobi_setup, dim3(vgrid(n)), dim3(256), 0, s, k->dinv.p, n);
@@ -349,8 +398,23 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     };
 
     FEM_HIP(hipMemsetAsync(st, 0, sizeof(KspState), s));
-    hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, s, n, pd, b->d.p, k->dinv.p, x->d.p, k->r.p, k->p.p, owned,
-                       k->pzz.p, k->pzr.p);
+    fem::Multigrid* mg = k->mg.get();   // external preconditioner: z is a vector produced by a V-cycle
+    auto apply_pc_and_dots = [&] {
+        if (mg->fuses_dots() && !owned) {
+            mg->apply(k->r.p, k->z.p, &st->done, k->pzz.p, k->pzr.p, (int)g);
+        } else {
+            mg->apply(k->r.p, k->z.p, &st->done);
+            hipLaunchKernelGGL(k_dot2, dim3(g), dim3(256), 0, s, n, pd, k->z.p, k->r.p, owned, k->pzz.p, k->pzr.p,
+                               &st->done);
+        }
+    };
+    if (mg) {
+        hipLaunchKernelGGL(k_cg_init_ext, dim3(g), dim3(256), 0, s, n, b->d.p, x->d.p, k->r.p, k->p.p);
+        apply_pc_and_dots();
+    } else {
+        hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, s, n, pd, b->d.p, k->dinv.p, x->d.p, k->r.p, k->p.p, owned,
+                           k->pzz.p, k->pzr.p);
+    }
     // multi-domain: reduce -> all-reduce -> logic reads st->red;  single domain: logic reduces the partials itself
     auto reduce_zz_zr = [&] {
         if (!comm) return;
@@ -364,7 +428,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     auto one_iteration = [&] {
         hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
-                           k->hist_len, k->dinv.p, k->r.p, k->p.p);
+                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr);
         if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
         mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
         if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
@@ -377,8 +441,10 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
             halo_sum(A->mesh, k->w.p, pd, pd, 1);
         }
         hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st,
-                           reduce_pw_first ? nullptr : A->spmv_partial.p, A->spmv_grid, k->dinv.p, k->p.p, k->w.p,
-                           x->d.p, k->r.p, owned, k->pzz.p, k->pzr.p);
+                           reduce_pw_first ? nullptr : A->spmv_partial.p, A->spmv_grid,
+                           mg ? (const double*)nullptr : k->dinv.p, k->p.p, k->w.p, x->d.p, k->r.p, owned, k->pzz.p,
+                           k->pzr.p);
+        if (mg) apply_pc_and_dots();
         reduce_zz_zr();
     };
     // The host runs ahead of the device: chunk c+1 is enqueued before chunk c's
@@ -479,9 +545,10 @@ void ksp_set_type(fem_ksp k, const char* t)
 }
 void ksp_set_pc_type(fem_ksp k, const char* t)
 {
-    FEM_CHECK(t && (std::string(t) == "jacobi" || std::string(t) == "none"), 6,
+    const std::string v = t ? t : "";
+    FEM_CHECK(v == "jacobi" || v == "none" || v == "mg" || v == "gamg", 6,
               std::string("fem_ksp_set_pc_type: unsupported type ") + (t ? t : "(null)"));
-    k->pc = t; k->setup_done = false;
+    k->pc = (v == "gamg") ? "mg" : v; k->setup_done = false;
 }
 void ksp_set_tolerances(fem_ksp k, double rtol, double abstol, double dtol, int maxit)
 {

@@ -1,0 +1,50 @@
+// fem_amd/csrc/mg.h -- box-aggregation multigrid preconditioner (`-pc_type mg`).
+//
+// "better preconditioner behind the same KSP surface ... to cut
+// CG iterations once SpMV is at roofline".  Unsmoothed-aggregation multigrid whose
+// aggregates are the cells of a uniform box grid laid over the node coordinates
+// (level 1: about 4 nodes per box edge; every further level merges 2x2x2 boxes).
+// Because boxes are a structured index space even on unstructured meshes, every
+// coarse operator is a dense 27-point block stencil: no coarse symbolic phase,
+// trivially parallel Galerkin products, coalesced box-major storage.
+//   P     piecewise constant per displacement component, zero on penalty dofs
+//   A_c   = P^T A P (Galerkin), exact dense inverse on the coarsest grid
+//   cycle V(1,1) with damped Jacobi, symmetric -> valid CG preconditioner
+#pragma once
+#include <vector>
+
+#include "objects.h"
+
+namespace fem {
+
+struct MgLevel {
+    int nx = 0, ny = 0, nz = 0, nb = 0;
+    DBuf<double> st;    // [27][bs*bs][nb]  stencil entries, box index fastest
+    DBuf<double> dinv;  // [nb*bs]
+    DBuf<double> x, r, t, xn;
+};
+
+struct Multigrid {
+    fem_mat A = nullptr;
+    int bs = 0, nn = 0;
+    double omega = 0.7, alpha = 1.0;
+    bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
+    std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
+    DBuf<int> agg;                  // [nn] level-1 box of every node
+    DBuf<int> box_ptr, box_nodes;   // level-1 box -> its nodes (ascending)
+    DBuf<double> w;                 // [nn*bs] 1 on free dofs, 0 on penalty dofs
+    DBuf<double> dinv0, t0;         // fine-level Jacobi inverse diagonal, work vector
+    DBuf<double> cinv;              // dense inverse of the coarsest operator
+    int ncoarse = 0;
+    void setup(fem_mat A);
+    // z = M^-1 r  (one V-cycle, zero initial guess); `done` (device flag, may be null) lets the
+    // two fine-level products return immediately once the enclosing solve has finished
+    // With pzz/pzr (npart partials each) the additive form also leaves the partial sums of z.z
+    // and z.r there (fuses_dots() tells the caller whether it did).
+    void apply(const double* r, double* z, const int* done = nullptr, double* pzz = nullptr, double* pzr = nullptr,
+               int npart = 0);
+    bool fuses_dots() const;
+    size_t device_bytes() const;
+};
+
+}  // namespace fem

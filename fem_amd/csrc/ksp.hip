@@ -276,7 +276,7 @@ struct fem_ksp_s {
     DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
     std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
     bool mg_additive = false;
-    double mg_alpha = 1.0, mg_omega = 0.7;
+    double mg_alpha = -1.0, mg_omega = 0.7;  // alpha < 0: default (1.3 over-correction for the additive form, 1 for the V-cycle)
     DBuf<KspState> state;
     KspState* h_state = nullptr;  // pinned, two poll slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -351,7 +351,8 @@ void ksp_set_up_impl(fem_ksp k)
     if (k->pc == "mg") {
         k->mg.reset(new fem::Multigrid);
         k->mg->fine_additive = k->mg_additive;
-        k->mg->alpha = k->mg_alpha; k->mg->omega = k->mg_omega;
+        k->mg->alpha = (k->mg_alpha > 0.0) ? k->mg_alpha : (k->mg_additive ? 1.3 : 1.0);
+        k->mg->omega = k->mg_omega;
         k->mg->setup(A);
         k->z.alloc(n);
     }

@@ -27,7 +27,7 @@ struct MgLevel {
 struct Multigrid {
     fem_mat A = nullptr;
     int bs = 0, nn = 0;
-    double omega = 0.7, alpha = 1.0;
+    double omega = 0.7, alpha = 1.3;
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     DBuf<int> agg;                  // [nn] level-1 box of every node

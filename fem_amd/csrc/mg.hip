@@ -245,25 +245,31 @@ __global__ void __launch_bounds__(256) k_fine_post(size_t n, double omega, const
     for (; i < n; i += st) z[i] += omega * dinv[i] * (r[i] - kz[i]);
 }
 
-// r_1[B] = sum_{i in B} w_i (r_i - (K z)_i)
+// r_1[B] = sum_{i in B} w_i (r_i - (K z)_i)      one wavefront per box, lanes over the box's
+// nodes (ascending), fixed shuffle tree -> bitwise reproducible
 template <int BS>
 __global__ void __launch_bounds__(256) k_restrict_fine(int nb, const int* __restrict__ box_ptr,
                                                        const int* __restrict__ box_nodes, const double* __restrict__ w,
                                                        const double* __restrict__ r, const double* __restrict__ kz,
                                                        double* __restrict__ rc)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (b >= nb) return;
     double acc[BS];
 #pragma unroll
     for (int q = 0; q < BS; q++) acc[q] = 0.0;
-    for (int p = box_ptr[b]; p < box_ptr[b + 1]; p++) {
+    for (int p = box_ptr[b] + lane; p < box_ptr[b + 1]; p += 64) {
         const size_t i = (size_t)box_nodes[p] * BS;
 #pragma unroll
         for (int q = 0; q < BS; q++) acc[q] += w[i + q] * (kz ? r[i + q] - kz[i + q] : r[i + q]);
     }
 #pragma unroll
-    for (int q = 0; q < BS; q++) rc[(size_t)b * BS + q] = acc[q];
+    for (int q = 0; q < BS; q++)
+        for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o);
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < BS; q++) rc[(size_t)b * BS + q] = acc[q];
+    }
 }
 
 // z_i += alpha * w_i * x_1[agg(i)]
@@ -400,6 +406,107 @@ __global__ void __launch_bounds__(256) k_dense_apply(int n, const double* __rest
     x[i] = s;
 }
 
+// ---- all small levels in ONE launch -----------------------------------------------------------------------
+// Levels with at most a few thousand boxes are latency-bound: seven launches each.  One
+// workgroup walks the whole tail of the hierarchy instead (down-sweep, dense coarsest
+// solve, up-sweep) with workgroup barriers between the steps.  Same arithmetic and
+// summation order as the per-level kernels.
+struct SmallLevel {
+    Grid3 g;
+    const double* st;
+    const double* dinv;
+    double *x, *r, *t;
+};
+struct SmallLevels {
+    SmallLevel l[8];
+    int n;
+};
+template <int BS>
+__global__ void __launch_bounds__(1024) k_small_cycle(SmallLevels S, const double* __restrict__ cinv, int ncoarse,
+                                                      double omega, double alpha)
+{
+    constexpr int BB = BS * BS;
+    const int T = blockDim.x, tid = threadIdx.x;
+    for (int l = 0; l + 1 < S.n; l++) {   // down
+        const SmallLevel& L = S.l[l];
+        const SmallLevel& C = S.l[l + 1];
+        const int nb = L.g.nb();
+        for (int i = tid; i < nb * BS; i += T) L.x[i] = omega * L.dinv[i] * L.r[i];
+        __syncthreads();
+        for (int b = tid; b < nb; b += T) {
+            double acc[BS];
+#pragma unroll
+            for (int q = 0; q < BS; q++) acc[q] = L.r[(size_t)b * BS + q];
+            for (int s = 0; s < 27; s++) {
+                int c;
+                if (!neighbour_box(L.g, b, s, c)) continue;
+#pragma unroll
+                for (int q = 0; q < BS; q++)
+#pragma unroll
+                    for (int p = 0; p < BS; p++) acc[q] -= L.st[((size_t)s * BB + q * BS + p) * nb + b] * L.x[(size_t)c * BS + p];
+            }
+#pragma unroll
+            for (int q = 0; q < BS; q++) L.t[(size_t)b * BS + q] = acc[q];
+        }
+        __syncthreads();
+        for (int A = tid; A < C.g.nb(); A += T) {
+            const int ax = A % C.g.nx, ay = (A / C.g.nx) % C.g.ny, az = A / (C.g.nx * C.g.ny);
+            double acc[BS];
+#pragma unroll
+            for (int q = 0; q < BS; q++) acc[q] = 0.0;
+            for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
+                const int fx = 2 * ax + cx, fy = 2 * ay + cy, fz = 2 * az + cz;
+                if (fx >= L.g.nx || fy >= L.g.ny || fz >= L.g.nz) continue;
+                const size_t a = (size_t)(fx + L.g.nx * (fy + L.g.ny * fz)) * BS;
+#pragma unroll
+                for (int q = 0; q < BS; q++) acc[q] += L.t[a + q];
+            }
+#pragma unroll
+            for (int q = 0; q < BS; q++) C.r[(size_t)A * BS + q] = acc[q];
+        }
+        __syncthreads();
+    }
+    {   // coarsest: dense inverse
+        const SmallLevel& L = S.l[S.n - 1];
+        for (int i = tid; i < ncoarse; i += T) {
+            double s = 0.0;
+            for (int j = 0; j < ncoarse; j++) s += cinv[(size_t)i * 2 * ncoarse + ncoarse + j] * L.r[j];
+            L.x[i] = s;
+        }
+        __syncthreads();
+    }
+    for (int l = S.n - 2; l >= 0; l--) {   // up
+        const SmallLevel& L = S.l[l];
+        const SmallLevel& C = S.l[l + 1];
+        const int nb = L.g.nb();
+        for (int a = tid; a < nb; a += T) {
+            const int px = (a % L.g.nx) >> 1, py = ((a / L.g.nx) % L.g.ny) >> 1, pz = (a / (L.g.nx * L.g.ny)) >> 1;
+            const size_t A = (size_t)(px + C.g.nx * (py + C.g.ny * pz)) * BS;
+#pragma unroll
+            for (int q = 0; q < BS; q++) L.x[(size_t)a * BS + q] += alpha * C.x[A + q];
+        }
+        __syncthreads();
+        for (int b = tid; b < nb; b += T) {
+            double acc[BS];
+#pragma unroll
+            for (int q = 0; q < BS; q++) acc[q] = L.r[(size_t)b * BS + q];
+            for (int s = 0; s < 27; s++) {
+                int c;
+                if (!neighbour_box(L.g, b, s, c)) continue;
+#pragma unroll
+                for (int q = 0; q < BS; q++)
+#pragma unroll
+                    for (int p = 0; p < BS; p++) acc[q] -= L.st[((size_t)s * BB + q * BS + p) * nb + b] * L.x[(size_t)c * BS + p];
+            }
+#pragma unroll
+            for (int q = 0; q < BS; q++) L.t[(size_t)b * BS + q] = acc[q];
+        }
+        __syncthreads();
+        for (int i = tid; i < nb * BS; i += T) L.x[i] += omega * L.dinv[i] * L.t[i];
+        __syncthreads();
+    }
+}
+
 // ---- host side ----------------------------------------------------------------------------------------------
 static unsigned g1(size_t n) { return std::max(1u, cdiv(n, 256)); }
 static unsigned gs(size_t n) { return std::min<unsigned>(std::max(1u, cdiv(n, 256)), 2048); }
@@ -496,6 +603,16 @@ static void cycle_t(Multigrid& mg, size_t l)
     MgLevel& L = mg.lev[l];
     const Grid3 g{L.nx, L.ny, L.nz};
     const size_t n = (size_t)L.nb * BS;
+    if (L.nb <= 1024 && mg.lev.size() - l <= 8) {   // the rest of the hierarchy (one box per thread) in one launch
+        SmallLevels S{};
+        S.n = (int)(mg.lev.size() - l);
+        for (int k = 0; k < S.n; k++) {
+            MgLevel& M = mg.lev[l + k];
+            S.l[k] = SmallLevel{Grid3{M.nx, M.ny, M.nz}, M.st.p, M.dinv.p, M.x.p, M.r.p, M.t.p};
+        }
+        hipLaunchKernelGGL(k_small_cycle<BS>, dim3(1), dim3(1024), 0, s, S, mg.cinv.p, mg.ncoarse, mg.omega, mg.alpha);
+        return;
+    }
     if (l + 1 == mg.lev.size()) {
         hipLaunchKernelGGL(k_dense_apply, dim3(g1(n)), dim3(256), 0, s, (int)n, mg.cinv.p, L.r.p, L.x.p);
         return;
@@ -522,8 +639,8 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     if (mg.fine_additive) {
         // fine level additive (Jacobi + coarse-grid correction of the un-smoothed residual): the
         // preconditioner costs no fine-level product; the coarse hierarchy is still a V-cycle
-        hipLaunchKernelGGL(k_restrict_fine<BS>, dim3(g1(L1.nb)), dim3(256), 0, s, L1.nb, mg.box_ptr.p, mg.box_nodes.p,
-                           mg.w.p, r, (const double*)nullptr, L1.r.p);
+        hipLaunchKernelGGL(k_restrict_fine<BS>, dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, L1.nb, mg.box_ptr.p,
+                           mg.box_nodes.p, mg.w.p, r, (const double*)nullptr, L1.r.p);
         cycle_t<BS>(mg, 0);
         if (pzz) {   // the caller wants z.z and z.r as well: one fused pass
             hipLaunchKernelGGL(k_additive_finish<BS>, dim3(npart), dim3(256), 0, s, nn, mg.alpha, mg.agg.p, mg.w.p,
@@ -536,8 +653,8 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     }
     hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
-    hipLaunchKernelGGL(k_restrict_fine<BS>, dim3(g1(L1.nb)), dim3(256), 0, s, L1.nb, mg.box_ptr.p, mg.box_nodes.p, mg.w.p, r,
-                       mg.t0.p, L1.r.p);
+    hipLaunchKernelGGL(k_restrict_fine<BS>, dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, L1.nb, mg.box_ptr.p, mg.box_nodes.p,
+                       mg.w.p, r, mg.t0.p, L1.r.p);
     cycle_t<BS>(mg, 0);
     hipLaunchKernelGGL(k_prolong_fine<BS>, dim3(g1(nn)), dim3(256), 0, s, nn, mg.alpha, mg.agg.p, mg.w.p, L1.x.p, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);

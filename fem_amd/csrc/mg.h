@@ -3,7 +3,7 @@
 // "better preconditioner behind the same KSP surface ... to cut
 // CG iterations once SpMV is at roofline".  Unsmoothed-aggregation multigrid whose
 // aggregates are the cells of a uniform box grid laid over the node coordinates
-// (level 1: about 4 nodes per box edge; every further level merges 2x2x2 boxes).
+// (level 1: about 4 nodes per box edge; every further level merges 2x2x2 boxes, down to <= 5 boxes per direction).
 // Because boxes are a structured index space even on unstructured meshes, every
 // coarse operator is a dense 27-point block stencil: no coarse symbolic phase,
 // trivially parallel Galerkin products, coalesced box-major storage.

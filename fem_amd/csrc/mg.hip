@@ -148,6 +148,57 @@ __global__ void __launch_bounds__(256) k_galerkin_fine(Grid3 g, const int* __res
     for (int e = 0; e < BB; e++) st[((size_t)slot * BB + e) * nb + A] = acc[e];
 }
 
+// The same product with one wavefront per box: lane = node of the box.  For each of the 27 slots
+// every lane sums its own matching blocks (the row's column ids are re-read per slot from L1/L2,
+// the 72-byte values only when they match, i.e. once), then a fixed shuffle tree adds the lanes:
+// bitwise reproducible, no atomics, 64x more parallel than the thread-per-(box,slot) form.
+template <int BS>
+__global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, const int* __restrict__ box_ptr,
+                                                            const int* __restrict__ box_nodes, const int* __restrict__ agg,
+                                                            const int* __restrict__ rowlen, const int* __restrict__ boff,
+                                                            const int* __restrict__ bcol, const double* __restrict__ val,
+                                                            const double* __restrict__ w, double* __restrict__ st,
+                                                            int* __restrict__ err)
+{
+    constexpr int BB = BS * BS;
+    const int nb = g.nb();
+    const int A = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (A >= nb) return;
+    const int ax = A % g.nx, ay = (A / g.nx) % g.ny, az = A / (g.nx * g.ny);
+    const int p0 = box_ptr[A], p1 = box_ptr[A + 1];
+    // pass 1: slot id of each block of the lane's row, 5 bits each, packed in two words per 12 entries
+    // (only the first node chunk of a box is cached; boxes with more than 64 nodes loop below)
+    for (int s = 0; s < 27; s++) {
+        double acc[BB];
+#pragma unroll
+        for (int e = 0; e < BB; e++) acc[e] = 0.0;
+        for (int p = p0 + lane; p < p1; p += 64) {
+            const int i = box_nodes[p];
+            const size_t o0 = (size_t)boff[i >> 6];
+            const int ln = i & 63, len = rowlen[i];
+            for (int j = 0; j < len; j++) {
+                const int c = bcol[(o0 + j) * 64 + ln];
+                const int B = agg[c];
+                const int dx = B % g.nx - ax, dy = (B / g.nx) % g.ny - ay, dz = B / (g.nx * g.ny) - az;
+                if (abs(dx) > 1 || abs(dy) > 1 || abs(dz) > 1) { if (s == 13) atomicExch(err, 1); continue; }
+                if ((dx + 1) + 3 * (dy + 1) + 9 * (dz + 1) != s) continue;
+#pragma unroll
+                for (int r = 0; r < BS; r++)
+#pragma unroll
+                    for (int q = 0; q < BS; q++)
+                        acc[r * BS + q] += w[(size_t)BS * i + r] * w[(size_t)BS * c + q] *
+                                           val[((o0 + j) * BB + r * BS + q) * 64 + ln];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < BB; e++) {
+            double a = acc[e];
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+            if (lane == 0) st[((size_t)s * BB + e) * nb + A] = a;
+        }
+    }
+}
+
 // A_{l+1} = P^T A_l P between two box levels (children = 2x2x2 boxes)
 template <int BS>
 __global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, Grid3 gc, const double* __restrict__ stf,
@@ -217,6 +268,36 @@ __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, const double* __r
     }
 #pragma unroll
     for (int q = 0; q < BS; q++) t[(size_t)b * BS + q] = acc[q];
+}
+
+// same for the small levels, which are latency-bound with one thread per box: 32 lanes per
+// box (one stencil slot each, 27 active), fixed shuffle tree over the slots
+template <int BS>
+__global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, const double* __restrict__ st,
+                                                            const double* __restrict__ x, const double* __restrict__ r,
+                                                            double* __restrict__ t)
+{
+    constexpr int BB = BS * BS;
+    const int nb = g.nb();
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = gid >> 5, s = gid & 31;
+    double acc[BS];
+#pragma unroll
+    for (int q = 0; q < BS; q++) acc[q] = 0.0;
+    int c;
+    if (b < nb && s < 27 && neighbour_box(g, b, s, c)) {
+#pragma unroll
+        for (int q = 0; q < BS; q++)
+#pragma unroll
+            for (int p = 0; p < BS; p++) acc[q] -= st[((size_t)s * BB + q * BS + p) * nb + b] * x[(size_t)c * BS + p];
+    }
+#pragma unroll
+    for (int q = 0; q < BS; q++)
+        for (int o = 16; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 32);
+    if (b < nb && s == 0) {
+#pragma unroll
+        for (int q = 0; q < BS; q++) t[(size_t)b * BS + q] = r[(size_t)b * BS + q] + acc[q];
+    }
 }
 
 // x = omega * dinv * r
@@ -374,137 +455,36 @@ __global__ void __launch_bounds__(256) k_dense_from_stencil(Grid3 g, const doubl
     }
 }
 
-// in-place Gauss-Jordan on [A | I] (n x 2n, row-major); A is symmetric positive (semi-)definite
-// with unit rows for empty boxes, so no pivot search is needed.  Single workgroup.
-__global__ void __launch_bounds__(1024) k_gauss_jordan(int n, double* __restrict__ M)
+// Gauss-Jordan on [A | I] (n x 2n, row-major), two small launches per pivot so that the
+// rank-1 update runs on the whole chip (a single workgroup needs ~50 ms for n = 375).  A is
+// symmetric positive (semi-)definite with unit rows for empty boxes: no pivot search.
+__global__ void __launch_bounds__(256) k_gj_pivot(int n, int k, const double* __restrict__ M, double* __restrict__ rowk,
+                                                  double* __restrict__ colk)
 {
-    __shared__ double piv;
-    for (int k = 0; k < n; k++) {
-        if (threadIdx.x == 0) piv = 1.0 / M[(size_t)k * 2 * n + k];
-        __syncthreads();
-        for (int j = threadIdx.x; j < 2 * n; j += blockDim.x) M[(size_t)k * 2 * n + j] *= piv;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < n * 2 * n; idx += blockDim.x) {
-            const int i = idx / (2 * n), j = idx - i * 2 * n;
-            if (i == k || j == k) continue;
-            M[(size_t)i * 2 * n + j] -= M[(size_t)i * 2 * n + k] * M[(size_t)k * 2 * n + j];
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x)
-            if (i != k) M[(size_t)i * 2 * n + k] = 0.0;
-        __syncthreads();
-    }
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const double piv = 1.0 / M[(size_t)k * 2 * n + k];
+    if (t < 2 * n) rowk[t] = M[(size_t)k * 2 * n + t] * piv;
+    if (t < n) colk[t] = M[(size_t)t * 2 * n + k];
+}
+__global__ void __launch_bounds__(256) k_gj_update(int n, int k, double* __restrict__ M, const double* __restrict__ rowk,
+                                                   const double* __restrict__ colk)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * 2 * n) return;
+    const int i = idx / (2 * n), j = idx - i * 2 * n;
+    M[idx] = (i == k) ? rowk[j] : M[idx] - colk[i] * rowk[j];
 }
 
+// x = A^-1 r on the coarsest grid: one wavefront per row, fixed shuffle tree
 __global__ void __launch_bounds__(256) k_dense_apply(int n, const double* __restrict__ M, const double* __restrict__ r,
                                                      double* __restrict__ x)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= n) return;
     double s = 0.0;
-    for (int j = 0; j < n; j++) s += M[(size_t)i * 2 * n + n + j] * r[j];
-    x[i] = s;
-}
-
-// ---- all small levels in ONE launch -----------------------------------------------------------------------
-// Levels with at most a few thousand boxes are latency-bound: seven launches each.  One
-// workgroup walks the whole tail of the hierarchy instead (down-sweep, dense coarsest
-// solve, up-sweep) with workgroup barriers between the steps.  Same arithmetic and
-// summation order as the per-level kernels.
-struct SmallLevel {
-    Grid3 g;
-    const double* st;
-    const double* dinv;
-    double *x, *r, *t;
-};
-struct SmallLevels {
-    SmallLevel l[8];
-    int n;
-};
-template <int BS>
-__global__ void __launch_bounds__(1024) k_small_cycle(SmallLevels S, const double* __restrict__ cinv, int ncoarse,
-                                                      double omega, double alpha)
-{
-    constexpr int BB = BS * BS;
-    const int T = blockDim.x, tid = threadIdx.x;
-    for (int l = 0; l + 1 < S.n; l++) {   // down
-        const SmallLevel& L = S.l[l];
-        const SmallLevel& C = S.l[l + 1];
-        const int nb = L.g.nb();
-        for (int i = tid; i < nb * BS; i += T) L.x[i] = omega * L.dinv[i] * L.r[i];
-        __syncthreads();
-        for (int b = tid; b < nb; b += T) {
-            double acc[BS];
-#pragma unroll
-            for (int q = 0; q < BS; q++) acc[q] = L.r[(size_t)b * BS + q];
-            for (int s = 0; s < 27; s++) {
-                int c;
-                if (!neighbour_box(L.g, b, s, c)) continue;
-#pragma unroll
-                for (int q = 0; q < BS; q++)
-#pragma unroll
-                    for (int p = 0; p < BS; p++) acc[q] -= L.st[((size_t)s * BB + q * BS + p) * nb + b] * L.x[(size_t)c * BS + p];
-            }
-#pragma unroll
-            for (int q = 0; q < BS; q++) L.t[(size_t)b * BS + q] = acc[q];
-        }
-        __syncthreads();
-        for (int A = tid; A < C.g.nb(); A += T) {
-            const int ax = A % C.g.nx, ay = (A / C.g.nx) % C.g.ny, az = A / (C.g.nx * C.g.ny);
-            double acc[BS];
-#pragma unroll
-            for (int q = 0; q < BS; q++) acc[q] = 0.0;
-            for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
-                const int fx = 2 * ax + cx, fy = 2 * ay + cy, fz = 2 * az + cz;
-                if (fx >= L.g.nx || fy >= L.g.ny || fz >= L.g.nz) continue;
-                const size_t a = (size_t)(fx + L.g.nx * (fy + L.g.ny * fz)) * BS;
-#pragma unroll
-                for (int q = 0; q < BS; q++) acc[q] += L.t[a + q];
-            }
-#pragma unroll
-            for (int q = 0; q < BS; q++) C.r[(size_t)A * BS + q] = acc[q];
-        }
-        __syncthreads();
-    }
-    {   // coarsest: dense inverse
-        const SmallLevel& L = S.l[S.n - 1];
-        for (int i = tid; i < ncoarse; i += T) {
-            double s = 0.0;
-            for (int j = 0; j < ncoarse; j++) s += cinv[(size_t)i * 2 * ncoarse + ncoarse + j] * L.r[j];
-            L.x[i] = s;
-        }
-        __syncthreads();
-    }
-    for (int l = S.n - 2; l >= 0; l--) {   // up
-        const SmallLevel& L = S.l[l];
-        const SmallLevel& C = S.l[l + 1];
-        const int nb = L.g.nb();
-        for (int a = tid; a < nb; a += T) {
-            const int px = (a % L.g.nx) >> 1, py = ((a / L.g.nx) % L.g.ny) >> 1, pz = (a / (L.g.nx * L.g.ny)) >> 1;
-            const size_t A = (size_t)(px + C.g.nx * (py + C.g.ny * pz)) * BS;
-#pragma unroll
-            for (int q = 0; q < BS; q++) L.x[(size_t)a * BS + q] += alpha * C.x[A + q];
-        }
-        __syncthreads();
-        for (int b = tid; b < nb; b += T) {
-            double acc[BS];
-#pragma unroll
-            for (int q = 0; q < BS; q++) acc[q] = L.r[(size_t)b * BS + q];
-            for (int s = 0; s < 27; s++) {
-                int c;
-                if (!neighbour_box(L.g, b, s, c)) continue;
-#pragma unroll
-                for (int q = 0; q < BS; q++)
-#pragma unroll
-                    for (int p = 0; p < BS; p++) acc[q] -= L.st[((size_t)s * BB + q * BS + p) * nb + b] * L.x[(size_t)c * BS + p];
-            }
-#pragma unroll
-            for (int q = 0; q < BS; q++) L.t[(size_t)b * BS + q] = acc[q];
-        }
-        __syncthreads();
-        for (int i = tid; i < nb * BS; i += T) L.x[i] += omega * L.dinv[i] * L.t[i];
-        __syncthreads();
-    }
+    for (int j = lane; j < n; j += 64) s += M[(size_t)i * 2 * n + n + j] * r[j];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if (lane == 0) x[i] = s;
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
@@ -571,11 +551,12 @@ static void setup_t(Multigrid& mg)
         L.t.alloc((size_t)L.nb * BS);
     };
     new_level(g);
-    hipLaunchKernelGGL(k_galerkin_fine<BS>, dim3(g1((size_t)27 * nb)), dim3(256), 0, s, g, mg.box_ptr.p, mg.box_nodes.p,
+    hipLaunchKernelGGL(k_galerkin_fine_wave<BS>, dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, mg.box_ptr.p, mg.box_nodes.p,
                        mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->val.p, mg.w.p, mg.lev[0].st.p, err.p);
     hipLaunchKernelGGL(k_level_dinv<BS>, dim3(g1(nb)), dim3(256), 0, s, nb, mg.lev[0].st.p, mg.lev[0].dinv.p);
-    // coarser levels: merge 2x2x2 boxes until the grid is at most 3 boxes per direction
-    while (std::max(g.nx, std::max(g.ny, g.nz)) > 3) {
+    // coarser levels: merge 2x2x2 boxes until the grid is at most 5 boxes per direction
+    // (<= 375 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
+    while (std::max(g.nx, std::max(g.ny, g.nz)) > 5) {
         Grid3 gc{(g.nx + 1) / 2, (g.ny + 1) / 2, (g.nz + 1) / 2};
         new_level(gc);
         MgLevel& Lf = mg.lev[mg.lev.size() - 2];
@@ -588,7 +569,15 @@ static void setup_t(Multigrid& mg)
     mg.ncoarse = g.nb() * BS;
     mg.cinv.alloc((size_t)mg.ncoarse * 2 * mg.ncoarse);
     hipLaunchKernelGGL(k_dense_from_stencil<BS>, dim3(1), dim3(256), 0, s, g, mg.lev.back().st.p, mg.cinv.p);
-    hipLaunchKernelGGL(k_gauss_jordan, dim3(1), dim3(1024), 0, s, mg.ncoarse, mg.cinv.p);
+    {
+        const int n = mg.ncoarse;
+        DBuf<double> rowk((size_t)2 * n), colk((size_t)n);
+        for (int k = 0; k < n; k++) {
+            hipLaunchKernelGGL(k_gj_pivot, dim3(g1((size_t)2 * n)), dim3(256), 0, s, n, k, mg.cinv.p, rowk.p, colk.p);
+            hipLaunchKernelGGL(k_gj_update, dim3(g1((size_t)n * 2 * n)), dim3(256), 0, s, n, k, mg.cinv.p, rowk.p, colk.p);
+        }
+        FEM_HIP(hipStreamSynchronize(s));   // rowk/colk go out of scope
+    }
     int herr = 0;
     err.download(&herr, 1, s);
     FEM_HIP(hipGetLastError());
@@ -603,28 +592,25 @@ static void cycle_t(Multigrid& mg, size_t l)
     MgLevel& L = mg.lev[l];
     const Grid3 g{L.nx, L.ny, L.nz};
     const size_t n = (size_t)L.nb * BS;
-    if (L.nb <= 1024 && mg.lev.size() - l <= 8) {   // the rest of the hierarchy (one box per thread) in one launch
-        SmallLevels S{};
-        S.n = (int)(mg.lev.size() - l);
-        for (int k = 0; k < S.n; k++) {
-            MgLevel& M = mg.lev[l + k];
-            S.l[k] = SmallLevel{Grid3{M.nx, M.ny, M.nz}, M.st.p, M.dinv.p, M.x.p, M.r.p, M.t.p};
-        }
-        hipLaunchKernelGGL(k_small_cycle<BS>, dim3(1), dim3(1024), 0, s, S, mg.cinv.p, mg.ncoarse, mg.omega, mg.alpha);
-        return;
-    }
     if (l + 1 == mg.lev.size()) {
-        hipLaunchKernelGGL(k_dense_apply, dim3(g1(n)), dim3(256), 0, s, (int)n, mg.cinv.p, L.r.p, L.x.p);
+        hipLaunchKernelGGL(k_dense_apply, dim3(g1(n * 64)), dim3(256), 0, s, (int)n, mg.cinv.p, L.r.p, L.x.p);
         return;
     }
+    auto residual = [&] {   // small levels: 32 lanes per box (latency), large ones: one thread per box (bandwidth)
+        if (L.nb <= 16384)
+            hipLaunchKernelGGL(k_box_residual_slots<BS>, dim3(g1((size_t)L.nb * 32)), dim3(256), 0, s, g, L.st.p, L.x.p,
+                               L.r.p, L.t.p);
+        else
+            hipLaunchKernelGGL(k_box_residual<BS>, dim3(g1(L.nb)), dim3(256), 0, s, g, L.st.p, L.x.p, L.r.p, L.t.p);
+    };
     MgLevel& C = mg.lev[l + 1];
     const Grid3 gc{C.nx, C.ny, C.nz};
     hipLaunchKernelGGL(k_smooth_first, dim3(gs(n)), dim3(256), 0, s, n, mg.omega, L.dinv.p, L.r.p, L.x.p);
-    hipLaunchKernelGGL(k_box_residual<BS>, dim3(g1(L.nb)), dim3(256), 0, s, g, L.st.p, L.x.p, L.r.p, L.t.p);
+    residual();
     hipLaunchKernelGGL(k_restrict_box<BS>, dim3(g1(C.nb)), dim3(256), 0, s, g, gc, L.t.p, C.r.p);
     cycle_t<BS>(mg, l + 1);
     hipLaunchKernelGGL(k_prolong_box<BS>, dim3(g1(L.nb)), dim3(256), 0, s, g, gc, mg.alpha, C.x.p, L.x.p);
-    hipLaunchKernelGGL(k_box_residual<BS>, dim3(g1(L.nb)), dim3(256), 0, s, g, L.st.p, L.x.p, L.r.p, L.t.p);
+    residual();
     hipLaunchKernelGGL(k_smooth_add, dim3(gs(n)), dim3(256), 0, s, n, mg.omega, L.dinv.p, L.t.p, L.x.p);
 }
 

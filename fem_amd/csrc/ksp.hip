@@ -276,7 +276,8 @@ struct fem_ksp_s {
     DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
     std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
     bool mg_additive = false;
-    double mg_alpha = -1.0, mg_omega = 0.7;  // alpha < 0: default (1.3 over-correction for the additive form, 1 for the V-cycle)
+    double mg_box = 4.0;                     // level-1 box edge in mean node spacings
+    double mg_alpha = -1.0, mg_omega = 0.7;  // alpha < 0: default (1.5 over-correction for the additive form, 1 for the V-cycle)
     DBuf<KspState> state;
     KspState* h_state = nullptr;  // pinned, two poll slots
     hipEvent_t poll_ev[2] = {nullptr, nullptr};
@@ -315,6 +316,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
             k->mg_additive = (val == "additive");
         }
         else if (key == "-pc_mg_alpha") { is >> k->mg_alpha; }     // coarse-correction scaling (over-correction)
+        else if (key == "-pc_mg_box") { is >> k->mg_box; FEM_CHECK(k->mg_box >= 2.0 && k->mg_box <= 16.0, 6, "-pc_mg_box must lie in [2, 16]"); }
         else if (key == "-pc_mg_omega") { is >> k->mg_omega; }     // Jacobi damping of the smoother
         else if (key == "-ksp_rtol") { is >> k->rtol; }
         else if (key == "-ksp_atol") { is >> k->abstol; }
@@ -351,8 +353,9 @@ void ksp_set_up_impl(fem_ksp k)
     if (k->pc == "mg") {
         k->mg.reset(new fem::Multigrid);
         k->mg->fine_additive = k->mg_additive;
-        k->mg->alpha = (k->mg_alpha > 0.0) ? k->mg_alpha : (k->mg_additive ? 1.3 : 1.0);
+        k->mg->alpha = (k->mg_alpha > 0.0) ? k->mg_alpha : (k->mg_additive ? 1.5 : 1.0);
         k->mg->omega = k->mg_omega;
+        k->mg->box = k->mg_box;
         k->mg->setup(A);
         k->z.alloc(n);
     }

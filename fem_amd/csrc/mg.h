@@ -7,9 +7,11 @@
 // Because boxes are a structured index space even on unstructured meshes, every
 // coarse operator is a dense 27-point block stencil: no coarse symbolic phase,
 // trivially parallel Galerkin products, coalesced box-major storage.
-//   P     piecewise constant per displacement component, zero on penalty dofs
+//   P     rigid-body modes of each box (translations + rotations about the box centre: 6 coarse
+//         dofs per box in 3-D, 3 in 2-D), zero on penalty dofs
 //   A_c   = P^T A P (Galerkin), exact dense inverse on the coarsest grid
-//   cycle V(1,1) with damped Jacobi, symmetric -> valid CG preconditioner
+//   cycle V(1,1), symmetric -> valid CG preconditioner; damped point Jacobi on the fine level, damped
+//         block Jacobi (one box = one block) on the box levels with omega = 4/(3*1.1*lambda_max estimate)
 #pragma once
 #include <vector>
 
@@ -19,15 +21,17 @@ namespace fem {
 
 struct MgLevel {
     int nx = 0, ny = 0, nz = 0, nb = 0;
-    DBuf<double> st;    // [27][bs*bs][nb]  stencil entries, box index fastest
-    DBuf<double> dinv;  // [nb*bs]
+    double lo[3] = {0, 0, 0}, H = 1.0;   // box b = (ix,iy,iz) has its centre at lo + (idx + 0.5) * H
+    DBuf<double> st;    // [27][cs*cs][nb]  stencil entries, box index fastest
+    DBuf<double> dinv;  // [cs*cs][nb]  inverse of the diagonal block of every box (block-Jacobi smoother)
     DBuf<double> x, r, t, xn;
 };
 
 struct Multigrid {
     fem_mat A = nullptr;
-    int bs = 0, nn = 0;
-    double omega = 0.7, alpha = 1.3;
+    int bs = 0, cs = 0, nn = 0;      // fine block size; coarse dofs per box (rigid-body modes: 3 in 2-D, 6 in 3-D)
+    double omega = 0.7, alpha = 1.5;   // fine-level Jacobi damping (V-cycle form); scaling of the coarse correction
+    double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     DBuf<int> agg;                  // [nn] level-1 box of every node
@@ -35,6 +39,7 @@ struct Multigrid {
     DBuf<double> w;                 // [nn*bs] 1 on free dofs, 0 on penalty dofs
     DBuf<double> dinv0, t0;         // fine-level Jacobi inverse diagonal, work vector
     DBuf<double> cinv;              // dense inverse of the coarsest operator
+    DBuf<double> omega_l;           // [levels] smoother damping per box level (from an eigenvalue estimate) + scratch
     int ncoarse = 0;
     void setup(fem_mat A);
     // z = M^-1 r  (one V-cycle, zero initial guess); `done` (device flag, may be null) lets the

@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 
 #include "comm.h"
 #include "scan.h"
@@ -101,202 +104,436 @@ __device__ __forceinline__ bool neighbour_box(const Grid3& g, int b, int slot, i
     return true;
 }
 
-// level-1 operator  A_1 = P^T K P : thread (box A, slot s) gathers every fine block
-// K_ij with i in A and j in the neighbour box A+s, in fixed (node, column) order.
-template <int BS>
-__global__ void __launch_bounds__(256) k_galerkin_fine(Grid3 g, const int* __restrict__ box_ptr,
-                                                       const int* __restrict__ box_nodes, const int* __restrict__ agg,
-                                                       const int* __restrict__ rowlen, const int* __restrict__ boff,
-                                                       const int* __restrict__ bcol, const double* __restrict__ val,
-                                                       const double* __restrict__ w, double* __restrict__ st,
-                                                       int* __restrict__ err)
+// ---- rigid-body-mode interpolation -----------------------------------------------------------------
+// Coarse dofs of a box: translations and infinitesimal rotations about the box centre
+// (3-D: 3 + 3, 2-D: 2 + 1).  A fine node at offset d from the centre moves by  u = U + Theta x d.
+template <int BS> struct CoarseDofs { static constexpr int value = (BS == 3) ? 6 : 3; };
+
+// u[BS] = P_d * xc[CS]
+template <int BS, int CS>
+__device__ __forceinline__ void rbm_apply(const double (&d)[3], const double* xc, double (&u)[BS])
 {
-    constexpr int BB = BS * BS;
-    const int nb = g.nb();
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 27 * nb) return;
-    const int slot = t / nb, A = t - slot * nb;
-    int T = -1;
-    const bool inside = neighbour_box(g, A, slot, T);
-    double acc[BB];
-#pragma unroll
-    for (int e = 0; e < BB; e++) acc[e] = 0.0;
-    if (inside) {
-        const int ax = A % g.nx, ay = (A / g.nx) % g.ny, az = A / (g.nx * g.ny);
-        for (int p = box_ptr[A]; p < box_ptr[A + 1]; p++) {
-            const int i = box_nodes[p];
-            const size_t o0 = (size_t)boff[i >> 6];
-            const int lane = i & 63, len = rowlen[i];
-            for (int j = 0; j < len; j++) {
-                const int c = bcol[(o0 + j) * 64 + lane];
-                const int B = agg[c];
-                if (slot == 13) {  // the centre thread also checks that coupled nodes sit in adjacent boxes
-                    const int bx = B % g.nx, by = (B / g.nx) % g.ny, bz = B / (g.nx * g.ny);
-                    if (abs(bx - ax) > 1 || abs(by - ay) > 1 || abs(bz - az) > 1) atomicExch(err, 1);
-                }
-                if (B != T) continue;
-#pragma unroll
-                for (int r = 0; r < BS; r++)
-#pragma unroll
-                    for (int q = 0; q < BS; q++)
-                        acc[r * BS + q] += w[(size_t)BS * i + r] * w[(size_t)BS * c + q] *
-                                           val[((o0 + j) * BB + r * BS + q) * 64 + lane];
-            }
-        }
+    if constexpr (BS == 3) {
+        u[0] = xc[0] + xc[4] * d[2] - xc[5] * d[1];
+        u[1] = xc[1] + xc[5] * d[0] - xc[3] * d[2];
+        u[2] = xc[2] + xc[3] * d[1] - xc[4] * d[0];
+    } else {
+        u[0] = xc[0] - xc[2] * d[1];
+        u[1] = xc[1] + xc[2] * d[0];
     }
+}
+// out[CS] = P_d^T * f[BS]   (forces and their moments about the centre)
+template <int BS, int CS>
+__device__ __forceinline__ void rbm_apply_t(const double (&d)[3], const double (&f)[BS], double (&out)[CS])
+{
+    if constexpr (BS == 3) {
+        out[0] = f[0]; out[1] = f[1]; out[2] = f[2];
+        out[3] = d[1] * f[2] - d[2] * f[1];
+        out[4] = d[2] * f[0] - d[0] * f[2];
+        out[5] = d[0] * f[1] - d[1] * f[0];
+    } else {
+        out[0] = f[0]; out[1] = f[1];
+        out[2] = d[0] * f[1] - d[1] * f[0];
+    }
+}
+// explicit P_d (BS x CS), row-major
+template <int BS, int CS>
+__device__ __forceinline__ void rbm_matrix(const double (&d)[3], double (&P)[BS * CS])
+{
 #pragma unroll
-    for (int e = 0; e < BB; e++) st[((size_t)slot * BB + e) * nb + A] = acc[e];
+    for (int k = 0; k < BS * CS; k++) P[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < BS; r++) P[r * CS + r] = 1.0;
+    if constexpr (BS == 3) {
+        P[0 * CS + 4] = d[2];  P[0 * CS + 5] = -d[1];
+        P[1 * CS + 3] = -d[2]; P[1 * CS + 5] = d[0];
+        P[2 * CS + 3] = d[1];  P[2 * CS + 4] = -d[0];
+    } else {
+        P[0 * CS + 2] = -d[1];
+        P[1 * CS + 2] = d[0];
+    }
+}
+// box -> parent box: child dofs (u, theta) = T * parent dofs (U, Theta),  T = [I, R(d); 0, I]
+template <int CS>
+__device__ __forceinline__ void box_apply(const double (&d)[3], const double* X, double (&x)[CS])
+{
+    if constexpr (CS == 6) {
+        x[0] = X[0] + X[4] * d[2] - X[5] * d[1];
+        x[1] = X[1] + X[5] * d[0] - X[3] * d[2];
+        x[2] = X[2] + X[3] * d[1] - X[4] * d[0];
+        x[3] = X[3]; x[4] = X[4]; x[5] = X[5];
+    } else {
+        x[0] = X[0] - X[2] * d[1];
+        x[1] = X[1] + X[2] * d[0];
+        x[2] = X[2];
+    }
+}
+template <int CS>
+__device__ __forceinline__ void box_apply_t(const double (&d)[3], const double* f, double (&F)[CS])
+{
+    if constexpr (CS == 6) {
+        F[0] = f[0]; F[1] = f[1]; F[2] = f[2];
+        F[3] = f[3] + d[1] * f[2] - d[2] * f[1];
+        F[4] = f[4] + d[2] * f[0] - d[0] * f[2];
+        F[5] = f[5] + d[0] * f[1] - d[1] * f[0];
+    } else {
+        F[0] = f[0]; F[1] = f[1];
+        F[2] = f[2] + d[0] * f[1] - d[1] * f[0];
+    }
+}
+template <int CS>
+__device__ __forceinline__ void box_matrix(const double (&d)[3], double (&T)[CS * CS])
+{
+#pragma unroll
+    for (int k = 0; k < CS * CS; k++) T[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < CS; r++) T[r * CS + r] = 1.0;
+    if constexpr (CS == 6) {
+        T[0 * 6 + 4] = d[2];  T[0 * 6 + 5] = -d[1];
+        T[1 * 6 + 3] = -d[2]; T[1 * 6 + 5] = d[0];
+        T[2 * 6 + 3] = d[1];  T[2 * 6 + 4] = -d[0];
+    } else {
+        T[0 * 3 + 2] = -d[1];
+        T[1 * 3 + 2] = d[0];
+    }
+}
+// geometry of a box level: centre of box b
+struct BoxGeom {
+    double lo[3], H;
+};
+__device__ __forceinline__ void box_centre(const Grid3& g, const BoxGeom& geo, int b, double (&c)[3])
+{
+    c[0] = geo.lo[0] + ((b % g.nx) + 0.5) * geo.H;
+    c[1] = geo.lo[1] + (((b / g.nx) % g.ny) + 0.5) * geo.H;
+    c[2] = geo.lo[2] + ((b / (g.nx * g.ny)) + 0.5) * geo.H;
+}
+template <int PD>
+__device__ __forceinline__ void node_offset(const double* coords, int v, const double (&c)[3], double (&d)[3])
+{
+    d[0] = coords[(size_t)v * PD] - c[0];
+    d[1] = coords[(size_t)v * PD + 1] - c[1];
+    d[2] = (PD == 3) ? coords[(size_t)v * PD + 2] - c[2] : 0.0;
 }
 
-// The same product with one wavefront per box: lane = node of the box.  For each of the 27 slots
-// every lane sums its own matching blocks (the row's column ids are re-read per slot from L1/L2,
-// the 72-byte values only when they match, i.e. once), then a fixed shuffle tree adds the lanes:
-// bitwise reproducible, no atomics, 64x more parallel than the thread-per-(box,slot) form.
-template <int BS>
-__global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, const int* __restrict__ box_ptr,
+// level-1 operator  A_1 = P^T K P, one wavefront per box: lane = node of the box.  A first sweep
+// over the lane's block row classifies every block by the stencil slot of its column's box (one
+// gather of agg[] per block) and parks the slot ids in LDS, four to a word, lane-private.  Then for
+// each of the 27 slots every lane sums P_i^T (w K_ij w) P_j over its matching blocks (the values
+// are read exactly once) and a fixed shuffle tree adds the lanes: bitwise reproducible, no atomics.
+// Boxes with more than 64 nodes and rows longer than MG_ROW_CHUNK blocks take further passes that
+// add to the stencil entries already written (the wavefront owns its box).
+constexpr int MG_ROW_CHUNK = 128;
+template <int BS, int CS, int PD>
+__global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo, const double* __restrict__ coords,
+                                                            const int* __restrict__ box_ptr,
                                                             const int* __restrict__ box_nodes, const int* __restrict__ agg,
                                                             const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                             const int* __restrict__ bcol, const double* __restrict__ val,
                                                             const double* __restrict__ w, double* __restrict__ st,
                                                             int* __restrict__ err)
 {
-    constexpr int BB = BS * BS;
+    constexpr int BB = BS * BS, CC = CS * CS;
+    __shared__ unsigned int sslot[4][MG_ROW_CHUNK / 4][64];
     const int nb = g.nb();
     const int A = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (A >= nb) return;
+    if (A >= nb) return;   // wave-uniform
+    unsigned int (*my)[64] = sslot[threadIdx.x >> 6];
     const int ax = A % g.nx, ay = (A / g.nx) % g.ny, az = A / (g.nx * g.ny);
     const int p0 = box_ptr[A], p1 = box_ptr[A + 1];
-    // pass 1: slot id of each block of the lane's row, 5 bits each, packed in two words per 12 entries
-    // (only the first node chunk of a box is cached; boxes with more than 64 nodes loop below)
-    for (int s = 0; s < 27; s++) {
-        double acc[BB];
+    double cA[3];
+    box_centre(g, geo, A, cA);
+    bool first = true;
+    for (int pbase = p0; pbase < p1 || first; pbase += 64) {
+        const bool have = pbase + lane < p1;
+        const int i = have ? box_nodes[pbase + lane] : 0;
+        const int len = have ? rowlen[i] : 0, ln = i & 63;
+        const size_t o0 = (size_t)boff[i >> 6];
+        double di[3] = {0.0, 0.0, 0.0}, wi[BS];
+        if (have) node_offset<PD>(coords, i, cA, di);
 #pragma unroll
-        for (int e = 0; e < BB; e++) acc[e] = 0.0;
-        for (int p = p0 + lane; p < p1; p += 64) {
-            const int i = box_nodes[p];
-            const size_t o0 = (size_t)boff[i >> 6];
-            const int ln = i & 63, len = rowlen[i];
-            for (int j = 0; j < len; j++) {
-                const int c = bcol[(o0 + j) * 64 + ln];
-                const int B = agg[c];
-                const int dx = B % g.nx - ax, dy = (B / g.nx) % g.ny - ay, dz = B / (g.nx * g.ny) - az;
-                if (abs(dx) > 1 || abs(dy) > 1 || abs(dz) > 1) { if (s == 13) atomicExch(err, 1); continue; }
-                if ((dx + 1) + 3 * (dy + 1) + 9 * (dz + 1) != s) continue;
-#pragma unroll
-                for (int r = 0; r < BS; r++)
-#pragma unroll
-                    for (int q = 0; q < BS; q++)
-                        acc[r * BS + q] += w[(size_t)BS * i + r] * w[(size_t)BS * c + q] *
-                                           val[((o0 + j) * BB + r * BS + q) * 64 + ln];
+        for (int r = 0; r < BS; r++) wi[r] = have ? w[(size_t)BS * i + r] : 0.0;
+        int maxlen = len;
+        for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+        for (int j0 = 0; j0 < maxlen || first; j0 += MG_ROW_CHUNK) {
+            const int j1 = min(len, j0 + MG_ROW_CHUNK);
+            // classify
+            for (int jw = j0; jw < j1; jw += 4) {
+                unsigned int word = 0xffffffffu;
+                for (int k = 0; k < 4 && jw + k < j1; k++) {
+                    const int B = agg[bcol[(o0 + jw + k) * 64 + ln]];
+                    const int dx = B % g.nx - ax, dy = (B / g.nx) % g.ny - ay, dz = B / (g.nx * g.ny) - az;
+                    unsigned int sl = 0xffu;
+                    if (abs(dx) > 1 || abs(dy) > 1 || abs(dz) > 1) atomicExch(err, 1);   // coupled nodes must sit in adjacent boxes
+                    else sl = (unsigned)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
+                    word = (word & ~(0xffu << (8 * k))) | (sl << (8 * k));
+                }
+                my[(jw - j0) >> 2][lane] = word;
             }
-        }
+            for (int s = 0; s < 27; s++) {
+                int T = -1;
+                const bool inside = neighbour_box(g, A, s, T);   // wave-uniform
+                double acc[CC];
 #pragma unroll
-        for (int e = 0; e < BB; e++) {
-            double a = acc[e];
-            for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
-            if (lane == 0) st[((size_t)s * BB + e) * nb + A] = a;
+                for (int e = 0; e < CC; e++) acc[e] = 0.0;
+                if (inside) {
+                    double cT[3];
+                    box_centre(g, geo, T, cT);
+                    for (int jw = j0; jw < j1; jw += 4) {
+                        const unsigned int word = my[(jw - j0) >> 2][lane];
+                        for (int k = 0; k < 4; k++) {
+                            if (((word >> (8 * k)) & 0xffu) != (unsigned)s) continue;
+                            const int j = jw + k;
+                            const int c = bcol[(o0 + j) * 64 + ln];
+                            double dj[3], KP[BS * CS], kw[BB];
+                            node_offset<PD>(coords, c, cT, dj);
+#pragma unroll
+                            for (int r = 0; r < BS; r++)
+#pragma unroll
+                                for (int q = 0; q < BS; q++)
+                                    kw[r * BS + q] = wi[r] * w[(size_t)BS * c + q] * val[((o0 + j) * BB + r * BS + q) * 64 + ln];
+                            // KP = (w K w) P_j : row r of K applied to the modes of node j
+#pragma unroll
+                            for (int r = 0; r < BS; r++) {
+                                double f[BS], m[CS];
+#pragma unroll
+                                for (int q = 0; q < BS; q++) f[q] = kw[r * BS + q];
+                                rbm_apply_t<BS, CS>(dj, f, m);
+#pragma unroll
+                                for (int cc = 0; cc < CS; cc++) KP[r * CS + cc] = m[cc];
+                            }
+                            // acc += P_i^T KP : column cc of KP seen as a force on node i
+#pragma unroll
+                            for (int cc = 0; cc < CS; cc++) {
+                                double f[BS], m[CS];
+#pragma unroll
+                                for (int r = 0; r < BS; r++) f[r] = KP[r * CS + cc];
+                                rbm_apply_t<BS, CS>(di, f, m);
+#pragma unroll
+                                for (int aa = 0; aa < CS; aa++) acc[aa * CS + cc] += m[aa];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < CC; e++) {
+                    double a = acc[e];
+                    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+                    if (lane == 0) {
+                        double* dst = &st[((size_t)s * CC + e) * nb + A];
+                        *dst = first ? a : *dst + a;
+                    }
+                }
+            }
+            first = false;
         }
     }
 }
 
-// A_{l+1} = P^T A_l P between two box levels (children = 2x2x2 boxes)
-template <int BS>
-__global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, Grid3 gc, const double* __restrict__ stf,
-                                                      double* __restrict__ stc)
+// A_{l+1} = T^T A_l T between two box levels (children = 2x2x2 boxes), T = [I, R(d); 0, I]
+template <int CS>
+__global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc,
+                                                      const double* __restrict__ stf, double* __restrict__ stc)
 {
-    constexpr int BB = BS * BS;
+    constexpr int CC = CS * CS;
     const int nbc = gc.nb(), nbf = gf.nb();
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= 27 * nbc) return;
     const int slot = t / nbc, A = t - slot * nbc;
     int T = -1;
     const bool inside = neighbour_box(gc, A, slot, T);
-    double acc[BB];
+    double acc[CC];
 #pragma unroll
-    for (int e = 0; e < BB; e++) acc[e] = 0.0;
+    for (int e = 0; e < CC; e++) acc[e] = 0.0;
     if (inside) {
         const int ax = A % gc.nx, ay = (A / gc.nx) % gc.ny, az = A / (gc.nx * gc.ny);
+        double cA[3], cT[3];
+        box_centre(gc, geoc, A, cA);
+        box_centre(gc, geoc, T, cT);
         for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
             const int fx = 2 * ax + cx, fy = 2 * ay + cy, fz = 2 * az + cz;
             if (fx >= gf.nx || fy >= gf.ny || fz >= gf.nz) continue;
             const int a = fx + gf.nx * (fy + gf.ny * fz);
+            double ca[3], da[3], Ta[CC];
+            box_centre(gf, geof, a, ca);
+            for (int k = 0; k < 3; k++) da[k] = ca[k] - cA[k];
+            box_matrix<CS>(da, Ta);
             for (int s = 0; s < 27; s++) {
                 int b;
                 if (!neighbour_box(gf, a, s, b)) continue;
                 const int bx = (b % gf.nx) >> 1, by = ((b / gf.nx) % gf.ny) >> 1, bz = (b / (gf.nx * gf.ny)) >> 1;
                 if (bx + gc.nx * (by + gc.ny * bz) != T) continue;
-#pragma unroll
-                for (int e = 0; e < BB; e++) acc[e] += stf[((size_t)s * BB + e) * nbf + a];
+                double cb[3], db[3], Tb[CC], ST[CC];
+                box_centre(gf, geof, b, cb);
+                for (int k = 0; k < 3; k++) db[k] = cb[k] - cT[k];
+                box_matrix<CS>(db, Tb);
+                for (int r = 0; r < CS; r++)
+                    for (int c = 0; c < CS; c++) {
+                        double v = 0.0;
+                        for (int q = 0; q < CS; q++) v += stf[((size_t)s * CC + r * CS + q) * nbf + a] * Tb[q * CS + c];
+                        ST[r * CS + c] = v;
+                    }
+                for (int r = 0; r < CS; r++)
+                    for (int c = 0; c < CS; c++) {
+                        double v = 0.0;
+                        for (int q = 0; q < CS; q++) v += Ta[q * CS + r] * ST[q * CS + c];
+                        acc[r * CS + c] += v;
+                    }
             }
         }
     }
 #pragma unroll
-    for (int e = 0; e < BB; e++) stc[((size_t)slot * BB + e) * nbc + A] = acc[e];
+    for (int e = 0; e < CC; e++) stc[((size_t)slot * CC + e) * nbc + A] = acc[e];
 }
 
-template <int BS>
+// inverse of the CS x CS diagonal block of every box (block-Jacobi smoother): dinv[r*CS+c][b].
+// Point Jacobi is not enough here: translations and rotations of one box are strongly coupled.
+// Rank-deficient blocks (boxes with fewer than three non-collinear free nodes, or none) get the
+// same relative shift as the coarsest matrix.
+template <int CS>
 __global__ void __launch_bounds__(256) k_level_dinv(int nb, const double* __restrict__ st, double* __restrict__ dinv)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    for (int r = 0; r < BS; r++) {
-        const double d = st[((size_t)13 * BS * BS + r * BS + r) * nb + b];
-        dinv[(size_t)b * BS + r] = (d != 0.0) ? 1.0 / d : 1.0;
+    double D[CS][2 * CS];
+#pragma unroll
+    for (int r = 0; r < CS; r++)
+#pragma unroll
+        for (int c = 0; c < CS; c++) {
+            D[r][c] = st[((size_t)13 * CS * CS + r * CS + c) * nb + b];
+            D[r][CS + c] = (r == c) ? 1.0 : 0.0;
+        }
+    double tr = 0.0;
+#pragma unroll
+    for (int r = 0; r < CS; r++) tr = fmax(tr, fabs(D[r][r]));
+#pragma unroll
+    for (int r = 0; r < CS; r++) D[r][r] = (D[r][r] == 0.0) ? ((tr > 0.0) ? tr : 1.0) : D[r][r] * (1.0 + 1e-10);
+#pragma unroll
+    for (int k = 0; k < CS; k++) {
+        const double piv = 1.0 / D[k][k];
+#pragma unroll
+        for (int c = 0; c < 2 * CS; c++) D[k][c] *= piv;
+#pragma unroll
+        for (int r = 0; r < CS; r++) {
+            if (r == k) continue;
+            const double f = D[r][k];
+#pragma unroll
+            for (int c = 0; c < 2 * CS; c++) D[r][c] -= f * D[k][c];
+        }
     }
+#pragma unroll
+    for (int r = 0; r < CS; r++)
+#pragma unroll
+        for (int c = 0; c < CS; c++) dinv[((size_t)r * CS + c) * nb + b] = D[r][CS + c];
+}
+
+// x_b = omega * Dinv_b r_b      and      x_b += omega * Dinv_b t_b   (t already holds r - A x)
+// omega is read from device memory: it comes from the eigenvalue estimate of the set-up
+template <int CS, bool ADD>
+__global__ void __launch_bounds__(256) k_block_smooth(int nb, const double* __restrict__ omega,
+                                                      const double* __restrict__ dinv, const double* __restrict__ r,
+                                                      double* __restrict__ x)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    const double om = omega ? *omega : 1.0;
+    double v[CS];
+#pragma unroll
+    for (int q = 0; q < CS; q++) v[q] = r[(size_t)b * CS + q];
+#pragma unroll
+    for (int q = 0; q < CS; q++) {
+        double a = 0.0;
+#pragma unroll
+        for (int p = 0; p < CS; p++) a += dinv[((size_t)q * CS + p) * nb + b] * v[p];
+        if (ADD) x[(size_t)b * CS + q] += om * a; else x[(size_t)b * CS + q] = om * a;
+    }
+}
+
+// deterministic start vector of the power iteration
+__global__ void __launch_bounds__(256) k_hash_fill(size_t n, double* __restrict__ x)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) {
+        unsigned int h = (unsigned int)i * 2654435761u + 12345u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[i] = 0.5 + (double)(h & 0xffffu) / 65536.0;
+    }
+}
+// out = sum x_i^2 (single workgroup; coarse levels only, set-up time)
+__global__ void __launch_bounds__(1024) k_norm2_small(size_t n, const double* __restrict__ x, double* __restrict__ out)
+{
+    __shared__ double sh[16];
+    double a = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) a += x[i] * x[i];
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += sh[k];
+        *out = t;
+    }
+}
+// damping from the estimate lambda ~ sqrt(n2[1] / n2[0]) of the largest eigenvalue of Dinv A:
+// omega = 4 / (3 * 1.1 * lambda)   (the power iteration approaches lambda from below: 10 % margin)
+__global__ void k_set_omega(const double* __restrict__ n2, double* __restrict__ omega)
+{
+    const double lam = (n2[0] > 0.0 && n2[1] > 0.0) ? sqrt(n2[1] / n2[0]) : 2.0;
+    *omega = fmin(1.0, 4.0 / (3.0 * 1.1 * fmax(lam, 1.0)));
 }
 
 // ---- cycle kernels ------------------------------------------------------------------------------------
 // t = r - A x on a box level (27-point block stencil, thread per box)
-template <int BS>
+template <int CS>
 __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, const double* __restrict__ st, const double* __restrict__ x,
                                                       const double* __restrict__ r, double* __restrict__ t)
 {
-    constexpr int BB = BS * BS;
+    constexpr int CC = CS * CS;
     const int nb = g.nb();
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
-    double acc[BS];
+    double acc[CS];
 #pragma unroll
-    for (int q = 0; q < BS; q++) acc[q] = r[(size_t)b * BS + q];
+    for (int q = 0; q < CS; q++) acc[q] = r[(size_t)b * CS + q];
     for (int s = 0; s < 27; s++) {
         int c;
         if (!neighbour_box(g, b, s, c)) continue;
 #pragma unroll
-        for (int q = 0; q < BS; q++)
+        for (int q = 0; q < CS; q++)
 #pragma unroll
-            for (int p = 0; p < BS; p++) acc[q] -= st[((size_t)s * BB + q * BS + p) * nb + b] * x[(size_t)c * BS + p];
+            for (int p = 0; p < CS; p++) acc[q] -= st[((size_t)s * CC + q * CS + p) * nb + b] * x[(size_t)c * CS + p];
     }
 #pragma unroll
-    for (int q = 0; q < BS; q++) t[(size_t)b * BS + q] = acc[q];
+    for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = acc[q];
 }
 
 // same for the small levels, which are latency-bound with one thread per box: 32 lanes per
 // box (one stencil slot each, 27 active), fixed shuffle tree over the slots
-template <int BS>
+template <int CS>
 __global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, const double* __restrict__ st,
                                                             const double* __restrict__ x, const double* __restrict__ r,
                                                             double* __restrict__ t)
 {
-    constexpr int BB = BS * BS;
+    constexpr int CC = CS * CS;
     const int nb = g.nb();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = gid >> 5, s = gid & 31;
-    double acc[BS];
+    double acc[CS];
 #pragma unroll
-    for (int q = 0; q < BS; q++) acc[q] = 0.0;
+    for (int q = 0; q < CS; q++) acc[q] = 0.0;
     int c;
     if (b < nb && s < 27 && neighbour_box(g, b, s, c)) {
 #pragma unroll
-        for (int q = 0; q < BS; q++)
+        for (int q = 0; q < CS; q++)
 #pragma unroll
-            for (int p = 0; p < BS; p++) acc[q] -= st[((size_t)s * BB + q * BS + p) * nb + b] * x[(size_t)c * BS + p];
+            for (int p = 0; p < CS; p++) acc[q] -= st[((size_t)s * CC + q * CS + p) * nb + b] * x[(size_t)c * CS + p];
     }
 #pragma unroll
-    for (int q = 0; q < BS; q++)
+    for (int q = 0; q < CS; q++)
         for (int o = 16; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 32);
     if (b < nb && s == 0) {
 #pragma unroll
-        for (int q = 0; q < BS; q++) t[(size_t)b * BS + q] = r[(size_t)b * BS + q] + acc[q];
+        for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = r[(size_t)b * CS + q] + acc[q];
     }
 }
 
@@ -308,14 +545,6 @@ __global__ void __launch_bounds__(256) k_smooth_first(size_t n, double omega, co
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) x[i] = omega * dinv[i] * r[i];
 }
-// x += omega * dinv * t          (t already holds r - A x)
-__global__ void __launch_bounds__(256) k_smooth_add(size_t n, double omega, const double* __restrict__ dinv,
-                                                    const double* __restrict__ t, double* __restrict__ x)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t st = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += st) x[i] += omega * dinv[i] * t[i];
-}
 // z += omega * dinv * (r - Kz)   (fine level; kz = K z)
 __global__ void __launch_bounds__(256) k_fine_post(size_t n, double omega, const double* __restrict__ dinv,
                                                    const double* __restrict__ r, const double* __restrict__ kz,
@@ -326,50 +555,65 @@ __global__ void __launch_bounds__(256) k_fine_post(size_t n, double omega, const
     for (; i < n; i += st) z[i] += omega * dinv[i] * (r[i] - kz[i]);
 }
 
-// r_1[B] = sum_{i in B} w_i (r_i - (K z)_i)      one wavefront per box, lanes over the box's
+// r_1[B] = sum_{i in B} P_i^T w_i (r_i - (K z)_i)      one wavefront per box, lanes over the box's
 // nodes (ascending), fixed shuffle tree -> bitwise reproducible
-template <int BS>
-__global__ void __launch_bounds__(256) k_restrict_fine(int nb, const int* __restrict__ box_ptr,
-                                                       const int* __restrict__ box_nodes, const double* __restrict__ w,
-                                                       const double* __restrict__ r, const double* __restrict__ kz,
-                                                       double* __restrict__ rc)
+template <int BS, int CS, int PD>
+__global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, const double* __restrict__ coords,
+                                                       const int* __restrict__ box_ptr, const int* __restrict__ box_nodes,
+                                                       const double* __restrict__ w, const double* __restrict__ r,
+                                                       const double* __restrict__ kz, double* __restrict__ rc)
 {
+    const int nb = g.nb();
     const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (b >= nb) return;
-    double acc[BS];
+    double cB[3], acc[CS];
+    box_centre(g, geo, b, cB);
 #pragma unroll
-    for (int q = 0; q < BS; q++) acc[q] = 0.0;
+    for (int q = 0; q < CS; q++) acc[q] = 0.0;
     for (int p = box_ptr[b] + lane; p < box_ptr[b + 1]; p += 64) {
-        const size_t i = (size_t)box_nodes[p] * BS;
+        const int v = box_nodes[p];
+        const size_t i = (size_t)v * BS;
+        double f[BS], d[3], m[CS];
 #pragma unroll
-        for (int q = 0; q < BS; q++) acc[q] += w[i + q] * (kz ? r[i + q] - kz[i + q] : r[i + q]);
+        for (int q = 0; q < BS; q++) f[q] = w[i + q] * (kz ? r[i + q] - kz[i + q] : r[i + q]);
+        node_offset<PD>(coords, v, cB, d);
+        rbm_apply_t<BS, CS>(d, f, m);
+#pragma unroll
+        for (int q = 0; q < CS; q++) acc[q] += m[q];
     }
 #pragma unroll
-    for (int q = 0; q < BS; q++)
+    for (int q = 0; q < CS; q++)
         for (int o = 32; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o);
     if (lane == 0) {
 #pragma unroll
-        for (int q = 0; q < BS; q++) rc[(size_t)b * BS + q] = acc[q];
+        for (int q = 0; q < CS; q++) rc[(size_t)b * CS + q] = acc[q];
     }
 }
 
-// z_i += alpha * w_i * x_1[agg(i)]
-template <int BS>
-__global__ void __launch_bounds__(256) k_prolong_fine(int nn, double alpha, const int* __restrict__ agg,
+// z_i += alpha * w_i * (P_i x_1[agg(i)])
+template <int BS, int CS, int PD>
+__global__ void __launch_bounds__(256) k_prolong_fine(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
+                                                      double alpha, const int* __restrict__ agg,
                                                       const double* __restrict__ w, const double* __restrict__ xc,
                                                       double* __restrict__ z)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nn) return;
-    const size_t b = (size_t)agg[v] * BS, i = (size_t)v * BS;
+    const int b = agg[v];
+    double c[3], d[3], u[BS];
+    box_centre(g, geo, b, c);
+    node_offset<PD>(coords, v, c, d);
+    rbm_apply<BS, CS>(d, xc + (size_t)b * CS, u);
+    const size_t i = (size_t)v * BS;
 #pragma unroll
-    for (int q = 0; q < BS; q++) z[i + q] += alpha * w[i + q] * xc[b + q];
+    for (int q = 0; q < BS; q++) z[i + q] += alpha * w[i + q] * u[q];
 }
 
-// additive fine level, one pass: z_i = dinv_i r_i + alpha w_i x_1[agg(i)], plus the partials of
+// additive fine level, one pass: z_i = dinv_i r_i + alpha w_i (P_i x_1[agg(i)]), plus the partials of
 // z.z and z.r that the CG needs next (same fixed-order two-stage reduction as the Jacobi path)
-template <int BS>
-__global__ void __launch_bounds__(256) k_additive_finish(int nn, double alpha, const int* __restrict__ agg,
+template <int BS, int CS, int PD>
+__global__ void __launch_bounds__(256) k_additive_finish(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
+                                                         double alpha, const int* __restrict__ agg,
                                                          const double* __restrict__ w, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ xc,
                                                          double* __restrict__ z, double* __restrict__ pzz,
@@ -379,11 +623,16 @@ __global__ void __launch_bounds__(256) k_additive_finish(int nn, double alpha, c
     __shared__ double sh[2][4];
     double zz = 0.0, zr = 0.0;
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nn; v += gridDim.x * blockDim.x) {
-        const size_t b = (size_t)agg[v] * BS, i = (size_t)v * BS;
+        const int b = agg[v];
+        double c[3], d[3], u[BS];
+        box_centre(g, geo, b, c);
+        node_offset<PD>(coords, v, c, d);
+        rbm_apply<BS, CS>(d, xc + (size_t)b * CS, u);
+        const size_t i = (size_t)v * BS;
 #pragma unroll
         for (int q = 0; q < BS; q++) {
             const double ri = r[i + q];
-            const double zi = dinv[i + q] * ri + alpha * w[i + q] * xc[b + q];
+            const double zi = dinv[i + q] * ri + alpha * w[i + q] * u[q];
             z[i + q] = zi;
             zz += zi * zi; zr += zi * ri;
         }
@@ -397,82 +646,138 @@ __global__ void __launch_bounds__(256) k_additive_finish(int nn, double alpha, c
     }
 }
 
-template <int BS>
-__global__ void __launch_bounds__(256) k_restrict_box(Grid3 gf, Grid3 gc, const double* __restrict__ tf,
-                                                      double* __restrict__ rc)
+// r_{l+1}[A] = sum over the children a of A of T_a^T t_l[a]
+template <int CS>
+__global__ void __launch_bounds__(256) k_restrict_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc,
+                                                      const double* __restrict__ tf, double* __restrict__ rc)
 {
     const int A = blockIdx.x * blockDim.x + threadIdx.x;
     if (A >= gc.nb()) return;
     const int ax = A % gc.nx, ay = (A / gc.nx) % gc.ny, az = A / (gc.nx * gc.ny);
-    double acc[BS];
+    double cA[3], acc[CS];
+    box_centre(gc, geoc, A, cA);
 #pragma unroll
-    for (int q = 0; q < BS; q++) acc[q] = 0.0;
+    for (int q = 0; q < CS; q++) acc[q] = 0.0;
     for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
         const int fx = 2 * ax + cx, fy = 2 * ay + cy, fz = 2 * az + cz;
         if (fx >= gf.nx || fy >= gf.ny || fz >= gf.nz) continue;
-        const size_t a = (size_t)(fx + gf.nx * (fy + gf.ny * fz)) * BS;
+        const int a = fx + gf.nx * (fy + gf.ny * fz);
+        double ca[3], d[3], F[CS];
+        box_centre(gf, geof, a, ca);
+        for (int k = 0; k < 3; k++) d[k] = ca[k] - cA[k];
+        box_apply_t<CS>(d, tf + (size_t)a * CS, F);
 #pragma unroll
-        for (int q = 0; q < BS; q++) acc[q] += tf[a + q];
+        for (int q = 0; q < CS; q++) acc[q] += F[q];
     }
 #pragma unroll
-    for (int q = 0; q < BS; q++) rc[(size_t)A * BS + q] = acc[q];
+    for (int q = 0; q < CS; q++) rc[(size_t)A * CS + q] = acc[q];
 }
 
-template <int BS>
-__global__ void __launch_bounds__(256) k_prolong_box(Grid3 gf, Grid3 gc, double alpha, const double* __restrict__ xc,
-                                                     double* __restrict__ xf)
+// x_l[a] += alpha * T_a x_{l+1}[parent(a)]
+template <int CS>
+__global__ void __launch_bounds__(256) k_prolong_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc, double alpha,
+                                                     const double* __restrict__ xc, double* __restrict__ xf)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= gf.nb()) return;
     const int px = (a % gf.nx) >> 1, py = ((a / gf.nx) % gf.ny) >> 1, pz = (a / (gf.nx * gf.ny)) >> 1;
-    const size_t A = (size_t)(px + gc.nx * (py + gc.ny * pz)) * BS;
+    const int A = px + gc.nx * (py + gc.ny * pz);
+    double ca[3], cA[3], d[3], x[CS];
+    box_centre(gf, geof, a, ca);
+    box_centre(gc, geoc, A, cA);
+    for (int k = 0; k < 3; k++) d[k] = ca[k] - cA[k];
+    box_apply<CS>(d, xc + (size_t)A * CS, x);
 #pragma unroll
-    for (int q = 0; q < BS; q++) xf[(size_t)a * BS + q] += alpha * xc[A + q];
+    for (int q = 0; q < CS; q++) xf[(size_t)a * CS + q] += alpha * x[q];
 }
 
-// ---- coarsest grid: dense inverse by Gauss-Jordan (one workgroup) -------------------------------------
-template <int BS>
+// ---- coarsest grid: dense inverse by Gauss-Jordan -----------------------------------------------------
+template <int CS>
 __global__ void __launch_bounds__(256) k_dense_from_stencil(Grid3 g, const double* __restrict__ st, double* __restrict__ M)
 {
-    constexpr int BB = BS * BS;
-    const int nb = g.nb(), n = nb * BS;
-    for (int idx = threadIdx.x + blockIdx.x * blockDim.x; idx < n * 2 * n; idx += gridDim.x * blockDim.x) M[idx] = 0.0;
+    constexpr int CC = CS * CS;
+    const int nb = g.nb(), n = nb * CS;
+    for (int idx = threadIdx.x; idx < n * 2 * n; idx += blockDim.x) M[idx] = 0.0;
     __syncthreads();
-    if (blockIdx.x != 0) return;
     for (int b = threadIdx.x; b < nb; b += blockDim.x) {
         for (int s = 0; s < 27; s++) {
             int c;
             if (!neighbour_box(g, b, s, c)) continue;
-            for (int q = 0; q < BS; q++)
-                for (int p = 0; p < BS; p++)
-                    M[(size_t)(b * BS + q) * 2 * n + c * BS + p] += st[((size_t)s * BB + q * BS + p) * nb + b];
+            for (int q = 0; q < CS; q++)
+                for (int p = 0; p < CS; p++)
+                    M[(size_t)(b * CS + q) * 2 * n + c * CS + p] += st[((size_t)s * CC + q * CS + p) * nb + b];
         }
-        for (int q = 0; q < BS; q++) {
-            const int i = b * BS + q;
-            if (M[(size_t)i * 2 * n + i] == 0.0) M[(size_t)i * 2 * n + i] = 1.0;  // empty / fully constrained box
+        for (int q = 0; q < CS; q++) {
+            const int i = b * CS + q;
+            double& dii = M[(size_t)i * 2 * n + i];
+            // a box with fewer than three non-collinear free nodes cannot carry all its rigid-body
+            // modes: its rows are rank deficient (the right-hand sides P^T r stay consistent).  A
+            // relative diagonal shift keeps the pivots of the unpivoted elimination away from zero;
+            // the null-space components it lets through prolong to nothing.
+            dii = (dii == 0.0) ? 1.0 : dii * (1.0 + 1e-10);  // == 0: empty / fully constrained box
             M[(size_t)i * 2 * n + n + i] = 1.0;
         }
     }
 }
 
-// Gauss-Jordan on [A | I] (n x 2n, row-major), two small launches per pivot so that the
-// rank-1 update runs on the whole chip (a single workgroup needs ~50 ms for n = 375).  A is
-// symmetric positive (semi-)definite with unit rows for empty boxes: no pivot search.
-__global__ void __launch_bounds__(256) k_gj_pivot(int n, int k, const double* __restrict__ M, double* __restrict__ rowk,
+// Gauss-Jordan on [A | I] (n x 2n, row-major) by CS x CS pivot blocks (one box at a time), two
+// launches per block so that the rank-CS update runs on the whole chip.  A is symmetric positive
+// definite after the shift above: no pivot search.
+//   rowk[q][t] = (D^-1 M[block rows])[q][t]      colk[p][i] = M[i][block col p]
+template <int CS>
+__global__ void __launch_bounds__(256) k_gj_pivot(int n, int kb, const double* __restrict__ M, double* __restrict__ rowk,
                                                   double* __restrict__ colk)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const double piv = 1.0 / M[(size_t)k * 2 * n + k];
-    if (t < 2 * n) rowk[t] = M[(size_t)k * 2 * n + t] * piv;
-    if (t < n) colk[t] = M[(size_t)t * 2 * n + k];
+    const int k0 = kb * CS;
+    double D[CS][2 * CS];   // [D | I] -> [I | D^-1], every thread for itself (CS <= 6)
+#pragma unroll
+    for (int r = 0; r < CS; r++)
+#pragma unroll
+        for (int c = 0; c < CS; c++) { D[r][c] = M[(size_t)(k0 + r) * 2 * n + k0 + c]; D[r][CS + c] = (r == c) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int k = 0; k < CS; k++) {
+        const double piv = 1.0 / D[k][k];
+#pragma unroll
+        for (int c = 0; c < 2 * CS; c++) D[k][c] *= piv;
+#pragma unroll
+        for (int r = 0; r < CS; r++) {
+            if (r == k) continue;
+            const double f = D[r][k];
+#pragma unroll
+            for (int c = 0; c < 2 * CS; c++) D[r][c] -= f * D[k][c];
+        }
+    }
+    if (t < 2 * n) {
+        double m[CS];
+#pragma unroll
+        for (int p = 0; p < CS; p++) m[p] = M[(size_t)(k0 + p) * 2 * n + t];
+#pragma unroll
+        for (int q = 0; q < CS; q++) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < CS; p++) v += D[q][CS + p] * m[p];
+            rowk[(size_t)q * 2 * n + t] = v;
+        }
+    }
+    if (t < n) {
+#pragma unroll
+        for (int p = 0; p < CS; p++) colk[(size_t)p * n + t] = M[(size_t)t * 2 * n + k0 + p];
+    }
 }
-__global__ void __launch_bounds__(256) k_gj_update(int n, int k, double* __restrict__ M, const double* __restrict__ rowk,
+template <int CS>
+__global__ void __launch_bounds__(256) k_gj_update(int n, int kb, double* __restrict__ M, const double* __restrict__ rowk,
                                                    const double* __restrict__ colk)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n * 2 * n) return;
     const int i = idx / (2 * n), j = idx - i * 2 * n;
-    M[idx] = (i == k) ? rowk[j] : M[idx] - colk[i] * rowk[j];
+    const int k0 = kb * CS;
+    if (i >= k0 && i < k0 + CS) { M[idx] = rowk[(size_t)(i - k0) * 2 * n + j]; return; }
+    double v = M[idx];
+#pragma unroll
+    for (int p = 0; p < CS; p++) v -= colk[(size_t)p * n + i] * rowk[(size_t)p * 2 * n + j];
+    M[idx] = v;
 }
 
 // x = A^-1 r on the coarsest grid: one wavefront per row, fixed shuffle tree
@@ -490,20 +795,24 @@ __global__ void __launch_bounds__(256) k_dense_apply(int n, const double* __rest
 // ---- host side ----------------------------------------------------------------------------------------------
 static unsigned g1(size_t n) { return std::max(1u, cdiv(n, 256)); }
 static unsigned gs(size_t n) { return std::min<unsigned>(std::max(1u, cdiv(n, 256)), 2048); }
+static Grid3 grid_of(const MgLevel& L) { return Grid3{L.nx, L.ny, L.nz}; }
+static BoxGeom geom_of(const MgLevel& L) { return BoxGeom{{L.lo[0], L.lo[1], L.lo[2]}, L.H}; }
 
-template <int BS>
+template <int BS, int PD>
 static void setup_t(Multigrid& mg)
 {
+    constexpr int CS = CoarseDofs<BS>::value;
     fem_mat A = mg.A;
     fem_mesh mesh = A->mesh;
     fem_ctx ctx = A->ctx;
     hipStream_t s = ctx->stream;
-    const int nn = mesh->nnds, pd = mesh->pdim;
+    const int nn = mesh->nnds;
     const size_t ndof = (size_t)nn * BS;
+    mg.cs = CS;
     // bounding box
     const int pg = 256;
     DBuf<double> dbb((size_t)pg * 6);
-    hipLaunchKernelGGL(k_bbox_partial, dim3(pg), dim3(256), 0, s, (size_t)nn, pd, mesh->coords.p, dbb.p);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(pg), dim3(256), 0, s, (size_t)nn, PD, mesh->coords.p, dbb.p);
     std::vector<double> hbb((size_t)pg * 6);
     dbb.download(hbb.data(), hbb.size(), s);
     FEM_HIP(hipStreamSynchronize(s));
@@ -511,13 +820,13 @@ static void setup_t(Multigrid& mg)
     for (int b = 0; b < pg; b++)
         for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], hbb[b * 6 + d]); hi[d] = std::max(hi[d], hbb[b * 6 + 3 + d]); }
     double vol = 1.0;
-    for (int d = 0; d < pd; d++) vol *= std::max(hi[d] - lo[d], 1e-300);
-    const double hnode = std::pow(vol / std::max(nn, 1), 1.0 / pd);  // mean node spacing
-    const double H = 4.0 * hnode;                                    // ~4 nodes per box edge
+    for (int d = 0; d < PD; d++) vol *= std::max(hi[d] - lo[d], 1e-300);
+    const double hnode = std::pow(vol / std::max(nn, 1), 1.0 / PD);  // mean node spacing
+    const double H = mg.box * hnode;                                 // ~4 nodes per box edge by default
     Grid3 g{1, 1, 1};
     int* gd[3] = {&g.nx, &g.ny, &g.nz};
-    for (int d = 0; d < pd; d++) *gd[d] = std::max(1, (int)std::floor((hi[d] - lo[d]) / H + 1e-9) + 1);
-    for (int d = pd; d < 3; d++) lo[d] = 0.0;
+    for (int d = 0; d < PD; d++) *gd[d] = std::max(1, (int)std::floor((hi[d] - lo[d]) / H + 1e-9) + 1);
+    for (int d = PD; d < 3; d++) lo[d] = -0.5 * H;   // flat direction: the single box layer is centred on z = 0
     FEM_CHECK((long long)g.nx * g.ny * g.nz < (1LL << 26), 9, "pc mg: box grid too large");
 
     // level-1 aggregates and their node lists
@@ -525,7 +834,7 @@ static void setup_t(Multigrid& mg)
     int nb = g.nb();
     DBuf<int> cnt((size_t)nb), cursor((size_t)nb), tmp(exclusive_scan_tmp_ints((size_t)nb + 1));
     cnt.zero(s); cursor.zero(s);
-    hipLaunchKernelGGL(k_assign_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, pd, mesh->coords.p, lo[0], lo[1], lo[2], 1.0 / H,
+    hipLaunchKernelGGL(k_assign_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, PD, mesh->coords.p, lo[0], lo[1], lo[2], 1.0 / H,
                        g, mg.agg.p, cnt.p);
     mg.box_ptr.alloc((size_t)nb + 1);
     exclusive_scan_i32(cnt.p, mg.box_ptr.p, nb, tmp.p, s);
@@ -538,43 +847,70 @@ static void setup_t(Multigrid& mg)
     mat_get_diagonal_raw(A, mg.t0.p);
     hipLaunchKernelGGL(k_free_weights, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.t0.p, mg.w.p, mg.dinv0.p);
 
-    // level 1
     DBuf<int> err(1);
     err.zero(s);
     mg.lev.clear();
-    auto new_level = [&](Grid3 gg) {
+    auto new_level = [&](Grid3 gg, double Hl) {
         mg.lev.emplace_back();
         MgLevel& L = mg.lev.back();
         L.nx = gg.nx; L.ny = gg.ny; L.nz = gg.nz; L.nb = gg.nb();
-        L.st.alloc((size_t)27 * BS * BS * L.nb);
-        L.dinv.alloc((size_t)L.nb * BS); L.x.alloc((size_t)L.nb * BS); L.r.alloc((size_t)L.nb * BS);
-        L.t.alloc((size_t)L.nb * BS);
+        for (int d = 0; d < 3; d++) L.lo[d] = lo[d];
+        L.H = Hl;
+        L.st.alloc((size_t)27 * CS * CS * L.nb);
+        L.dinv.alloc((size_t)L.nb * CS * CS); L.x.alloc((size_t)L.nb * CS); L.r.alloc((size_t)L.nb * CS);
+        L.t.alloc((size_t)L.nb * CS);
     };
-    new_level(g);
-    hipLaunchKernelGGL(k_galerkin_fine_wave<BS>, dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, mg.box_ptr.p, mg.box_nodes.p,
-                       mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->val.p, mg.w.p, mg.lev[0].st.p, err.p);
-    hipLaunchKernelGGL(k_level_dinv<BS>, dim3(g1(nb)), dim3(256), 0, s, nb, mg.lev[0].st.p, mg.lev[0].dinv.p);
+    new_level(g, H);
+    if (PD == 2) mg.lev[0].lo[2] = -0.5 * H;
+    hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, geom_of(mg.lev[0]),
+                       mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->val.p,
+                       mg.w.p, mg.lev[0].st.p, err.p);
+    hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(nb)), dim3(256), 0, s, nb, mg.lev[0].st.p, mg.lev[0].dinv.p);
     // coarser levels: merge 2x2x2 boxes until the grid is at most 5 boxes per direction
-    // (<= 375 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
+    // (<= 750 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
+    double Hl = H;
     while (std::max(g.nx, std::max(g.ny, g.nz)) > 5) {
         Grid3 gc{(g.nx + 1) / 2, (g.ny + 1) / 2, (g.nz + 1) / 2};
-        new_level(gc);
+        Hl *= 2.0;
+        new_level(gc, Hl);
         MgLevel& Lf = mg.lev[mg.lev.size() - 2];
         MgLevel& Lc = mg.lev.back();
-        hipLaunchKernelGGL(k_galerkin_box<BS>, dim3(g1((size_t)27 * gc.nb())), dim3(256), 0, s, g, gc, Lf.st.p, Lc.st.p);
-        hipLaunchKernelGGL(k_level_dinv<BS>, dim3(g1(gc.nb())), dim3(256), 0, s, gc.nb(), Lc.st.p, Lc.dinv.p);
+        if (PD == 2) Lc.lo[2] = -0.5 * Hl;   // keep the single layer centred on z = 0
+        hipLaunchKernelGGL(k_galerkin_box<CS>, dim3(g1((size_t)27 * gc.nb())), dim3(256), 0, s, g, geom_of(Lf), gc,
+                           geom_of(Lc), Lf.st.p, Lc.st.p);
+        hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(gc.nb())), dim3(256), 0, s, gc.nb(), Lc.st.p, Lc.dinv.p);
         g = gc;
     }
+    // damping of the block-Jacobi smoother on every smoothed level: power iteration on Dinv A
+    mg.omega_l.alloc(mg.lev.size() + 2);
+    for (size_t l = 0; l + 1 < mg.lev.size(); l++) {
+        MgLevel& L = mg.lev[l];
+        const Grid3 gl = grid_of(L);
+        const size_t n = (size_t)L.nb * CS;
+        double* n2 = mg.omega_l.p + mg.lev.size();
+        L.r.zero(s);
+        hipLaunchKernelGGL(k_hash_fill, dim3(gs(n)), dim3(256), 0, s, n, L.x.p);
+        const int npow = 12;
+        for (int it = 0; it < npow; it++) {
+            if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2);
+            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, gl, L.st.p, L.x.p, L.r.p, L.t.p);
+            hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, (const double*)nullptr,
+                               L.dinv.p, L.t.p, L.x.p);
+        }
+        hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2 + 1);
+        hipLaunchKernelGGL(k_set_omega, dim3(1), dim3(1), 0, s, n2, mg.omega_l.p + l);
+    }
     // coarsest: dense inverse
-    mg.ncoarse = g.nb() * BS;
+    mg.ncoarse = g.nb() * CS;
     mg.cinv.alloc((size_t)mg.ncoarse * 2 * mg.ncoarse);
-    hipLaunchKernelGGL(k_dense_from_stencil<BS>, dim3(1), dim3(256), 0, s, g, mg.lev.back().st.p, mg.cinv.p);
+    hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, g, mg.lev.back().st.p, mg.cinv.p);
     {
         const int n = mg.ncoarse;
-        DBuf<double> rowk((size_t)2 * n), colk((size_t)n);
-        for (int k = 0; k < n; k++) {
-            hipLaunchKernelGGL(k_gj_pivot, dim3(g1((size_t)2 * n)), dim3(256), 0, s, n, k, mg.cinv.p, rowk.p, colk.p);
-            hipLaunchKernelGGL(k_gj_update, dim3(g1((size_t)n * 2 * n)), dim3(256), 0, s, n, k, mg.cinv.p, rowk.p, colk.p);
+        DBuf<double> rowk((size_t)CS * 2 * n), colk((size_t)CS * n);
+        for (int kb = 0; kb < n / CS; kb++) {
+            hipLaunchKernelGGL(k_gj_pivot<CS>, dim3(g1((size_t)2 * n)), dim3(256), 0, s, n, kb, mg.cinv.p, rowk.p, colk.p);
+            hipLaunchKernelGGL(k_gj_update<CS>, dim3(g1((size_t)n * 2 * n)), dim3(256), 0, s, n, kb, mg.cinv.p, rowk.p,
+                               colk.p);
         }
         FEM_HIP(hipStreamSynchronize(s));   // rowk/colk go out of scope
     }
@@ -583,66 +919,84 @@ static void setup_t(Multigrid& mg)
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
     FEM_CHECK(!herr, 9, "pc mg: an element spans more than two boxes of the aggregation grid (mesh too graded)");
+    if (getenv("FEM_AMD_MG_VERBOSE")) {
+        std::vector<double> om(mg.lev.size() + 2);
+        mg.omega_l.download(om.data(), om.size(), s);
+        FEM_HIP(hipStreamSynchronize(s));
+        for (size_t l = 0; l < mg.lev.size(); l++)
+            fprintf(stderr, "[fem_amd mg] level %zu: %d x %d x %d boxes, %d dofs/box, H = %g%s\n", l + 1, mg.lev[l].nx,
+                    mg.lev[l].ny, mg.lev[l].nz, CS, mg.lev[l].H,
+                    (l + 1 < mg.lev.size()) ? (", omega = " + std::to_string(om[l])).c_str() : ", dense inverse");
+    }
 }
 
-template <int BS>
+template <int CS>
 static void cycle_t(Multigrid& mg, size_t l)
 {
     hipStream_t s = mg.A->ctx->stream;
     MgLevel& L = mg.lev[l];
-    const Grid3 g{L.nx, L.ny, L.nz};
-    const size_t n = (size_t)L.nb * BS;
+    const Grid3 g = grid_of(L);
+    const size_t n = (size_t)L.nb * CS;
     if (l + 1 == mg.lev.size()) {
         hipLaunchKernelGGL(k_dense_apply, dim3(g1(n * 64)), dim3(256), 0, s, (int)n, mg.cinv.p, L.r.p, L.x.p);
         return;
     }
     auto residual = [&] {   // small levels: 32 lanes per box (latency), large ones: one thread per box (bandwidth)
         if (L.nb <= 16384)
-            hipLaunchKernelGGL(k_box_residual_slots<BS>, dim3(g1((size_t)L.nb * 32)), dim3(256), 0, s, g, L.st.p, L.x.p,
+            hipLaunchKernelGGL(k_box_residual_slots<CS>, dim3(g1((size_t)L.nb * 32)), dim3(256), 0, s, g, L.st.p, L.x.p,
                                L.r.p, L.t.p);
         else
-            hipLaunchKernelGGL(k_box_residual<BS>, dim3(g1(L.nb)), dim3(256), 0, s, g, L.st.p, L.x.p, L.r.p, L.t.p);
+            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, L.st.p, L.x.p, L.r.p, L.t.p);
     };
     MgLevel& C = mg.lev[l + 1];
-    const Grid3 gc{C.nx, C.ny, C.nz};
-    hipLaunchKernelGGL(k_smooth_first, dim3(gs(n)), dim3(256), 0, s, n, mg.omega, L.dinv.p, L.r.p, L.x.p);
+    const Grid3 gc = grid_of(C);
+    hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, mg.omega_l.p + l, L.dinv.p, L.r.p,
+                       L.x.p);
     residual();
-    hipLaunchKernelGGL(k_restrict_box<BS>, dim3(g1(C.nb)), dim3(256), 0, s, g, gc, L.t.p, C.r.p);
-    cycle_t<BS>(mg, l + 1);
-    hipLaunchKernelGGL(k_prolong_box<BS>, dim3(g1(L.nb)), dim3(256), 0, s, g, gc, mg.alpha, C.x.p, L.x.p);
+    hipLaunchKernelGGL(k_restrict_box<CS>, dim3(g1(C.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), L.t.p, C.r.p);
+    cycle_t<CS>(mg, l + 1);
+    hipLaunchKernelGGL(k_prolong_box<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), mg.alpha, C.x.p,
+                       L.x.p);
     residual();
-    hipLaunchKernelGGL(k_smooth_add, dim3(gs(n)), dim3(256), 0, s, n, mg.omega, L.dinv.p, L.t.p, L.x.p);
+    hipLaunchKernelGGL((k_block_smooth<CS, true>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, mg.omega_l.p + l, L.dinv.p, L.t.p,
+                       L.x.p);
 }
 
-template <int BS>
+template <int BS, int PD>
 static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, double* pzz, double* pzr, int npart)
 {
+    constexpr int CS = CoarseDofs<BS>::value;
     fem_mat A = mg.A;
     hipStream_t s = A->ctx->stream;
     const int nn = mg.nn;
     const size_t ndof = (size_t)nn * BS;
     MgLevel& L1 = mg.lev[0];
+    const Grid3 g = grid_of(L1);
+    const BoxGeom geo = geom_of(L1);
+    const double* coords = A->mesh->coords.p;
     if (mg.fine_additive) {
         // fine level additive (Jacobi + coarse-grid correction of the un-smoothed residual): the
         // preconditioner costs no fine-level product; the coarse hierarchy is still a V-cycle
-        hipLaunchKernelGGL(k_restrict_fine<BS>, dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, L1.nb, mg.box_ptr.p,
-                           mg.box_nodes.p, mg.w.p, r, (const double*)nullptr, L1.r.p);
-        cycle_t<BS>(mg, 0);
+        hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
+                           mg.box_ptr.p, mg.box_nodes.p, mg.w.p, r, (const double*)nullptr, L1.r.p);
+        cycle_t<CS>(mg, 0);
         if (pzz) {   // the caller wants z.z and z.r as well: one fused pass
-            hipLaunchKernelGGL(k_additive_finish<BS>, dim3(npart), dim3(256), 0, s, nn, mg.alpha, mg.agg.p, mg.w.p,
-                               mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done);
+            hipLaunchKernelGGL((k_additive_finish<BS, CS, PD>), dim3(npart), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
+                               mg.agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done);
         } else {
             hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, 1.0, mg.dinv0.p, r, z);
-            hipLaunchKernelGGL(k_prolong_fine<BS>, dim3(g1(nn)), dim3(256), 0, s, nn, mg.alpha, mg.agg.p, mg.w.p, L1.x.p, z);
+            hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
+                               mg.agg.p, mg.w.p, L1.x.p, z);
         }
         return;
     }
     hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
-    hipLaunchKernelGGL(k_restrict_fine<BS>, dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, L1.nb, mg.box_ptr.p, mg.box_nodes.p,
-                       mg.w.p, r, mg.t0.p, L1.r.p);
-    cycle_t<BS>(mg, 0);
-    hipLaunchKernelGGL(k_prolong_fine<BS>, dim3(g1(nn)), dim3(256), 0, s, nn, mg.alpha, mg.agg.p, mg.w.p, L1.x.p, z);
+    hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
+                       mg.box_ptr.p, mg.box_nodes.p, mg.w.p, r, mg.t0.p, L1.r.p);
+    cycle_t<CS>(mg, 0);
+    hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.agg.p,
+                       mg.w.p, L1.x.p, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
     hipLaunchKernelGGL(k_fine_post, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, mg.t0.p, z);
 }
@@ -652,19 +1006,19 @@ void Multigrid::setup(fem_mat A_)
     A = A_; bs = A->bs; nn = A->nbrows;
     FEM_CHECK(!(A->mesh->halo && A->mesh->halo->comm->size > 1), 9, "pc mg: multi-domain runs are not supported yet");
     A->ctx->bind();
-    if (bs == 3) setup_t<3>(*this); else setup_t<2>(*this);
+    if (bs == 3) setup_t<3, 3>(*this); else setup_t<2, 2>(*this);
 }
 
 void Multigrid::apply(const double* r, double* z, const int* done, double* pzz, double* pzr, int npart)
 {
-    if (bs == 3) apply_t<3>(*this, r, z, done, pzz, pzr, npart); else apply_t<2>(*this, r, z, done, pzz, pzr, npart);
+    if (bs == 3) apply_t<3, 3>(*this, r, z, done, pzz, pzr, npart); else apply_t<2, 2>(*this, r, z, done, pzz, pzr, npart);
 }
 
 bool Multigrid::fuses_dots() const { return fine_additive; }
 
 size_t Multigrid::device_bytes() const
 {
-    size_t b = agg.bytes() + box_ptr.bytes() + box_nodes.bytes() + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
+    size_t b = omega_l.bytes() + agg.bytes() + box_ptr.bytes() + box_nodes.bytes() + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
     for (auto& L : lev) b += L.st.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes();
     return b;
 }

@@ -48,6 +48,7 @@ _SIGS = {
     "fem_form_el_ke": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp],
     "fem_calc_el_stress": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp],
     "fem_form_el_indx": [C.c_int, C.c_int, _ip, _ip],
+    "fem_rcm_order": [C.c_int, _ip, _ip, _ip],
     "fem_mesh_create": [_h, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp, C.c_int, _dp, C.POINTER(_h)],
     "fem_mesh_destroy": [_h],
     "fem_mesh_set_halo": [_h, _h, C.c_int, _ip, _ip, _ip],
@@ -213,6 +214,14 @@ def form_el_indx(pdim: int, enodes) -> np.ndarray:
     out = np.zeros(len(en) * pdim, dtype=np.int32)
     _ck(_lib.fem_form_el_indx(pdim, len(en), _i(en), _i(out)))
     return out
+
+
+def rcm_order(ptr, adj) -> np.ndarray:
+    """Reverse Cuthill-McKee numbering of an undirected graph (CSR adjacency): perm[old] = new."""
+    ptr, adj = _i32(ptr), _i32(adj)
+    perm = np.zeros(len(ptr) - 1, dtype=np.int32)
+    _ck(_lib.fem_rcm_order(len(ptr) - 1, _i(ptr), _i(adj), _i(perm)))
+    return perm
 
 
 class Comm:

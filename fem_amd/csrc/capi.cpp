@@ -3,7 +3,11 @@
 // codes; fem_last_error() returns the message of the calling thread's last failure.
 #include <cstring>
 
+#include <algorithm>
+#include <vector>
+
 #include "comm.h"
+#include "direct.h"
 #include "objects.h"
 
 using namespace fem;
@@ -190,6 +194,17 @@ int fem_form_el_indx(int pdim, int n, const int* enodes, int* indx)
     FEM_CHECK(pdim == 2 || pdim == 3, 2, "fem_form_el_indx: pdim must be 2 or 3");
     for (int j = 0; j < n; j++)
         for (int d = 0; d < pdim; d++) indx[pdim * j + d] = pdim * enodes[j] + d;
+    FEM_CATCH
+}
+
+int fem_rcm_order(int n, const int* ptr, const int* adj, int* perm)
+{
+    FEM_TRY
+    FEM_CHECK(n >= 0 && ptr && perm && (adj || ptr[n] == 0), 2, "fem_rcm_order: bad arguments");
+    std::vector<int> p(ptr, ptr + n + 1), a(adj, adj + ptr[n]);
+    for (int v : a) FEM_CHECK(v >= 0 && v < n, 2, "fem_rcm_order: neighbour id out of range");
+    const std::vector<int> out = fem::rcm_order(n, p, a);
+    std::copy(out.begin(), out.end(), perm);
     FEM_CATCH
 }
 

@@ -1,0 +1,42 @@
+// fem_amd/csrc/direct.h -- direct solve behind the KSP surface (`-ksp_type preonly -pc_type lu|cholesky`).
+//
+// The reference's production path is a direct factorisation: KSPPREONLY + PCLU through MUMPS
+// (src/main.F90:354-372).  SURVEY.md 8(f4) asks for that option for small and medium decks.
+// Mat_K is symmetric (the penalty method only INSERTs on the diagonal, src/m_global.F90:400-414)
+// and positive definite once rigid-body motion is constrained, so the factorisation is a banded
+// Cholesky  P K P^T = L L^T  after a reverse Cuthill-McKee renumbering of the nodes:
+//   storage   lower band, element (i, j) at ab[i*bw + j + bw]  (j <= i <= j + bw): any block inside
+//             the band is an ordinary row-major matrix with row stride bw
+//   factor    right-looking, 64-column blocks: potrf of the diagonal block plus the inverse of its
+//             factor (one workgroup, LDS) -> panel L21 = A21 L11^-T and the symmetric rank-64 update
+//             of the trailing window, both 64x64 tiles on the fp64 matrix cores (v_mfma_f64_16x16x4_f64)
+//   solve     blocked forward / backward substitution, one launch per 64-row block; the diagonal
+//             blocks act through their stored inverses (no dependent chains)
+// Memory is n*(bw+1) doubles; set-up refuses decks whose band does not fit (use -ksp_type cg).
+#pragma once
+#include <vector>
+
+#include "objects.h"
+
+namespace fem {
+
+struct BandCholesky {
+    fem_mat A = nullptr;
+    int bs = 0;
+    long long n = 0;
+    int bw = 0;                 // half bandwidth in dofs after renumbering
+    bool failed = false;        // a non-positive pivot was met (matrix not positive definite)
+    DBuf<int> perm_dof;         // [n] new position of every dof
+    DBuf<double> ab;            // [n*(bw+1)] the factor L, band storage
+    DBuf<double> linv;          // [n/64][64][64] inverse of every diagonal block of L
+    DBuf<double> v0, v1, v2;    // work vectors (permuted rhs, y, x)
+    DBuf<int> flag;
+    void setup(fem_mat A);      // renumber, fill the band, factor
+    void solve(const double* b, double* x);
+    size_t device_bytes() const { return perm_dof.bytes() + ab.bytes() + linv.bytes() + v0.bytes() + v1.bytes() + v2.bytes(); }
+};
+
+// reverse Cuthill-McKee ordering of an undirected graph given as CSR adjacency (host)
+std::vector<int> rcm_order(int n, const std::vector<int>& ptr, const std::vector<int>& adj);
+
+}  // namespace fem

@@ -1,0 +1,517 @@
+// fem_amd/csrc/direct.hip -- banded Cholesky direct solve (see direct.h).
+#include "direct.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+
+#include "comm.h"
+
+using namespace fem;
+
+namespace fem {
+
+// ---- reverse Cuthill-McKee (host; set-up only) -------------------------------------------------------------
+std::vector<int> rcm_order(int n, const std::vector<int>& ptr, const std::vector<int>& adj)
+{
+    std::vector<int> order;           // order[k] = old id of the node numbered k (before reversal)
+    order.reserve(n);
+    std::vector<int> level(n, -1), deg(n);
+    for (int v = 0; v < n; v++) deg[v] = ptr[v + 1] - ptr[v];
+    std::vector<char> done(n, 0);
+    std::vector<int> by_deg(n);
+    for (int v = 0; v < n; v++) by_deg[v] = v;
+    std::stable_sort(by_deg.begin(), by_deg.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+    std::vector<int> queue, nb;
+    // breadth-first levels from `root` over the not yet numbered nodes; returns the last level's minimum-degree node
+    auto bfs = [&](int root, int& depth) {
+        queue.clear();
+        queue.push_back(root);
+        level[root] = 0;
+        for (size_t h = 0; h < queue.size(); h++) {
+            const int v = queue[h];
+            for (int e = ptr[v]; e < ptr[v + 1]; e++) {
+                const int u = adj[e];
+                if (!done[u] && level[u] < 0) { level[u] = level[v] + 1; queue.push_back(u); }
+            }
+        }
+        depth = level[queue.back()];
+        int far = queue.back();
+        for (size_t h = queue.size(); h-- > 0 && level[queue[h]] == depth;)
+            if (deg[queue[h]] < deg[far]) far = queue[h];
+        for (int v : queue) level[v] = -1;
+        return far;
+    };
+    size_t scan = 0;
+    while ((int)order.size() < n) {
+        while (done[by_deg[scan]]) scan++;
+        int root = by_deg[scan];                 // minimum-degree node of the next component
+        // pseudo-peripheral node: walk to the far end while the eccentricity grows
+        int depth = -1;
+        for (int pass = 0; pass < 8; pass++) {
+            int d;
+            const int far = bfs(root, d);
+            if (d <= depth) break;
+            depth = d;
+            root = far;
+        }
+        // Cuthill-McKee numbering of the component
+        const size_t first = order.size();
+        order.push_back(root);
+        done[root] = 1;
+        for (size_t h = first; h < order.size(); h++) {
+            const int v = order[h];
+            nb.clear();
+            for (int e = ptr[v]; e < ptr[v + 1]; e++)
+                if (!done[adj[e]]) { nb.push_back(adj[e]); done[adj[e]] = 1; }
+            std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return deg[a] < deg[b]; });
+            order.insert(order.end(), nb.begin(), nb.end());
+        }
+    }
+    std::vector<int> perm(n);          // perm[old] = new, reversed numbering
+    for (int k = 0; k < n; k++) perm[order[k]] = n - 1 - k;
+    return perm;
+}
+
+// ---- kernels ------------------------------------------------------------------------------------
+constexpr int NB = 64;
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ size_t band_idx(long long i, long long j, int bw) { return (size_t)(i * bw + j + bw); }
+
+// lower triangle of P K P^T into the band
+template <int BS>
+__global__ void __launch_bounds__(256) k_band_fill(int nbrows, const int* __restrict__ boff, const int* __restrict__ bcol,
+                                                   const double* __restrict__ val, const int* __restrict__ rowlen,
+                                                   const int* __restrict__ perm, int bw, double* __restrict__ ab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbrows) return;
+    const size_t o0 = (size_t)boff[i >> 6];
+    const int ln = i & 63, len = rowlen[i];
+    const long long pi = perm[i];
+    for (int j = 0; j < len; j++) {
+        const long long pc = perm[bcol[(o0 + j) * 64 + ln]];
+#pragma unroll
+        for (int r = 0; r < BS; r++)
+#pragma unroll
+            for (int c = 0; c < BS; c++) {
+                const long long gi = pi * BS + r, gj = pc * BS + c;
+                if (gj <= gi) ab[band_idx(gi, gj, bw)] = val[((o0 + j) * BS * BS + r * BS + c) * 64 + ln];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_perm_dof(int nn, int bs, const int* __restrict__ perm, int* __restrict__ perm_dof)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    for (int r = 0; r < bs; r++) perm_dof[(size_t)v * bs + r] = perm[v] * bs + r;
+}
+__global__ void __launch_bounds__(256) k_permute_in(size_t n, const int* __restrict__ perm, const double* __restrict__ b,
+                                                    double* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[perm[i]] = b[i];
+}
+__global__ void __launch_bounds__(256) k_permute_out(size_t n, const int* __restrict__ perm, const double* __restrict__ in,
+                                                     double* __restrict__ x)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = in[perm[i]];
+}
+
+// Loaders (256 threads).  Masked entries read ab[0] (allocated, unused) and are replaced after the
+// load, so that the 16 loads of a thread are issued back to back instead of behind branches.
+// the kb x kb diagonal block at k0 (lower triangle, zero outside the band); identity padding
+__device__ __forceinline__ void load_diag_block(double (*L)[NB + 1], const double* __restrict__ ab, int bw, long long k0,
+                                                int kb, int tid)
+{
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; e++) {
+        const int t = tid + e * 256, i = t >> 6, j = t & 63;
+        const bool ok = i < kb && j <= i && i - j <= bw;
+        v[e] = ab[ok ? band_idx(k0 + i, k0 + j, bw) : 0];
+    }
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; e++) {
+        const int t = tid + e * 256, i = t >> 6, j = t & 63;
+        const bool ok = i < kb && j <= i && i - j <= bw;
+        L[i][j] = ok ? v[e] : ((i == j) ? 1.0 : 0.0);
+    }
+}
+// 64 rows from R0 of the panel below the diagonal block (columns k0 .. k0+kb-1), zero outside the band
+__device__ __forceinline__ void load_panel_tile(double (*T)[NB + 1], const double* __restrict__ ab, int bw, long long k0,
+                                                int kb, long long R0, long long lim, int tid)
+{
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; e++) {
+        const int t = tid + e * 256, i = t >> 6, j = t & 63;
+        const long long row = R0 + i;
+        const bool ok = row < lim && j < kb && row - (k0 + j) <= bw;
+        v[e] = ab[ok ? band_idx(row, k0 + j, bw) : 0];
+    }
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; e++) {
+        const int t = tid + e * 256, i = t >> 6, j = t & 63;
+        const long long row = R0 + i;
+        const bool ok = row < lim && j < kb && row - (k0 + j) <= bw;
+        T[i][j] = ok ? v[e] : 0.0;
+    }
+}
+__device__ __forceinline__ void load_dense64(double (*L)[NB + 1], const double* __restrict__ src, int tid)
+{
+    double v[NB * NB / 256];
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; e++) v[e] = src[tid + e * 256];
+#pragma unroll
+    for (int e = 0; e < NB * NB / 256; e++) {
+        const int t = tid + e * 256;
+        L[t >> 6][t & 63] = v[e];
+    }
+}
+
+// 64x64 product on the fp64 matrix cores, D = A B^T with A = Ap (rows i), B = Bp (rows j), both
+// [64][64+1] in LDS; four wavefronts, each 16 rows x 64 columns = four 16x16 accumulators
+// (v_mfma_f64_16x16x4_f64):
+//   A operand  lane l holds Ap[16w + (l&15)][k + (l>>4)],  B operand  lane l holds Bp[16c + (l&15)][k + (l>>4)]
+//   C/D        register q of lane l is (row 16w + (l>>4) + 4q, col 16c + (l&15))
+__device__ __forceinline__ void mfma_tile_abt(const double (*Ap)[NB + 1], const double (*Bp)[NB + 1], int wave, int l,
+                                              double4_t (&acc)[4])
+{
+#pragma unroll
+    for (int c = 0; c < 4; c++) acc[c] = double4_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int kk = 0; kk < NB; kk += 4) {
+        const double a = Ap[16 * wave + (l & 15)][kk + (l >> 4)];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const double b = Bp[16 * c + (l & 15)][kk + (l >> 4)];
+            acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[c], 0, 0, 0);
+        }
+    }
+}
+
+// Cholesky of the diagonal block, in place, and the inverse of its factor into linv[64][64]
+// (zero above the diagonal, identity beyond kb): the panel solve and both substitutions become products.
+// 16 x 16 threads, each keeps a 4x4 sub-block in registers; per column one broadcast of the pivot
+// and one of the scaled column through LDS (two barriers).  Blocks shorter than 64 run on their
+// identity padding.  The inverse is one unrolled forward substitution per column (one wavefront).
+__global__ void __launch_bounds__(256) k_potrf(int bw, long long k0, int kb, double* __restrict__ ab,
+                                               double* __restrict__ linv, int* __restrict__ flag)
+{
+    __shared__ double a[NB][NB + 1], colbuf[NB], dk;
+    const int tid = threadIdx.x;
+    load_diag_block(a, ab, bw, k0, kb, tid);
+    __syncthreads();
+    const int tx = tid & 15, ty = tid >> 4;
+    double c[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[r][q] = a[4 * ty + r][4 * tx + q];
+    for (int kq = 0; kq < NB / 4; kq++) {
+#pragma unroll
+        for (int kr = 0; kr < 4; kr++) {
+            const int k = 4 * kq + kr;
+            if (ty == kq && tx == kq) dk = c[kr][kr];
+            __syncthreads();
+            double d = dk;
+            if (!(d > 0.0)) {          // not positive definite (or NaN): flag it and keep the arithmetic finite
+                if (tid == 0) atomicExch(flag, 1);
+                d = 1.0;
+            }
+            const double sq = sqrt(d), inv = 1.0 / sq;
+            if (tx == kq && ty >= kq) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int i = 4 * ty + r;
+                    if (i > k) c[r][kr] *= inv;
+                    else if (i == k) c[r][kr] = sq;
+                    colbuf[i] = c[r][kr];
+                }
+            }
+            __syncthreads();
+            if (ty >= tx && ty >= kq) {
+                double ci[4], cj[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { ci[r] = colbuf[4 * ty + r]; cj[r] = colbuf[4 * tx + r]; }
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (4 * tx + q > k && 4 * ty + r >= 4 * tx + q) c[r][q] -= ci[r] * cj[q];
+            }
+        }
+    }
+    __syncthreads();
+    if (ty >= tx) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int i = 4 * ty + r, j = 4 * tx + q;
+                if (j <= i) {
+                    a[i][j] = c[r][q];
+                    if (i < kb && i - j <= bw) ab[band_idx(k0 + i, k0 + j, bw)] = c[r][q];
+                }
+            }
+    }
+    __syncthreads();
+    if (tid < NB) {                // column tid of L^-1: forward substitution on the unit vector
+        double x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            double t = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < i; k++) t -= a[i][k] * x[k];
+            x[i] = t / a[i][i];
+            linv[i * NB + tid] = x[i];
+        }
+    }
+}
+
+// panel below the diagonal block:  L21 = A21 L11^-T  as a product with the inverse (64 rows per workgroup)
+__global__ void __launch_bounds__(256) k_trsm(int bw, long long k0, int kb, int m, double* __restrict__ ab,
+                                              const double* __restrict__ linv)
+{
+    __shared__ double T[NB][NB + 1], Li[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const long long R0 = k0 + kb + (long long)blockIdx.x * NB, lim = k0 + kb + m;
+    load_panel_tile(T, ab, bw, k0, kb, R0, lim, tid);
+    load_dense64(Li, linv, tid);
+    __syncthreads();
+    const int wave = tid >> 6, l = tid & 63;
+    double4_t acc[4];
+    mfma_tile_abt(T, Li, wave, l, acc);        // X[i][j] = sum_k T[i][k] Linv[j][k]
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long row = R0 + 16 * wave + (l >> 4) + 4 * q;
+            const int j = 16 * c + (l & 15);
+            if (row < lim && j < kb && row - (k0 + j) <= bw) ab[band_idx(row, k0 + j, bw)] = acc[c][q];
+        }
+}
+
+// trailing window:  A22 -= L21 L21^T  (lower triangle), one 64x64 tile per workgroup
+__global__ void __launch_bounds__(256) k_syrk(int bw, long long k0, int kb, int m, double* __restrict__ ab)
+{
+    __shared__ double Ap[NB][NB + 1], Bp[NB][NB + 1];
+    const int tid = threadIdx.x;
+    const int t = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > t) ti--;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    const long long base = k0 + kb, lim = base + m;
+    const long long I0 = base + (long long)NB * ti, J0 = base + (long long)NB * tj;
+    load_panel_tile(Ap, ab, bw, k0, kb, I0, lim, tid);
+    load_panel_tile(Bp, ab, bw, k0, kb, J0, lim, tid);
+    __syncthreads();
+    const int wave = tid >> 6, l = tid & 63;
+    double4_t acc[4];
+    mfma_tile_abt(Ap, Bp, wave, l, acc);
+    double old[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {     // all sixteen reads in flight before the first write
+            const long long row = I0 + 16 * wave + (l >> 4) + 4 * q, col = J0 + 16 * c + (l & 15);
+            const bool ok = row < lim && col < lim && col <= row;
+            old[c][q] = ab[ok ? band_idx(row, col, bw) : 0];
+        }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const long long row = I0 + 16 * wave + (l >> 4) + 4 * q, col = J0 + 16 * c + (l & 15);
+            if (row < lim && col < lim && col <= row) ab[band_idx(row, col, bw)] = old[c][q] - acc[c][q];
+        }
+}
+
+// forward substitution, block k0:  y_k = L11^-1 b_k  (every wavefront for itself, lane = row), then
+// b[row] -= L21[row] . y_k for this wavefront's rows below the block
+constexpr int FWD_ROWS = 8;    // per wavefront; a workgroup of four covers 32 rows
+__global__ void __launch_bounds__(256) k_fwd(int bw, long long k0, int kb, int m, const double* __restrict__ ab,
+                                             const double* __restrict__ linv, double* __restrict__ b,
+                                             double* __restrict__ y)
+{
+    __shared__ double Li[NB][NB + 1], bk[NB];
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    load_dense64(Li, linv, tid);
+    if (tid < NB) bk[tid] = (tid < kb) ? b[k0 + tid] : 0.0;
+    __syncthreads();
+    double v = 0.0;
+#pragma unroll 8
+    for (int j = 0; j < NB; j++) v += Li[l][j] * bk[j];
+    if (blockIdx.x == 0 && wave == 0 && l < kb) y[k0 + l] = v;
+    const long long lim = k0 + kb + m, row0 = k0 + kb + ((long long)blockIdx.x * 4 + wave) * FWD_ROWS;
+    double t[FWD_ROWS];
+#pragma unroll
+    for (int rr = 0; rr < FWD_ROWS; rr++) {   // independent loads first, reductions after
+        const long long row = row0 + rr;
+        const bool ok = row < lim && l < kb && row - (k0 + l) <= bw;
+        const double a = ab[ok ? band_idx(row, k0 + l, bw) : 0];
+        t[rr] = ok ? a * v : 0.0;
+    }
+#pragma unroll
+    for (int rr = 0; rr < FWD_ROWS; rr++)
+        for (int o = 32; o > 0; o >>= 1) t[rr] += __shfl_down(t[rr], o);
+    if (l == 0) {
+#pragma unroll
+        for (int rr = 0; rr < FWD_ROWS; rr++)
+            if (row0 + rr < lim) b[row0 + rr] -= t[rr];
+    }
+}
+
+// backward substitution, block k0:  x_k = L11^-T y_k, then y[col] -= sum_r L[k0+r][col] x_k[r] for the
+// columns left of the block (thread per column: coalesced along the band rows)
+__global__ void __launch_bounds__(256) k_bwd(int bw, long long k0, int kb, const double* __restrict__ ab,
+                                             const double* __restrict__ linv, double* __restrict__ y,
+                                             double* __restrict__ x)
+{
+    __shared__ double Li[NB][NB + 1], yk[NB], xs[NB];
+    const int tid = threadIdx.x;
+    load_dense64(Li, linv, tid);
+    if (tid < NB) yk[tid] = (tid < kb) ? y[k0 + tid] : 0.0;
+    __syncthreads();
+    if (tid < NB) {
+        double v = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < NB; j++) v += Li[j][tid] * yk[j];     // (L^-1)^T
+        xs[tid] = v;
+        if (blockIdx.x == 0 && tid < kb) x[k0 + tid] = v;
+    }
+    __syncthreads();
+    const long long c_lo = (k0 > bw) ? k0 - bw : 0;
+    const long long col = c_lo + (long long)blockIdx.x * 256 + tid;
+    if (col < k0) {
+        double s = 0.0;
+        for (int r0 = 0; r0 < NB; r0 += 16) {
+            double a[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {     // sixteen independent loads in flight
+                const bool ok = r0 + r < kb && k0 + r0 + r - col <= bw;
+                a[r] = ab[ok ? band_idx(k0 + r0 + r, col, bw) : 0];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const bool ok = r0 + r < kb && k0 + r0 + r - col <= bw;
+                s += ok ? a[r] * xs[r0 + r] : 0.0;
+            }
+        }
+        y[col] -= s;
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+void BandCholesky::setup(fem_mat A_)
+{
+    A = A_; bs = A->bs;
+    const int nn = A->nbrows;
+    n = (long long)nn * bs;
+    FEM_CHECK(!(A->mesh->halo && A->mesh->halo->comm->size > 1), 9,
+              "pc lu: the direct solve is single-domain (use -ksp_type cg on partitioned meshes)");
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+
+    // node graph from the block structure, reverse Cuthill-McKee numbering
+    std::vector<int> hc((size_t)A->padded_blocks);
+    A->bcol.download(hc.data(), hc.size(), s);
+    FEM_HIP(hipStreamSynchronize(s));
+    std::vector<int> ptr(nn + 1, 0), adj;
+    for (int v = 0; v < nn; v++) ptr[v + 1] = ptr[v] + A->h_rowlen[v];
+    adj.resize((size_t)ptr[nn]);
+    for (int v = 0; v < nn; v++) {
+        const size_t o0 = (size_t)A->h_boff[v >> 6];
+        for (int j = 0; j < A->h_rowlen[v]; j++) adj[(size_t)ptr[v] + j] = hc[(o0 + j) * 64 + (v & 63)];
+    }
+    // numbering: the caller's own (structured meshes arrive well numbered) or reverse
+    // Cuthill-McKee, whichever gives the narrower band
+    std::vector<int> perm = rcm_order(nn, ptr, adj);
+    long long bwn = 0, bw_nat = 0;
+    for (int v = 0; v < nn; v++)
+        for (int e = ptr[v]; e < ptr[v + 1]; e++) {
+            bwn = std::max(bwn, (long long)std::abs(perm[v] - perm[adj[e]]));
+            bw_nat = std::max(bw_nat, (long long)std::abs(v - adj[e]));
+        }
+    if (bw_nat <= bwn) {
+        for (int v = 0; v < nn; v++) perm[v] = v;
+        bwn = bw_nat;
+    }
+    bw = (int)std::min<long long>(bwn * bs + bs - 1, n - 1);
+
+    size_t free_b = 0, total_b = 0;
+    FEM_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)n * (bw + 1) * sizeof(double);
+    FEM_CHECK(need < 0.8 * (double)free_b, 9,
+              "pc lu: the band of the factor needs " + std::to_string((long long)(need / 1048576.0)) +
+                  " MiB (n = " + std::to_string(n) + ", half bandwidth " + std::to_string(bw) +
+                  "), which does not fit the device: use -ksp_type cg");
+
+    DBuf<int> dperm((size_t)nn);
+    dperm.upload(perm.data(), perm.size(), s);
+    perm_dof.alloc((size_t)n);
+    hipLaunchKernelGGL(k_perm_dof, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, bs, dperm.p, perm_dof.p);
+    ab.alloc((size_t)n * (bw + 1));
+    ab.zero(s);
+    if (bs == 3)
+        hipLaunchKernelGGL(k_band_fill<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->val.p,
+                           A->rowlen.p, dperm.p, bw, ab.p);
+    else
+        hipLaunchKernelGGL(k_band_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->val.p,
+                           A->rowlen.p, dperm.p, bw, ab.p);
+    linv.alloc((size_t)((n + NB - 1) / NB) * NB * NB);
+    v0.alloc((size_t)n); v1.alloc((size_t)n); v2.alloc((size_t)n);
+    flag.alloc(1);
+    flag.zero(s);
+
+    for (long long k0 = 0; k0 < n; k0 += NB) {
+        const int kb = (int)std::min<long long>(NB, n - k0);
+        const int m = (int)(std::min<long long>(n, k0 + kb + bw) - (k0 + kb));
+        double* li = linv.p + (size_t)(k0 / NB) * NB * NB;
+        hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, s, bw, k0, kb, ab.p, li, flag.p);
+        if (m > 0) {
+            const int tiles = (m + NB - 1) / NB;
+            hipLaunchKernelGGL(k_trsm, dim3(tiles), dim3(256), 0, s, bw, k0, kb, m, ab.p, li);
+            hipLaunchKernelGGL(k_syrk, dim3(tiles * (tiles + 1) / 2), dim3(256), 0, s, bw, k0, kb, m, ab.p);
+        }
+    }
+    int hflag = 0;
+    flag.download(&hflag, 1, s);
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));   // dperm and the host staging go out of scope
+    failed = hflag != 0;
+}
+
+void BandCholesky::solve(const double* b, double* x)
+{
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const unsigned g = cdiv((size_t)n, 256);
+    hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);
+    for (long long k0 = 0; k0 < n; k0 += NB) {
+        const int kb = (int)std::min<long long>(NB, n - k0);
+        const int m = (int)(std::min<long long>(n, k0 + kb + bw) - (k0 + kb));
+        hipLaunchKernelGGL(k_fwd, dim3(std::max(1, (m + 4 * FWD_ROWS - 1) / (4 * FWD_ROWS))), dim3(256), 0, s, bw, k0, kb, m,
+                           ab.p, linv.p + (size_t)(k0 / NB) * NB * NB, v0.p, v1.p);
+    }
+    const long long nblk = (n + NB - 1) / NB;
+    for (long long kbk = nblk - 1; kbk >= 0; kbk--) {
+        const long long k0 = kbk * NB;
+        const int kb = (int)std::min<long long>(NB, n - k0);
+        const long long ncols = std::min<long long>(k0, bw);
+        hipLaunchKernelGGL(k_bwd, dim3((unsigned)std::max<long long>(1, (ncols + 255) / 256)), dim3(256), 0, s, bw, k0, kb, ab.p,
+                           linv.p + (size_t)(k0 / NB) * NB * NB, v1.p, v2.p);
+    }
+    hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, v2.p, x);
+    FEM_HIP(hipGetLastError());
+}
+
+}  // namespace fem

@@ -21,6 +21,7 @@
 #include <sstream>
 
 #include "comm.h"
+#include "direct.h"
 #include "mg.h"
 #include "objects.h"
 
@@ -275,6 +276,7 @@ struct fem_ksp_s {
     long long n = 0;
     DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
     std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
+    std::unique_ptr<fem::BandCholesky> direct;   // -ksp_type preonly -pc_type lu|cholesky
     bool mg_additive = false;
     double mg_box = 4.0;                     // level-1 box edge in mean node spacings
     double mg_alpha = -1.0, mg_omega = 0.7;  // alpha < 0: default (1.5 over-correction for the additive form, 1 for the V-cycle)
@@ -303,12 +305,16 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
     std::istringstream is(options ? options : "");
     std::string key, val;
     while (is >> key) {
-        if (key == "-ksp_type") { is >> val; FEM_CHECK(val == "cg", 6, "unsupported -ksp_type " + val + " (cg)"); k->type = val; }
+        if (key == "-ksp_type") {
+            is >> val;
+            FEM_CHECK(val == "cg" || val == "preonly", 6, "unsupported -ksp_type " + val + " (cg|preonly)");
+            k->type = val;
+        }
         else if (key == "-pc_type") {
             is >> val;
-            FEM_CHECK(val == "jacobi" || val == "none" || val == "mg" || val == "gamg", 6,
-                      "unsupported -pc_type " + val + " (jacobi|none|mg)");
-            k->pc = (val == "gamg") ? "mg" : val;
+            FEM_CHECK(val == "jacobi" || val == "none" || val == "mg" || val == "gamg" || val == "lu" || val == "cholesky", 6,
+                      "unsupported -pc_type " + val + " (jacobi|none|mg|lu|cholesky)");
+            k->pc = (val == "gamg") ? "mg" : (val == "cholesky") ? "lu" : val;
         }
         else if (key == "-pc_mg_type") {
             is >> val;
@@ -323,6 +329,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-ksp_divtol") { is >> k->dtol; }
         else if (key == "-ksp_max_it") { is >> k->maxit; }
         else if (key == "-ksp_norm_type") { is >> val; FEM_CHECK(val == "preconditioned", 6, "only -ksp_norm_type preconditioned"); }
+        else if (key == "-pc_factor_mat_solver_package" || key == "-pc_factor_mat_solver_type") { is >> val; }  // one built-in factorisation
         else if (key == "-f") { is >> val; }
         else throw Error(6, "fem_ksp_set_from_options: unknown option " + key);
         FEM_CHECK(!is.fail(), 6, "fem_ksp_set_from_options: bad value for " + key);
@@ -339,6 +346,20 @@ void ksp_set_up_impl(fem_ksp k)
     fem_mat A = k->A;
     k->n = (long long)A->nbrows * A->bs;
     const size_t n = (size_t)k->n;
+    // KSPPREONLY applies the preconditioner once: only meaningful with a factorisation, and a
+    // factorisation under CG would only hide its cost (src/main.F90:354-358 pairs them the same way)
+    const bool direct = k->pc == "lu";
+    FEM_CHECK((k->type == "preonly") == direct, 6,
+              "fem_ksp_set_up: -ksp_type " + k->type + " with -pc_type " + k->pc +
+                  " is not supported (cg with jacobi|none|mg, preonly with lu|cholesky)");
+    k->direct.reset();
+    if (direct) {
+        k->mg.reset();
+        k->direct.reset(new fem::BandCholesky);
+        k->direct->setup(A);
+        k->setup_done = true;
+        return;
+    }
     k->dinv.alloc(n); k->r.alloc(n); k->p.alloc(n); k->w.alloc(n);
     k->pzz.alloc(VGRID); k->pzr.alloc(VGRID);
     k->state.alloc(1);
@@ -378,6 +399,16 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     fem_ctx ctx = k->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
+    if (k->direct) {
+        // KSPSolve_PREONLY: x = PC(b), one "iteration", KSP_CONVERGED_ITS; a failed factorisation
+        // reports KSP_DIVERGED_PC_FAILED (PETSc raises "zero pivot" there)
+        k->direct->solve(b->d.p, x->d.p);
+        FEM_HIP(hipStreamSynchronize(s));
+        k->its = 1; k->rnorm = 0.0;
+        k->reason = k->direct->failed ? -11 : 4;
+        k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
+        return;
+    }
     fem_mat A = k->A;
     const size_t n = (size_t)k->n;
     const int pd = A->bs;
@@ -544,15 +575,16 @@ void ksp_delete(fem_ksp k) { delete k; }
 void ksp_set_operators(fem_ksp k, fem_mat A) { k->A = A; k->setup_done = false; }
 void ksp_set_type(fem_ksp k, const char* t)
 {
-    FEM_CHECK(t && std::string(t) == "cg", 6, std::string("fem_ksp_set_type: unsupported type ") + (t ? t : "(null)"));
-    k->type = t;
+    FEM_CHECK(t && (std::string(t) == "cg" || std::string(t) == "preonly"), 6,
+              std::string("fem_ksp_set_type: unsupported type ") + (t ? t : "(null)"));
+    k->type = t; k->setup_done = false;
 }
 void ksp_set_pc_type(fem_ksp k, const char* t)
 {
     const std::string v = t ? t : "";
-    FEM_CHECK(v == "jacobi" || v == "none" || v == "mg" || v == "gamg", 6,
+    FEM_CHECK(v == "jacobi" || v == "none" || v == "mg" || v == "gamg" || v == "lu" || v == "cholesky", 6,
               std::string("fem_ksp_set_pc_type: unsupported type ") + (t ? t : "(null)"));
-    k->pc = (v == "gamg") ? "mg" : v; k->setup_done = false;
+    k->pc = (v == "gamg") ? "mg" : (v == "cholesky") ? "lu" : v; k->setup_done = false;
 }
 void ksp_set_tolerances(fem_ksp k, double rtol, double abstol, double dtol, int maxit)
 {

@@ -160,13 +160,19 @@ int fem_form_rhs(fem_mesh mesh, int nbcs, const int *bcnode, const double *bcval
 int fem_ksp_create(fem_ctx ctx, fem_ksp *ksp);
 int fem_ksp_destroy(fem_ksp ksp);
 int fem_ksp_set_operators(fem_ksp ksp, fem_mat A);          /* KSPSetOperators :348 */
-int fem_ksp_set_type(fem_ksp ksp, const char *type);        /* "cg" */
-int fem_ksp_set_pc_type(fem_ksp ksp, const char *type);     /* "jacobi" | "none" */
+/* KSPSetType / PCSetType.  "cg" pairs with "jacobi" | "none" | "mg" ("gamg"); "preonly" pairs with
+ * "lu" | "cholesky" -- the reference's own production pairing KSPPREONLY + PCLU (MUMPS),
+ * src/main.F90:354-358 -- served here by a banded Cholesky factorisation on the device (single
+ * domain, decks whose band fits the HBM; its = 1, reason KSP_CONVERGED_ITS = 4, or
+ * KSP_DIVERGED_PC_FAILED = -11 when a pivot is not positive). */
+int fem_ksp_set_type(fem_ksp ksp, const char *type);
+int fem_ksp_set_pc_type(fem_ksp ksp, const char *type);
 /* KSPSetTolerances :350; FEM_DEFAULT_* keeps the PETSc default
  * (rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 10000). */
 int fem_ksp_set_tolerances(fem_ksp ksp, double rtol, double abstol, double dtol, int maxits);
-/* KSPSetFromOptions :377: parses "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-12
- * -ksp_atol .. -ksp_divtol .. -ksp_max_it .." */
+/* KSPSetFromOptions :377: parses "-ksp_type cg|preonly -pc_type jacobi|none|mg|gamg|lu|cholesky
+ * -ksp_rtol 1e-12 -ksp_atol .. -ksp_divtol .. -ksp_max_it .. -pc_mg_type multiplicative|additive
+ * -pc_mg_alpha .. -pc_mg_omega .. -pc_mg_box .." */
 int fem_ksp_set_from_options(fem_ksp ksp, const char *options);
 int fem_ksp_set_up(fem_ksp ksp);                            /* KSPSetUp :378 */
 int fem_ksp_solve(fem_ksp ksp, fem_vec b, fem_vec x);       /* KSPSolve :247 (zero initial guess) */
@@ -179,6 +185,10 @@ int fem_ksp_get_residual_history(fem_ksp ksp, double *hist, int len, int *n);
  * and their summed duration, total solve duration. */
 int fem_ksp_set_profiling(fem_ksp ksp, int on);
 int fem_ksp_get_profile(fem_ksp ksp, int *n_spmv, double *spmv_ms, double *solve_ms);
+
+/* Reverse Cuthill-McKee numbering used by the direct solve (host only): CSR adjacency of an
+ * undirected graph with n nodes -> perm[old] = new. */
+int fem_rcm_order(int n, const int *ptr, const int *adj, int *perm);
 
 /* ---- nodal stress: src/main.F90:253-292 -------------------------------------- */
 /* RecoverStress (src/m_global.F90:466) + RecoverNodalStress (:488) + valence

@@ -1,0 +1,101 @@
+"""GPU: direct solve behind the KSP surface, `-ksp_type preonly -pc_type lu` (the
+reference's own production pairing KSPPREONLY + PCLU, src/main.F90:354-358).  The oracle's dense
+LU of the same assembled system is the checker; larger decks are checked against the CG path."""
+import os
+
+import numpy as np
+import pytest
+
+from fem_amd import capi, driver
+from fem_amd.inp import read_inp
+from fem_amd.mesh import structured_hex, structured_quad, hex_to_tets, quad_to_mixed
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LU = "-ksp_type preonly -pc_type lu"
+
+
+def _small():
+    return {
+        "hex5_jitter": structured_hex(5, 4, 3, jitter=0.2),
+        "hex_67nodes_x": structured_hex(66, 2, 2, jitter=0.1),
+        "quad9_jitter": structured_quad(9, 7, jitter=0.2),
+        "quad_strip": structured_quad(60, 1, jitter=0.1),         # half bandwidth below one 64-column block
+        "tet": hex_to_tets(structured_hex(4, 3, 3, jitter=0.15)),
+        "mixed_tri_qua": quad_to_mixed(structured_quad(8, 5, jitter=0.1)),
+        "single_hex": structured_hex(1, 1, 1),
+    }
+
+
+@pytest.mark.parametrize("name", list(_small()))
+def test_direct_solve_matches_oracle_dense_lu(gpu_ctx, oracle, name):
+    m = _small()[name]
+    res = driver.run(m, LU, ctx=gpu_ctx)
+    u, s, _ = oracle.run(m, "lu")
+    assert res.reasons[-1] == 4 and res.its[-1] == 1          # KSP_CONVERGED_ITS after one application
+    # two factorisations of the same matrix agree to cond(K) * eps: the slender strip (a cantilever,
+    # cond ~ (L/h)^4) gets the looser bound
+    tol = 1e-8 if name == "quad_strip" else 1e-11
+    assert np.abs(res.aggregate_u - u).max() <= tol * np.abs(u).max()
+    assert np.abs(res.aggregate_stress - s).max() <= max(1e-9, 100 * tol) * np.abs(s).max()
+
+
+@pytest.mark.parametrize("deck", ["elastic_test.inp", "lin_two_quads_qs.inp"])
+def test_reference_decks_with_the_reference_solver_choice(gpu_ctx, oracle, deck):
+    """The reference's example decks, solved the way the reference solves them (factorisation,
+    every increment re-uses it)."""
+    m = read_inp(os.path.join(ROOT, "tests", "golden", "decks", deck))
+    res = driver.run(m, LU, ctx=gpu_ctx)
+    u, s, its = oracle.run(m, "lu")
+    assert len(res.its) == len(its) and all(r == 4 for r in res.reasons)
+    assert np.abs(res.aggregate_u - u).max() <= 1e-11 * np.abs(u).max()
+    assert np.abs(res.aggregate_stress - s).max() <= 1e-9 * max(np.abs(s).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name,mesh", [
+    ("quad200x150", lambda: structured_quad(200, 150, jitter=0.2)),   # 60k dofs, band ~ 300: many blocks, ragged tiles
+    ("hex20", lambda: structured_hex(20, 19, 18, jitter=0.2)),        # 25k dofs, band ~ 1.2k
+    ("tet12", lambda: hex_to_tets(structured_hex(12, 11, 10, jitter=0.15))),
+])
+def test_direct_solve_agrees_with_cg_on_larger_decks(gpu_ctx, name, mesh):
+    m = mesh()
+    d = driver.run(m, LU, ctx=gpu_ctx)
+    c = driver.run(m, "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-13", ctx=gpu_ctx)
+    assert d.reasons[-1] == 4 and c.reasons[-1] == 2
+    assert np.abs(d.aggregate_u - c.aggregate_u).max() <= 1e-9 * np.abs(c.aggregate_u).max()
+    assert np.abs(d.aggregate_stress - c.aggregate_stress).max() <= 1e-8 * np.abs(c.aggregate_stress).max()
+
+
+def test_direct_residual_and_cholesky_alias(gpu_ctx):
+    """||K x - b|| of the factorisation's answer, through MatMult of the same Mat."""
+    m = structured_hex(14, 9, 8, jitter=0.2)
+    prob = driver.Problem(gpu_ctx, m, "-ksp_type preonly -pc_type cholesky")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == 4 and prob.ksp.get_iteration_number() == 1
+    R = capi.Vec(gpu_ctx, m.ndof)
+    prob.K.mult(prob.U, R)
+    r = R.get_array() - prob.F.get_array()
+    b = prob.F.get_array()
+    # penalty rows carry 1e30 * u: compare per row against the row's own scale
+    diag = capi.Vec(gpu_ctx, m.ndof); prob.K.get_diagonal(diag)
+    scale = diag.get_array() * np.abs(prob.U.get_array()).max() + np.abs(b).max()
+    assert (np.abs(r) <= 1e-10 * scale).all()
+    # the same factor serves a second right-hand side
+    u1 = prob.U.get_array()
+    prob.ksp.solve(prob.F, prob.U)
+    assert np.array_equal(u1, prob.U.get_array())
+    for o in (R, diag):
+        o.destroy()
+    prob.destroy()
+
+
+def test_unsupported_pairings_fail_loudly(gpu_ctx):
+    m = structured_hex(3, 2, 2)
+    for opts in ("-ksp_type preonly -pc_type jacobi", "-ksp_type cg -pc_type lu", "-ksp_type preonly"):
+        prob = driver.Problem(gpu_ctx, m, opts)
+        prob.assemble()
+        with pytest.raises(capi.FemError):
+            prob.ksp.set_up()
+        prob.destroy()

@@ -208,3 +208,29 @@ def test_header_is_plain_c(tmp_path):
     if capi.device_count() == 0:
         p = subprocess.run([str(exe)], capture_output=True, text=True)
         assert p.returncode != 0 and "no HIP device" in p.stderr       # loud failure, no fallback
+
+
+def test_rcm_order_is_a_bandwidth_reducing_permutation():
+    """Host part of the direct solve (-pc_type lu): reverse Cuthill-McKee over a scrambled grid
+    graph with two components; the band must shrink to about the short grid edge."""
+    from fem_amd import capi
+    nx, ny = 30, 7
+    rng = np.random.default_rng(0)
+    n = 2 * nx * ny
+    ids = rng.permutation(n).reshape(2, nx, ny)
+    nbrs = [[] for _ in range(n)]
+    for c in range(2):
+        for i in range(nx):
+            for j in range(ny):
+                for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                    a, b = i + di, j + dj
+                    if 0 <= a < nx and 0 <= b < ny:
+                        nbrs[ids[c, i, j]].append(ids[c, a, b])
+    ptr = np.cumsum([0] + [len(x) for x in nbrs])
+    adj = np.concatenate(nbrs)
+    perm = capi.rcm_order(ptr, adj)
+    assert sorted(perm) == list(range(n))
+    band = max(abs(int(perm[v]) - int(perm[u])) for v in range(n) for u in nbrs[v])
+    assert band <= ny + 2
+    # a graph without edges keeps every node
+    assert sorted(capi.rcm_order([0, 0, 0, 0], [])) == [0, 1, 2]

@@ -10,6 +10,10 @@
 //   P     rigid-body modes of each box (translations + rotations about the box centre: 6 coarse
 //         dofs per box in 3-D, 3 in 2-D), zero on penalty dofs
 //   A_c   = P^T A P (Galerkin), exact dense inverse on the coarsest grid
+// Partitioned meshes: the boxes are cells of one grid over the global bounding box; the level-1
+// operator is the all-reduced sum of the domains' P_r^T K_r P_r, the whole box hierarchy is replicated
+// on every domain (identical arithmetic on identical data), each application all-reduces the level-1
+// residual once; restriction counts shared nodes at their owner, prolongation is local.
 //   cycle V(1,1), symmetric -> valid CG preconditioner; damped point Jacobi on the fine level, damped
 //         block Jacobi (one box = one block) on the box levels with omega = 4/(3*1.1*lambda_max estimate)
 #pragma once
@@ -37,6 +41,7 @@ struct Multigrid {
     DBuf<int> agg;                  // [nn] level-1 box of every node
     DBuf<int> box_ptr, box_nodes;   // level-1 box -> its nodes (ascending)
     DBuf<double> w;                 // [nn*bs] 1 on free dofs, 0 on penalty dofs
+    DBuf<double> wr;                // partitioned mesh: w on the nodes this domain owns, 0 on the other copies
     DBuf<double> dinv0, t0;         // fine-level Jacobi inverse diagonal, work vector
     DBuf<double> cinv;              // dense inverse of the coarsest operator
     DBuf<double> omega_l;           // [levels] smoother damping per box level (from an eigenvalue estimate) + scratch

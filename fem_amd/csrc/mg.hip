@@ -95,6 +95,26 @@ __global__ void __launch_bounds__(256) k_free_weights(size_t n, const double* __
     }
 }
 
+// restriction weights of a partitioned mesh: every shared node is counted by its owner only
+__global__ void __launch_bounds__(256) k_owner_weights(int nn, int bs, const double* __restrict__ w,
+                                                       const unsigned char* __restrict__ owned, double* __restrict__ wr)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    const double o = owned[v] ? 1.0 : 0.0;
+    for (int r = 0; r < bs; r++) wr[(size_t)v * bs + r] = o * w[(size_t)v * bs + r];
+}
+__global__ void __launch_bounds__(256) k_count_owned(int nn, const unsigned char* __restrict__ owned, double* __restrict__ out)
+{
+    __shared__ int sh[4];
+    int c = 0;
+    for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nn; v += gridDim.x * blockDim.x) c += owned[v] ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, (double)(sh[0] + sh[1] + sh[2] + sh[3]));   // integers: exact in any order
+}
+
 __device__ __forceinline__ bool neighbour_box(const Grid3& g, int b, int slot, int& out)
 {
     const int ix = b % g.nx, iy = (b / g.nx) % g.ny, iz = b / (g.nx * g.ny);
@@ -809,6 +829,10 @@ static void setup_t(Multigrid& mg)
     const int nn = mesh->nnds;
     const size_t ndof = (size_t)nn * BS;
     mg.cs = CS;
+    // partitioned mesh: the box grid is laid over the GLOBAL bounding box, so every domain sees the
+    // same boxes; the coarse hierarchy is replicated on every domain (see Multigrid::setup)
+    Halo* halo = mesh->halo.get();
+    Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
     // bounding box
     const int pg = 256;
     DBuf<double> dbb((size_t)pg * 6);
@@ -819,9 +843,28 @@ static void setup_t(Multigrid& mg)
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int b = 0; b < pg; b++)
         for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], hbb[b * 6 + d]); hi[d] = std::max(hi[d], hbb[b * 6 + 3 + d]); }
+    double nn_global = nn;
+    if (comm) {
+        // min / max / node count over the domains through the one collective there is: every domain
+        // fills its own slot of a zeroed table, the sum of the tables is the table of all domains
+        const int nr = comm->size;
+        std::vector<double> tab((size_t)nr * 7, 0.0);
+        DBuf<double> dtab(tab.size());
+        for (int d = 0; d < 3; d++) { tab[(size_t)comm->rank * 7 + d] = lo[d]; tab[(size_t)comm->rank * 7 + 3 + d] = hi[d]; }
+        dtab.upload(tab.data(), tab.size(), s);
+        hipLaunchKernelGGL(k_count_owned, dim3(64), dim3(256), 0, s, nn, halo->owned.p, dtab.p + (size_t)comm->rank * 7 + 6);
+        comm->allreduce_sum(dtab.p, (int)tab.size(), s);
+        dtab.download(tab.data(), tab.size(), s);
+        FEM_HIP(hipStreamSynchronize(s));
+        nn_global = 0.0;
+        for (int r = 0; r < nr; r++) {
+            for (int d = 0; d < PD; d++) { lo[d] = std::min(lo[d], tab[(size_t)r * 7 + d]); hi[d] = std::max(hi[d], tab[(size_t)r * 7 + 3 + d]); }
+            nn_global += tab[(size_t)r * 7 + 6];
+        }
+    }
     double vol = 1.0;
     for (int d = 0; d < PD; d++) vol *= std::max(hi[d] - lo[d], 1e-300);
-    const double hnode = std::pow(vol / std::max(nn, 1), 1.0 / PD);  // mean node spacing
+    const double hnode = std::pow(vol / std::max(nn_global, 1.0), 1.0 / PD);  // mean node spacing
     const double H = mg.box * hnode;                                 // ~4 nodes per box edge by default
     Grid3 g{1, 1, 1};
     int* gd[3] = {&g.nx, &g.ny, &g.nz};
@@ -845,7 +888,12 @@ static void setup_t(Multigrid& mg)
     // free-dof weights and fine Jacobi diagonal
     mg.w.alloc(ndof); mg.dinv0.alloc(ndof); mg.t0.alloc(ndof);
     mat_get_diagonal_raw(A, mg.t0.p);
+    halo_sum(mesh, mg.t0.p, BS, BS, 1);   // assembled diagonal: the penalty sits on the owner's copy only
     hipLaunchKernelGGL(k_free_weights, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.t0.p, mg.w.p, mg.dinv0.p);
+    if (comm) {
+        mg.wr.alloc(ndof);
+        hipLaunchKernelGGL(k_owner_weights, dim3(g1(nn)), dim3(256), 0, s, nn, BS, mg.w.p, halo->owned.p, mg.wr.p);
+    }
 
     DBuf<int> err(1);
     err.zero(s);
@@ -865,6 +913,25 @@ static void setup_t(Multigrid& mg)
     hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, geom_of(mg.lev[0]),
                        mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->val.p,
                        mg.w.p, mg.lev[0].st.p, err.p);
+    if (comm) {
+        // A_1 = sum over the domains of P_r^T K_r P_r (sub-assembled matrices, same P on shared nodes);
+        // the flag travels along so that every domain raises the same error
+        FEM_CHECK((size_t)27 * CS * CS * nb < (size_t)1 << 31, 9, "pc mg: level-1 operator too large for one all-reduce");
+        comm->allreduce_sum(mg.lev[0].st.p, 27 * CS * CS * nb, s);
+        DBuf<double> derr(1);
+        int herr0 = 0;
+        err.download(&herr0, 1, s);
+        FEM_HIP(hipStreamSynchronize(s));
+        const double e0 = herr0 ? 1.0 : 0.0;
+        derr.upload(&e0, 1, s);
+        comm->allreduce_sum(derr.p, 1, s);
+        double e1 = 0.0;
+        derr.download(&e1, 1, s);
+        FEM_HIP(hipStreamSynchronize(s));
+        const int any = e1 > 0.0 ? 1 : 0;
+        err.upload(&any, 1, s);
+        FEM_HIP(hipStreamSynchronize(s));
+    }
     hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(nb)), dim3(256), 0, s, nb, mg.lev[0].st.p, mg.lev[0].dinv.p);
     // coarser levels: merge 2x2x2 boxes until the grid is at most 5 boxes per direction
     // (<= 750 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
@@ -974,13 +1041,23 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     const Grid3 g = grid_of(L1);
     const BoxGeom geo = geom_of(L1);
     const double* coords = A->mesh->coords.p;
+    Halo* halo = A->mesh->halo.get();
+    Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
+    // partitioned mesh: r and z are consistent on every copy of a shared node; the restriction counts
+    // each node once (owner weights), one all-reduce makes the level-1 residual global, the coarse
+    // cycle then runs replicated and the prolongation is local again
+    const double* wr = comm ? mg.wr.p : mg.w.p;
+    auto restrict_to_level1 = [&](const double* kz) {
+        hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
+                           mg.box_ptr.p, mg.box_nodes.p, wr, r, kz, L1.r.p);
+        if (comm) comm->allreduce_sum(L1.r.p, L1.nb * CS, s);
+    };
     if (mg.fine_additive) {
         // fine level additive (Jacobi + coarse-grid correction of the un-smoothed residual): the
         // preconditioner costs no fine-level product; the coarse hierarchy is still a V-cycle
-        hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
-                           mg.box_ptr.p, mg.box_nodes.p, mg.w.p, r, (const double*)nullptr, L1.r.p);
+        restrict_to_level1(nullptr);
         cycle_t<CS>(mg, 0);
-        if (pzz) {   // the caller wants z.z and z.r as well: one fused pass
+        if (pzz) {   // the caller wants z.z and z.r as well: one fused pass (single domain)
             hipLaunchKernelGGL((k_additive_finish<BS, CS, PD>), dim3(npart), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
                                mg.agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done);
         } else {
@@ -992,19 +1069,19 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     }
     hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
-    hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
-                       mg.box_ptr.p, mg.box_nodes.p, mg.w.p, r, mg.t0.p, L1.r.p);
+    halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
+    restrict_to_level1(mg.t0.p);
     cycle_t<CS>(mg, 0);
     hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.agg.p,
                        mg.w.p, L1.x.p, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
+    halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
     hipLaunchKernelGGL(k_fine_post, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, mg.t0.p, z);
 }
 
 void Multigrid::setup(fem_mat A_)
 {
     A = A_; bs = A->bs; nn = A->nbrows;
-    FEM_CHECK(!(A->mesh->halo && A->mesh->halo->comm->size > 1), 9, "pc mg: multi-domain runs are not supported yet");
     A->ctx->bind();
     if (bs == 3) setup_t<3, 3>(*this); else setup_t<2, 2>(*this);
 }
@@ -1018,7 +1095,7 @@ bool Multigrid::fuses_dots() const { return fine_additive; }
 
 size_t Multigrid::device_bytes() const
 {
-    size_t b = omega_l.bytes() + agg.bytes() + box_ptr.bytes() + box_nodes.bytes() + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
+    size_t b = omega_l.bytes() + wr.bytes() + agg.bytes() + box_ptr.bytes() + box_nodes.bytes() + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
     for (auto& L : lev) b += L.st.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes();
     return b;
 }

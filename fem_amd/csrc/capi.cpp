@@ -106,6 +106,7 @@ int fem_ctx_destroy(fem_ctx c)
     (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
     (void)hipStreamDestroy(c->stream);
     delete c;
+    pool_trim();   // cached device blocks go back to the driver with the context
     FEM_CATCH
 }
 

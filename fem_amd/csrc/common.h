@@ -38,6 +38,17 @@ void set_last_error(const std::string& m);
         if (!(cond)) throw ::fem::Error((code), (msg));   \
     } while (0)
 
+// Device-memory pool behind DBuf (pool.cpp).  The path re-creates its large objects every run
+// (Mat_K: 7 GB at config 3, the symbolic-phase scratch, the multigrid hierarchy); going to the
+// driver for each of them costs from a few to >100 ms per step depending on the machine.  Released
+// blocks are kept by exact size (after a device synchronisation, which is what hipFree does
+// implicitly) and handed out again; the cache is bounded (FEM_AMD_POOL_MAX_GB, default 96) and is
+// emptied when an allocation fails and when a context is destroyed.
+void* pool_alloc(size_t bytes);
+void pool_release(void* p, size_t bytes) noexcept;
+void pool_trim() noexcept;      // give every cached block of the current device back to the driver
+size_t pool_cached_bytes();
+
 // device buffer (owned)
 template <typename T>
 struct DBuf {
@@ -56,10 +67,10 @@ struct DBuf {
     void alloc(size_t n_) {
         release();
         n = n_;
-        if (n) FEM_HIP(hipMalloc((void**)&p, n * sizeof(T)));
+        if (n) p = static_cast<T*>(pool_alloc(n * sizeof(T)));
     }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) pool_release(p, n * sizeof(T));
         p = nullptr; n = 0;
     }
     size_t bytes() const { return n * sizeof(T); }

@@ -447,6 +447,7 @@ void BandCholesky::setup(fem_mat A_)
     bw = (int)std::min<long long>(bwn * bs + bs - 1, n - 1);
 
     size_t free_b = 0, total_b = 0;
+    pool_trim();                      // cached blocks count as free memory for this decision
     FEM_HIP(hipMemGetInfo(&free_b, &total_b));
     const double need = (double)n * (bw + 1) * sizeof(double);
     FEM_CHECK(need < 0.8 * (double)free_b, 9,

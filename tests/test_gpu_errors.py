@@ -46,7 +46,7 @@ def test_vector_and_solver_misuse(gpu_ctx):
     with pytest.raises(capi.FemError, match="unsupported"):
         ksp.set_type("gmres")
     with pytest.raises(capi.FemError, match="unsupported"):
-        ksp.set_pc_type("lu")
+        ksp.set_pc_type("ilu")
     with pytest.raises(capi.FemError, match="unknown option"):
         ksp.set_from_options("-ksp_foo 3")
     with pytest.raises(capi.FemError, match="bad value"):

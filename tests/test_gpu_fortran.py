@@ -63,6 +63,21 @@ def test_fortran_driver_mixed_deck_matches_oracle(tmp_path, oracle):
     assert np.abs(full[:, 2:] - so).max() <= 1e-9 * np.abs(so).max()
 
 
+def test_fortran_driver_with_the_reference_solver_options(tmp_path, oracle):
+    """`-ksp_type preonly -pc_type lu` (what src/main.F90:355-358 selects) through the Fortran driver:
+    ten increments re-use one factorisation and give the golden numbers of the elastic deck."""
+    _need(EXE)
+    deck = os.path.join(ROOT, "tests", "golden", "decks", "elastic_test.inp")
+    p = subprocess.run([EXE, "-f", deck, "-ksp_type", "preonly", "-pc_type", "lu", "-o", str(tmp_path / "0_output")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("Interval:") == 10 and "Finished" in p.stdout
+    full = np.loadtxt(tmp_path / "0_output_000000.full.txt", skiprows=1)
+    expect_u = np.array([[0, .1], [0, .05], [0, 0], [0, .1], [0, .05], [0, 0]])
+    assert np.abs(full[:, :2] - expect_u).max() < 1e-12
+    assert np.abs(full[:, 2:] - np.array([105.0, 245.0, 0.0])).max() < 1e-9
+
+
 def test_plain_c_client_of_the_abi(tmp_path):
     """include/fem_amd.h consumed by gcc as C99 (no C++ types leak through the boundary)."""
     exe = tmp_path / "abi_smoke"

@@ -818,8 +818,9 @@ static unsigned gs(size_t n) { return std::min<unsigned>(std::max(1u, cdiv(n, 25
 static Grid3 grid_of(const MgLevel& L) { return Grid3{L.nx, L.ny, L.nz}; }
 static BoxGeom geom_of(const MgLevel& L) { return BoxGeom{{L.lo[0], L.lo[1], L.lo[2]}, L.H}; }
 
+// returns false when the box grid is too fine for the mesh (an element spans more than two boxes)
 template <int BS, int PD>
-static void setup_t(Multigrid& mg)
+static bool setup_t(Multigrid& mg)
 {
     constexpr int CS = CoarseDofs<BS>::value;
     fem_mat A = mg.A;
@@ -932,6 +933,12 @@ static void setup_t(Multigrid& mg)
         err.upload(&any, 1, s);
         FEM_HIP(hipStreamSynchronize(s));
     }
+    {
+        int herr = 0;
+        err.download(&herr, 1, s);
+        FEM_HIP(hipStreamSynchronize(s));
+        if (herr) return false;
+    }
     hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(nb)), dim3(256), 0, s, nb, mg.lev[0].st.p, mg.lev[0].dinv.p);
     // coarser levels: merge 2x2x2 boxes until the grid is at most 5 boxes per direction
     // (<= 750 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
@@ -981,11 +988,8 @@ static void setup_t(Multigrid& mg)
         }
         FEM_HIP(hipStreamSynchronize(s));   // rowk/colk go out of scope
     }
-    int herr = 0;
-    err.download(&herr, 1, s);
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
-    FEM_CHECK(!herr, 9, "pc mg: an element spans more than two boxes of the aggregation grid (mesh too graded)");
     if (getenv("FEM_AMD_MG_VERBOSE")) {
         std::vector<double> om(mg.lev.size() + 2);
         mg.omega_l.download(om.data(), om.size(), s);
@@ -995,6 +999,7 @@ static void setup_t(Multigrid& mg)
                     mg.lev[l].ny, mg.lev[l].nz, CS, mg.lev[l].H,
                     (l + 1 < mg.lev.size()) ? (", omega = " + std::to_string(om[l])).c_str() : ", dense inverse");
     }
+    return true;
 }
 
 template <int CS>
@@ -1083,7 +1088,16 @@ void Multigrid::setup(fem_mat A_)
 {
     A = A_; bs = A->bs; nn = A->nbrows;
     A->ctx->bind();
-    if (bs == 3) setup_t<3, 3>(*this); else setup_t<2, 2>(*this);
+    // graded meshes: where the largest element spans more than two boxes the grid is coarsened
+    // (box edge x1.5) until every element fits; all domains of a partitioned mesh take the same decision
+    for (int attempt = 0;; attempt++) {
+        const bool ok = (bs == 3) ? setup_t<3, 3>(*this) : setup_t<2, 2>(*this);
+        if (ok) break;
+        FEM_CHECK(attempt < 6 && box < 64.0, 9,
+                  "pc mg: an element spans more than two boxes of the aggregation grid even with boxes of " +
+                      std::to_string(box) + " mean node spacings (mesh too graded)");
+        box *= 1.5;
+    }
 }
 
 void Multigrid::apply(const double* r, double* z, const int* done, double* pzz, double* pzr, int npart)

@@ -3,7 +3,7 @@ silent fallback) and degenerate inputs (empty element list, isolated nodes, ragg
 import numpy as np
 import pytest
 
-from fem_amd import capi
+from fem_amd import capi, driver
 from fem_amd.mesh import Mesh, TRI, QUA, structured_quad
 
 pytestmark = pytest.mark.gpu
@@ -107,3 +107,30 @@ def test_degenerate_meshes(gpu_ctx, oracle):
     with pytest.raises(capi.FemError, match="neighbour nodes"):
         capi.Mat(dm)
     dm.destroy()
+
+
+def test_device_pool_reuses_blocks_and_context_destroy_returns_them():
+    """Re-creating the matrix must not grow the device footprint (released blocks are handed out
+    again), and destroying the context gives the cache back to the driver."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def used():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return total.value - free.value
+
+    ctx = capi.Context(0)
+    from fem_amd.mesh import structured_hex
+    m = structured_hex(40)
+    prob = driver.Problem(ctx, m, "-pc_type jacobi")
+    prob.assemble(); prob.ksp.set_up(); ctx.synchronize()
+    base = used()
+    for _ in range(3):
+        prob.K.destroy(); prob.K = None
+        prob.assemble(); prob.ksp.set_up(); ctx.synchronize()
+        assert used() <= base + (64 << 20)
+    prob.destroy()
+    held = used()
+    ctx.destroy()
+    assert used() < held - (100 << 20)      # the 140 MB matrix blocks went back

@@ -92,3 +92,21 @@ def test_mg_on_a_partitioned_mesh(oracle, world, npr, mgtype):
             common, ir, iq = np.intersect1d(out[r][5], out[q][5], return_indices=True)
             if common.size:
                 assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])
+
+
+def test_mg_coarsens_its_boxes_on_a_graded_mesh(gpu_ctx, oracle, monkeypatch, capfd):
+    """Geometric grading 1:1000 along x: the largest element is wider than the default box (4 mean node
+    spacings), so it would span three boxes; set-up must coarsen the grid by itself and still converge
+    to the oracle's solution."""
+    m = structured_hex(24, 6, 6)
+    x = m.coords[:, 0] / m.coords[:, 0].max()
+    m.coords[:, 0] = 24.0 * (np.exp(7.0 * x) - 1.0) / (np.exp(7.0) - 1.0)
+    monkeypatch.setenv("FEM_AMD_MG_VERBOSE", "1")
+    res = driver.run(m, "-pc_type mg -pc_mg_type additive -ksp_rtol 1e-12", ctx=gpu_ctx)
+    log = capfd.readouterr().err
+    H = float(log.split("level 1:")[1].split("H = ")[1].split(",")[0])
+    hnode = (24.0 * 6 * 6 / m.nnds) ** (1 / 3)
+    assert H >= 1.4 * 4 * hnode                       # at least one coarsening step was taken
+    u, s, _ = oracle.run(m, "cg", rtol=1e-13)
+    assert res.reasons[-1] == 2
+    assert np.abs(res.aggregate_u - u).max() <= 1e-9 * np.abs(u).max()

@@ -98,6 +98,7 @@ _SIGS = {
     "fem_comm_create_local_group": [C.c_int, C.POINTER(_h), C.POINTER(_h)],
     "fem_comm_destroy": [_h],
     "fem_comm_rank": [_h, _ip, _ip],
+    "fem_comm_exchange": [_h, C.c_int, _ip, C.POINTER(C.c_longlong), _h, _h],
 }
 EXPORTED = sorted(_SIGS) + ["fem_last_error"]
 for _n, _a in _SIGS.items():
@@ -254,6 +255,12 @@ class Comm:
         out = (_h * n)()
         _ck(_lib.fem_comm_create_local_group(n, ca, out))
         return [Comm(_h(out[i])) for i in range(n)]
+
+    def exchange(self, neigh_rank, off, send: "Vec", recv: "Vec"):
+        """Neighbour i gets send[off[i]:off[i+1]]; recv[off[i]:off[i+1]] is filled from neighbour i."""
+        nr = _i32(neigh_rank)
+        o = np.ascontiguousarray(off, dtype=np.int64)
+        _ck(_lib.fem_comm_exchange(self.h, len(nr), _i(nr), o.ctypes.data_as(C.POINTER(C.c_longlong)), send.h, recv.h))
 
     def rank_size(self):
         r, s = C.c_int(0), C.c_int(0)

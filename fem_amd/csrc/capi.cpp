@@ -608,4 +608,23 @@ int fem_comm_rank(fem_comm c, int* rank, int* size)
     FEM_CATCH
 }
 
+int fem_comm_exchange(fem_comm c, int nneigh, const int* neigh_rank, const long long* off, fem_vec send, fem_vec recv)
+{
+    FEM_TRY
+    FEM_CHECK(c && c->impl && send && recv, 1, "fem_comm_exchange: null handle");
+    FEM_CHECK(nneigh >= 0 && (nneigh == 0 || (neigh_rank && off)), 2, "fem_comm_exchange: bad neighbour list");
+    std::vector<size_t> o((size_t)nneigh + 1, 0);
+    for (int i = 0; i <= nneigh && nneigh > 0; i++) {
+        FEM_CHECK(off[i] >= 0 && (i == 0 || off[i] >= off[i - 1]), 2, "fem_comm_exchange: offsets must ascend");
+        o[i] = (size_t)off[i];
+    }
+    FEM_CHECK((long long)o[nneigh] <= send->n && (long long)o[nneigh] <= recv->n, 8, "fem_comm_exchange: vectors too short");
+    for (int i = 0; i < nneigh; i++)
+        FEM_CHECK(neigh_rank[i] >= 0 && neigh_rank[i] < c->impl->size, 3, "fem_comm_exchange: bad neighbour rank");
+    send->ctx->bind();
+    c->impl->exchange(nneigh, neigh_rank, o.data(), send->d.p, recv->d.p, send->ctx->stream);
+    FEM_HIP(hipStreamSynchronize(send->ctx->stream));
+    FEM_CATCH
+}
+
 }  // extern "C"

@@ -209,6 +209,11 @@ int fem_comm_create_rccl(fem_ctx ctx, int nranks, int rank, const char unique_id
 int fem_comm_create_local_group(int n, const fem_ctx *ctxs, fem_comm *comms);
 int fem_comm_destroy(fem_comm comm);
 int fem_comm_rank(fem_comm comm, int *rank, int *size);
+/* The neighbour exchange the halo sums are built on (replaces the MPI_Send/MPI_Recv pairs of
+ * src/m_io.F90:150-237 and PETSc's VecScatter): neighbour i receives send[off[i]..off[i+1]) and the
+ * same range of recv is filled from it; one grouped ncclSend/ncclRecv per call on the RCCL back end.
+ * Blocking (returns when recv is complete). */
+int fem_comm_exchange(fem_comm comm, int nneigh, const int *neigh_rank, const long long *off, fem_vec send, fem_vec recv);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,69 @@ print("RCCL_OK")
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
+def test_rccl_send_recv_primitive_on_one_rank():
+    """ncclSend / ncclRecv as the halo exchange issues them (one group, fp64 counts, the solve's
+    stream), here between rank 0 and itself -- the only peer a 1-GPU box has.  Two "neighbours" (both
+    rank 0) with different segment lengths check offsets and the group semantics."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from fem_amd import capi
+ctx = capi.Context(0)
+comm = capi.Comm.rccl(ctx, 1, 0, capi.Comm.unique_id())
+n = 1000
+send, recv = capi.Vec(ctx, n), capi.Vec(ctx, n)
+x = np.arange(n, dtype=np.float64) * 0.5 + 1.0
+send.set_array(x); recv.set_array(np.zeros(n))
+comm.exchange([0], [0, 700], send, recv)
+got = recv.get_array()
+assert np.array_equal(got[:700], x[:700]) and not got[700:].any(), got[:8]
+send.destroy(); recv.destroy(); comm.destroy(); ctx.destroy()
+print("SENDRECV_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "SENDRECV_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
+def test_exchange_primitive_local_group():
+    """The same primitive through the in-process communicator: three domains, everybody a neighbour of
+    everybody; domain r must receive, in its segment for q, what q put into its segment for r."""
+    world, seg = 3, 6
+    ctxs = [capi.Context(0) for _ in range(world)]
+    comms = capi.Comm.local_group(ctxs)
+    out, err = [None] * world, []
+    nbs = [[q for q in range(world) if q != r] for r in range(world)]
+
+    def work(r):
+        try:
+            send, recv = capi.Vec(ctxs[r], 2 * seg), capi.Vec(ctxs[r], 2 * seg)
+            send.set_array(100.0 * r + np.arange(2 * seg)); recv.set_array(np.zeros(2 * seg))
+            comms[r].exchange(nbs[r], [0, seg, 2 * seg], send, recv)
+            out[r] = recv.get_array()
+            send.destroy(); recv.destroy()
+        except Exception as e:  # noqa: BLE001
+            err.append((r, repr(e)))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not err, err
+    for r in range(world):
+        for i, q in enumerate(nbs[r]):
+            j = nbs[q].index(r)
+            assert np.array_equal(out[r][i * seg:(i + 1) * seg], 100.0 * q + np.arange(j * seg, (j + 1) * seg))
+    for c in comms:
+        c.destroy()
+    for c in ctxs:
+        c.destroy()
+
+
 def _unstructured_case(kind):
     """A deck-like mesh with every load type: clamped edge, nodal forces over a time window, tractions."""
     from fem_amd.mesh import hex_to_tets, quad_to_mixed, structured_quad

@@ -28,7 +28,7 @@ struct MgLevel {
     double lo[3] = {0, 0, 0}, H = 1.0;   // box b = (ix,iy,iz) has its centre at lo + (idx + 0.5) * H
     DBuf<double> st;    // [27][cs*cs][nb]  stencil entries, box index fastest
     DBuf<double> dinv;  // [cs*cs][nb]  inverse of the diagonal block of every box (block-Jacobi smoother)
-    DBuf<double> x, r, t, xn;
+    DBuf<double> x, r, t;   // [nb*cs] iterate, right-hand side, residual
 };
 
 struct Multigrid {

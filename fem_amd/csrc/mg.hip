@@ -156,23 +156,6 @@ __device__ __forceinline__ void rbm_apply_t(const double (&d)[3], const double (
         out[2] = d[0] * f[1] - d[1] * f[0];
     }
 }
-// explicit P_d (BS x CS), row-major
-template <int BS, int CS>
-__device__ __forceinline__ void rbm_matrix(const double (&d)[3], double (&P)[BS * CS])
-{
-#pragma unroll
-    for (int k = 0; k < BS * CS; k++) P[k] = 0.0;
-#pragma unroll
-    for (int r = 0; r < BS; r++) P[r * CS + r] = 1.0;
-    if constexpr (BS == 3) {
-        P[0 * CS + 4] = d[2];  P[0 * CS + 5] = -d[1];
-        P[1 * CS + 3] = -d[2]; P[1 * CS + 5] = d[0];
-        P[2 * CS + 3] = d[1];  P[2 * CS + 4] = -d[0];
-    } else {
-        P[0 * CS + 2] = -d[1];
-        P[1 * CS + 2] = d[0];
-    }
-}
 // box -> parent box: child dofs (u, theta) = T * parent dofs (U, Theta),  T = [I, R(d); 0, I]
 template <int CS>
 __device__ __forceinline__ void box_apply(const double (&d)[3], const double* X, double (&x)[CS])

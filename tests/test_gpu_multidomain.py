@@ -57,7 +57,7 @@ def _run_domains(world, npr, jitter, options):
     return grid, out
 
 
-@pytest.mark.parametrize("world,npr", [(2, (5, 4, 3)), (4, (3, 3, 4)), (6, (2, 3, 3))])
+@pytest.mark.parametrize("world,npr", [(2, (5, 4, 3)), (4, (3, 3, 4)), (6, (2, 3, 3)), (8, (3, 2, 3))])   # 8 = 2x2x2: the layout of config 4
 def test_multidomain_matches_serial_oracle(oracle, world, npr):
     grid, out = _run_domains(world, npr, 0.15, "-ksp_rtol 1e-13")
     gn = tuple(grid[d] * npr[d] for d in range(3))

@@ -34,7 +34,8 @@ struct MgLevel {
 struct Multigrid {
     fem_mat A = nullptr;
     int bs = 0, cs = 0, nn = 0;      // fine block size; coarse dofs per box (rigid-body modes: 3 in 2-D, 6 in 3-D)
-    double omega = 0.7, alpha = 1.5;   // fine-level Jacobi damping (V-cycle form); scaling of the coarse correction
+    double omega = 0.7, alpha = 1.5;   // upper bound of the fine-level Jacobi damping (V-cycle form); scaling of the coarse correction
+    double omega_fine = 0.7, lambda_fine = 0.0;   // damping actually used: min(omega, 1.6 / lambda_max estimate)
     double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)

@@ -957,6 +957,30 @@ static bool setup_t(Multigrid& mg)
         hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2 + 1);
         hipLaunchKernelGGL(k_set_omega, dim3(1), dim3(1), 0, s, n2, mg.omega_l.p + l);
     }
+    // fine level of the V-cycle form: point Jacobi must stay below 2 / lambda_max(D^-1 K) or the cycle
+    // is indefinite (materials with nu -> 0.5, distorted elements and stiffness jumps push lambda_max
+    // beyond 3); same power iteration, the norms are all-reduced so that every domain takes the
+    // same damping.  The additive form needs no damping (a sum of positive definite terms).
+    mg.omega_fine = mg.omega;
+    if (!mg.fine_additive) {
+        DBuf<double> xv(ndof), n2(2);
+        hipLaunchKernelGGL(k_hash_fill, dim3(gs(ndof)), dim3(256), 0, s, ndof, xv.p);
+        const int npow = 10;
+        for (int it = 0; it < npow; it++) {
+            if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, ndof, xv.p, n2.p);
+            mat_mult_raw(A, xv.p, mg.t0.p, nullptr, nullptr);
+            halo_sum(mesh, mg.t0.p, BS, BS, 1);
+            hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, 1.0, mg.dinv0.p, mg.t0.p, xv.p);
+        }
+        hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, ndof, xv.p, n2.p + 1);
+        if (comm) comm->allreduce_sum(n2.p, 2, s);
+        double h2[2] = {0.0, 0.0};
+        n2.download(h2, 2, s);
+        FEM_HIP(hipStreamSynchronize(s));
+        const double lam = (h2[0] > 0.0 && h2[1] > 0.0) ? std::sqrt(h2[1] / h2[0]) : 2.5;
+        mg.lambda_fine = lam;
+        mg.omega_fine = std::min(mg.omega, 1.6 / std::max(lam, 1.0));   // 20 % below the stability bound
+    }
     // coarsest: dense inverse
     mg.ncoarse = g.nb() * CS;
     mg.cinv.alloc((size_t)mg.ncoarse * 2 * mg.ncoarse);
@@ -977,6 +1001,8 @@ static bool setup_t(Multigrid& mg)
         std::vector<double> om(mg.lev.size() + 2);
         mg.omega_l.download(om.data(), om.size(), s);
         FEM_HIP(hipStreamSynchronize(s));
+        if (!mg.fine_additive)
+            fprintf(stderr, "[fem_amd mg] fine level: lambda_max(D^-1 K) ~ %g, omega = %g\n", mg.lambda_fine, mg.omega_fine);
         for (size_t l = 0; l < mg.lev.size(); l++)
             fprintf(stderr, "[fem_amd mg] level %zu: %d x %d x %d boxes, %d dofs/box, H = %g%s\n", l + 1, mg.lev[l].nx,
                     mg.lev[l].ny, mg.lev[l].nz, CS, mg.lev[l].H,
@@ -1055,7 +1081,7 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
         }
         return;
     }
-    hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, z);
+    hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega_fine, mg.dinv0.p, r, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
     halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
     restrict_to_level1(mg.t0.p);
@@ -1064,7 +1090,7 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
                        mg.w.p, L1.x.p, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
     halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
-    hipLaunchKernelGGL(k_fine_post, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega, mg.dinv0.p, r, mg.t0.p, z);
+    hipLaunchKernelGGL(k_fine_post, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega_fine, mg.dinv0.p, r, mg.t0.p, z);
 }
 
 void Multigrid::setup(fem_mat A_)

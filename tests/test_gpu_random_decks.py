@@ -1,0 +1,83 @@
+"""GPU: seeded random decks against the oracle -- element mixes, scrambled node numbering, several
+materials, partial Dirichlet flags with non-zero values, nodal forces with time windows, tractions,
+several increments -- through every solver option of the KSP surface.  Each deck is small enough for
+the oracle's dense LU, so the comparison does not depend on an iteration tolerance."""
+import numpy as np
+import pytest
+
+from fem_amd import driver
+from fem_amd.mesh import Mesh, structured_hex, structured_quad, hex_to_tets, quad_to_mixed
+
+pytestmark = pytest.mark.gpu
+
+SOLVERS = ["-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14",
+           "-ksp_type cg -pc_type mg -pc_mg_type additive -ksp_rtol 1e-14",
+           "-ksp_type cg -pc_type mg -ksp_rtol 1e-14",
+           "-ksp_type preonly -pc_type lu"]
+
+
+def random_deck(seed: int) -> Mesh:
+    rng = np.random.default_rng(seed)
+    kind = ["quad", "mixed", "hex", "tet"][seed % 4]
+    if kind in ("quad", "mixed"):
+        base = structured_quad(int(rng.integers(3, 9)), int(rng.integers(3, 8)), jitter=float(rng.uniform(0, 0.25)))
+        if kind == "mixed":
+            base = quad_to_mixed(base)
+    else:
+        base = structured_hex(int(rng.integers(2, 6)), int(rng.integers(2, 5)), int(rng.integers(2, 5)),
+                              jitter=float(rng.uniform(0, 0.2)))
+        if kind == "tet":
+            base = hex_to_tets(base)
+    pd, nn = base.pdim, base.nnds
+    # scramble the node numbering (decks written by mesh generators are not lexicographic)
+    perm = rng.permutation(nn)                      # new id of old node
+    coords = np.empty_like(base.coords); coords[perm] = base.coords
+    conn = perm[base.conn].astype(np.int32)
+    nmats = int(rng.integers(1, 4))
+    mats = np.zeros((nmats, 5))
+    # stiffness contrast up to 30 between materials (beyond that the decks stop being comparable to 1e-9)
+    mats[:, 0] = 10.0 ** (rng.uniform(3, 9.5) + rng.uniform(0, 1.5, nmats)); mats[:, 1] = rng.uniform(0.0, 0.45, nmats); mats[:, 2:] = 1.0
+    mat_id = rng.integers(0, nmats, base.nels).astype(np.int32)
+    # Dirichlet: clamp the nodes of the lowest layer fully (no rigid-body motion), then a few partial
+    # constraints with prescribed non-zero values elsewhere
+    axis = pd - 1
+    low = np.where(coords[:, axis] <= coords[:, axis].min() + 1e-9 + 0.3)[0]
+    rows, vals = [], []
+    for v in low:
+        rows.append([v] + [0] * pd); vals.append([0.0] * pd)
+    others = np.setdiff1d(np.arange(nn), low)
+    for v in rng.choice(others, size=min(len(others), int(rng.integers(1, 5))), replace=False):
+        flags = rng.integers(0, 2, pd)
+        if flags.all():
+            flags[rng.integers(0, pd)] = 0
+        rows.append([v] + list(flags)); vals.append(list(rng.uniform(-1e-3, 1e-3, pd) * (1 - flags)))
+    scale = float(mats[:, 0].min())
+    nf = int(rng.integers(0, 4))
+    fnode = rng.choice(others, size=min(nf, len(others)), replace=False).astype(np.int32)
+    fval = np.zeros((len(fnode), pd + 2))
+    fval[:, :pd] = rng.uniform(-1, 1, (len(fnode), pd)) * 1e-4 * scale
+    fval[:, pd] = rng.uniform(0.0, 0.3, len(fnode)); fval[:, pd + 1] = fval[:, pd] + rng.uniform(0.3, 1.0, len(fnode))
+    nt = int(rng.integers(0, 4))
+    tel = rng.choice(base.nels, size=min(nt, base.nels), replace=False)
+    nsides = {1: 3, 2: 4, 3: 4, 4: 6}                                    # tri, qua, tet, hex (fem_amd.mesh codes)
+    telsd = np.array([[e, 1 + rng.integers(0, nsides[int(base.eltype[e])])] for e in tel], dtype=np.int32).reshape(-1, 2)
+    tval = np.zeros((len(tel), pd + 2))
+    tval[:, :pd] = rng.uniform(-1, 1, (len(tel), pd)) * 1e-4 * scale
+    tval[:, pd] = 0.0; tval[:, pd + 1] = rng.uniform(0.4, 1.0, len(tel))
+    dt = float(rng.choice([1.0, 0.5, 0.25]))
+    return Mesh(pdim=pd, eltype=base.eltype, eptr=base.eptr, conn=conn, mat_id=mat_id, coords=coords, mats=mats,
+                bcnode=np.array(rows, dtype=np.int32), bcval=np.array(vals), fnode=fnode, fval=fval,
+                telsd=telsd, tval=tval, t=1.0, dt=dt)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_deck_matches_oracle(gpu_ctx, oracle, seed):
+    m = random_deck(seed)
+    u, s, its = oracle.run(m, "lu")
+    for opts in SOLVERS:
+        res = driver.run(m, opts, ctx=gpu_ctx)
+        assert len(res.its) == len(its), opts
+        assert all(r > 0 for r in res.reasons), (opts, res.reasons)
+        su, ss = max(np.abs(u).max(), 1e-300), max(np.abs(s).max(), 1e-300)
+        assert np.abs(res.aggregate_u - u).max() <= 1e-9 * su, (opts, seed)
+        assert np.abs(res.aggregate_stress - s).max() <= 1e-8 * ss, (opts, seed)

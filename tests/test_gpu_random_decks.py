@@ -81,3 +81,55 @@ def test_random_deck_matches_oracle(gpu_ctx, oracle, seed):
         su, ss = max(np.abs(u).max(), 1e-300), max(np.abs(s).max(), 1e-300)
         assert np.abs(res.aggregate_u - u).max() <= 1e-9 * su, (opts, seed)
         assert np.abs(res.aggregate_stress - s).max() <= 1e-8 * ss, (opts, seed)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_deck_partitioned(oracle, seed):
+    """The same random decks cut into 2-4 domains by recursive coordinate bisection (in-process
+    communicator): interface nodes carry Dirichlet flags, forces and traction sides like any other
+    node, every increment, CG/Jacobi and the multigrid preconditioner; vs the serial oracle."""
+    import threading
+    from fem_amd import capi, partition
+    m = random_deck(1000 + seed)
+    world = 2 + seed % 3
+    epart = partition.rcb_partition(m, world)
+    parts = [partition.split_mesh(m, epart, r) for r in range(world)]
+    nl2g = [p[1] for p in parts]
+    ug, sg, its = oracle.run(m, "lu")
+    nsteps, pd = len(its), m.pdim
+    for opts in ("-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14", "-ksp_type cg -pc_type mg -pc_mg_type additive -ksp_rtol 1e-14",
+                 "-ksp_type cg -pc_type mg -ksp_rtol 1e-14"):
+        ctxs = [capi.Context(0) for _ in range(world)]
+        comms = capi.Comm.local_group(ctxs)
+        out, err = [None] * world, []
+
+        def work(r):
+            try:
+                lm = parts[r][0]
+                prob = driver.Problem(ctxs[r], lm, opts, comm=comms[r], halo=partition.general_halo(r, nl2g))
+                prob.assemble(); prob.ksp.set_up()
+                u = np.zeros(lm.ndof); s = np.zeros((lm.nnds, lm.cpdim))
+                for step in range(nsteps):
+                    prob.dmesh.form_rhs(prob.F, lm.dt * step, lm.dt)
+                    prob.ksp.solve(prob.F, prob.U)
+                    assert prob.ksp.get_converged_reason() > 0, prob.ksp.get_converged_reason()
+                    u += prob.U.get_array()
+                    s += prob.dmesh.recover_nodal_stress(prob.U)
+                out[r] = (u, s)
+                prob.destroy()
+            except Exception as e:  # noqa: BLE001
+                err.append((r, repr(e)))
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+        [t.start() for t in th]
+        [t.join(timeout=300) for t in th]
+        assert not err, (opts, err)
+        assert all(o is not None for o in out), "a domain thread hung"
+        for r in range(world):
+            u, s = out[r]
+            assert np.abs(u.reshape(-1, pd) - ug.reshape(-1, pd)[nl2g[r]]).max() <= 1e-9 * np.abs(ug).max(), (opts, r)
+            assert np.abs(s - sg[nl2g[r]]).max() <= 1e-8 * np.abs(sg).max(), (opts, r)
+        for c in comms:
+            c.destroy()
+        for c in ctxs:
+            c.destroy()

@@ -99,3 +99,27 @@ def test_unsupported_pairings_fail_loudly(gpu_ctx):
         with pytest.raises(capi.FemError):
             prob.ksp.set_up()
         prob.destroy()
+
+
+def test_direct_solve_config2_full_size(gpu_ctx):
+    """BASELINE config 2 at full size (707^2 quad4, 1.0 M DOF): the banded factor (11 GB) against
+    CG/Jacobi at rtol 1e-13 and against the residual of the assembled operator."""
+    m = structured_quad(707)
+    prob = driver.Problem(gpu_ctx, m, LU)
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == 4
+    u_lu = prob.U.get_array()
+    R, D = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof)
+    prob.K.mult(prob.U, R); prob.K.get_diagonal(D)
+    r = R.get_array() - prob.F.get_array()
+    scale = D.get_array() * np.abs(u_lu).max() + np.abs(prob.F.get_array()).max()
+    assert (np.abs(r) <= 1e-9 * scale).all()
+    prob.ksp.set_from_options("-ksp_type cg -pc_type jacobi -ksp_rtol 1e-13")
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == 2
+    assert np.abs(u_lu - prob.U.get_array()).max() <= 1e-8 * np.abs(u_lu).max()
+    for o in (R, D):
+        o.destroy()
+    prob.destroy()

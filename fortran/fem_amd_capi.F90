@@ -242,6 +242,170 @@ module fem_amd_capi
       real(c_double), intent(out) :: stress_node(*)
       integer(c_int) :: ierr
     end function
+    ! ---- the rest of include/fem_amd.h: multi-GPU, MatView-style access, Vec algebra, profiling ----
+    function fem_version() bind(C, name="fem_version") result(v)
+      import :: c_int
+      integer(c_int) :: v
+    end function
+    function fem_device_count(count) bind(C, name="fem_device_count") result(ierr)
+      import :: c_int
+      integer(c_int), intent(out) :: count
+      integer(c_int) :: ierr
+    end function
+    function fem_ctx_timer_start(ctx) bind(C, name="fem_ctx_timer_start") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      integer(c_int) :: ierr
+    end function
+    function fem_ctx_timer_stop(ctx, elapsed_ms) bind(C, name="fem_ctx_timer_stop") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      real(c_double), intent(out) :: elapsed_ms
+      integer(c_int) :: ierr
+    end function
+    ! one process per GPU (replaces MPI_Comm_rank/size + PETSc's communicators, src/main.F90:27-28)
+    function fem_comm_create_self(ctx, comm) bind(C, name="fem_comm_create_self") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      type(c_ptr), intent(out) :: comm
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_get_unique_id(unique_id) bind(C, name="fem_comm_get_unique_id") result(ierr)
+      import :: c_int, c_char
+      character(kind=c_char), intent(out) :: unique_id(128)
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_create_rccl(ctx, nranks, rank, unique_id, comm) bind(C, name="fem_comm_create_rccl") result(ierr)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: nranks, rank
+      character(kind=c_char), intent(in) :: unique_id(128)
+      type(c_ptr), intent(out) :: comm
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_create_local_group(n, ctxs, comms) bind(C, name="fem_comm_create_local_group") result(ierr)
+      import :: c_int, c_ptr
+      integer(c_int), value :: n
+      type(c_ptr), intent(in) :: ctxs(*)
+      type(c_ptr), intent(out) :: comms(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_destroy(comm) bind(C, name="fem_comm_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: comm
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_rank(comm, rank, nranks) bind(C, name="fem_comm_rank") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: comm
+      integer(c_int), intent(out) :: rank, nranks
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_exchange(comm, nneigh, neigh_rank, off, send, recv) bind(C, name="fem_comm_exchange") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: comm, send, recv
+      integer(c_int), value :: nneigh
+      integer(c_int), intent(in) :: neigh_rank(*)
+      integer(c_long_long), intent(in) :: off(*)
+      integer(c_int) :: ierr
+    end function
+    ! interface lists of this rank (what nl2g, src/main.F90:78-96, already holds); 0-based node ids
+    function fem_mesh_set_halo(mesh, comm, nneigh, neigh_rank, neigh_ptr, neigh_nodes) &
+        bind(C, name="fem_mesh_set_halo") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mesh, comm
+      integer(c_int), value :: nneigh
+      integer(c_int), intent(in) :: neigh_rank(*), neigh_ptr(*), neigh_nodes(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_rcm_order(n, ptr, adj, perm) bind(C, name="fem_rcm_order") result(ierr)
+      import :: c_int
+      integer(c_int), value :: n
+      integer(c_int), intent(in) :: ptr(*), adj(*)
+      integer(c_int), intent(out) :: perm(*)
+      integer(c_int) :: ierr
+    end function
+    ! MatView-style access (src/m_global.F90:702-741 GetStiffnessArray, without the dense copy)
+    function fem_mat_get_csr(mat, rowptr, colind, val) bind(C, name="fem_mat_get_csr") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mat
+      integer(c_int), intent(out) :: rowptr(*), colind(*)
+      real(c_double), intent(out) :: val(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_get_diagonal(mat, d) bind(C, name="fem_mat_get_diagonal") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat, d
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_mult_timed(mat, x, y, reps, avg_ms) bind(C, name="fem_mat_mult_timed") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mat, x, y
+      integer(c_int), value :: reps
+      real(c_double), intent(out) :: avg_ms
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_get_size(v, n) bind(C, name="fem_vec_get_size") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: v
+      integer(c_long_long), intent(out) :: n
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_device_ptr(v, dptr) bind(C, name="fem_vec_device_ptr") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: v
+      type(c_ptr), intent(out) :: dptr
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_copy(src, dst) bind(C, name="fem_vec_copy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: src, dst
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_axpy(y, a, x) bind(C, name="fem_vec_axpy") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: y, x
+      real(c_double), value :: a
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_dot(x, y, dot) bind(C, name="fem_vec_dot") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: x, y
+      real(c_double), intent(out) :: dot
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_norm2(x, nrm) bind(C, name="fem_vec_norm2") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: x
+      real(c_double), intent(out) :: nrm
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_get_residual_history(ksp, hist, len, n) bind(C, name="fem_ksp_get_residual_history") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ksp
+      real(c_double), intent(out) :: hist(*)
+      integer(c_int), value :: len
+      integer(c_int), intent(out) :: n
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_set_profiling(ksp, on) bind(C, name="fem_ksp_set_profiling") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp
+      integer(c_int), value :: on
+      integer(c_int) :: ierr
+    end function
+    function fem_ksp_get_profile(ksp, n_spmv, spmv_ms, solve_ms) bind(C, name="fem_ksp_get_profile") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ksp
+      integer(c_int), intent(out) :: n_spmv
+      real(c_double), intent(out) :: spmv_ms, solve_ms
+      integer(c_int) :: ierr
+    end function
+    function fem_recover_nodal_stress_vec(mesh, U, S) bind(C, name="fem_recover_nodal_stress_vec") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mesh, U, S
+      integer(c_int) :: ierr
+    end function
   end interface
 
 contains

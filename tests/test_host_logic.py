@@ -234,3 +234,16 @@ def test_rcm_order_is_a_bandwidth_reducing_permutation():
     assert band <= ny + 2
     # a graph without edges keeps every node
     assert sorted(capi.rcm_order([0, 0, 0, 0], [])) == [0, 1, 2]
+
+
+def test_fortran_interface_module_covers_the_whole_c_abi():
+    """fortran/fem_amd_capi.F90 must bind every entry point include/fem_amd.h declares (a Fortran host
+    is the reference's own language, north_star) -- keeps the two files in step."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "fem_amd.h")).read()
+    f90 = open(os.path.join(ROOT, "fortran", "fem_amd_capi.F90")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?\s*(fem_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    bound = set(re.findall(r'name="(fem_[a-z0-9_]+)"', f90))
+    assert len(declared) > 60
+    assert declared - bound == set(), sorted(declared - bound)
+    assert bound - declared == set(), sorted(bound - declared)

@@ -60,6 +60,7 @@ _SIGS = {
     "fem_mat_get_info": [_h, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)],
     "fem_mat_get_csr": [_h, _ip, _ip, _dp],
     "fem_mat_mult": [_h, _h, _h],
+    "fem_mat_set_mult_type": [_h, C.c_char_p],
     "fem_mat_get_diagonal": [_h, _h],
     "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
     "fem_vec_create": [_h, C.c_longlong, C.POINTER(_h)],
@@ -395,6 +396,10 @@ class Mat:
 
     def mult(self, x: Vec, y: Vec):
         _ck(_lib.fem_mat_mult(self.h, x.h, y.h))
+
+    def set_mult_type(self, kind: str):
+        """'assembled' (sliced block-ELL SpMV) or 'ebe' (element-by-element recomputation)."""
+        _ck(_lib.fem_mat_set_mult_type(self.h, kind.encode()))
 
     def mult_timed(self, x: Vec, y: Vec, reps: int) -> float:
         ms = C.c_double(0)

@@ -19,6 +19,7 @@ fem_mesh mesh_create_impl(fem_ctx, int, int, int, const int*, const int*, const 
 void mesh_set_halo_impl(fem_mesh, fem_comm, int, const int*, const int*, const int*);
 fem_mat mat_create_impl(fem_mesh);
 void mat_assemble_elements_impl(fem_mat);
+void mat_set_mult_type_impl(fem_mat, const char*);
 void mat_apply_kbc_impl(fem_mat, int, const int*);
 void mat_get_csr_impl(fem_mat, int*, int*, double*);
 void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
@@ -254,6 +255,7 @@ int fem_mat_zero_entries(fem_mat A)
     FEM_CHECK(A, 1, "null matrix");
     A->ctx->bind();
     A->val.zero(A->ctx->stream);
+    A->bc_saved = false;   // the next ApplyKBC sees a freshly assembled diagonal again
     FEM_CATCH
 }
 
@@ -262,6 +264,14 @@ int fem_mat_assemble_elements(fem_mat A)
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
     mat_assemble_elements_impl(A);
+    FEM_CATCH
+}
+
+int fem_mat_set_mult_type(fem_mat A, const char* type)
+{
+    FEM_TRY
+    FEM_CHECK(A && type, 1, "null argument");
+    mat_set_mult_type_impl(A, type);
     FEM_CATCH
 }
 

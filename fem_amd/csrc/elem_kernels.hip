@@ -479,6 +479,196 @@ void mat_assemble_elements_impl(fem_mat A)
     FEM_HIP(hipGetLastError());
 }
 
+// ---- MatMult by element-by-element recomputation (`-mat_mult_type ebe`) -----------------------
+// y = K x without reading the assembled matrix: every element recomputes f_e = K_e x_e at its Gauss
+// points (J, dN/dx, strain, stress, B^T sigma w detJ: ~3.2 kFMA per hex8 against 7 GB of stored
+// blocks), writes its npe*pdim nodal forces to an element-major buffer, and a second kernel sums, for
+// every node, the entries of its incident elements in ascending (group, element) order: no atomics,
+// bitwise reproducible.  Penalty rows: ApplyKBC INSERTs on the diagonal only, so y_i += (inserted -
+// assembled diagonal) * x_i.  p.Kp comes for free as sum_e x_e.f_e (+ the penalty term), the same
+// un-assembled identity the partitioned product uses.
+// Traffic at config 3: 0.11 GB connectivity + 1.27 GB element buffer (write + read) + gathers from
+// L2, i.e. 1.5 GB instead of 7.4 GB; the element kernel is bound by the fp64 FMA pipe.
+template <int PD, int NPE, int NIP>
+__global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int* __restrict__ conn,
+                                                   const double* __restrict__ coords, const double* __restrict__ Ev,
+                                                   const double* __restrict__ nuv, const double* __restrict__ x,
+                                                   double* __restrict__ f, double* __restrict__ partial,
+                                                   const int* __restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double sh[4];
+    const ElemTable& tab = c_tab[type];
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double dot = 0.0;
+    if (e < (size_t)nel) {
+        double X[NPE][PD], u[NPE][PD], fe[NPE][PD];
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+            const size_t v = (size_t)conn[e * NPE + a];
+#pragma unroll
+            for (int d = 0; d < PD; d++) { X[a][d] = coords[v * PD + d]; u[a][d] = x[v * PD + d]; fe[a][d] = 0.0; }
+        }
+        const DCoef D = dmat_coef(Ev[e], nuv[e]);
+#pragma unroll
+        for (int q = 0; q < NIP; q++) {
+            constexpr int CP = (PD == 2) ? 3 : 6;
+            double dN[NPE][PD], detj, sig[CP];
+            dndx_at_gp<PD, NPE>(tab.dNxi[q], X, dN, detj);
+            gp_stress<PD, NPE>(dN, u, D, sig);
+            const double wd = tab.w[q] * detj;
+#pragma unroll
+            for (int c = 0; c < CP; c++) sig[c] *= wd;
+#pragma unroll
+            for (int a = 0; a < NPE; a++) {
+                if constexpr (PD == 2) {   // Voigt xx, yy, xy
+                    fe[a][0] += dN[a][0] * sig[0] + dN[a][1] * sig[2];
+                    fe[a][1] += dN[a][1] * sig[1] + dN[a][0] * sig[2];
+                } else {                   // Voigt xx, yy, zz, xy, yz, zx
+                    fe[a][0] += dN[a][0] * sig[0] + dN[a][1] * sig[3] + dN[a][2] * sig[5];
+                    fe[a][1] += dN[a][1] * sig[1] + dN[a][0] * sig[3] + dN[a][2] * sig[4];
+                    fe[a][2] += dN[a][2] * sig[2] + dN[a][1] * sig[4] + dN[a][0] * sig[5];
+                }
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NPE; a++)
+#pragma unroll
+            for (int d = 0; d < PD; d++) {
+                f[(size_t)(a * PD + d) * nel + e] = fe[a][d];   // component-major: consecutive elements, consecutive words
+                dot += u[a][d] * fe[a][d];
+            }
+    }
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+struct EbeViews {
+    const double* f[4];
+    int nel[4];
+};
+// ascending codes inside every node's list (the symbolic phase fills them with an atomic cursor)
+__global__ void __launch_bounds__(256) k_sort_n2e(int nn, const int* __restrict__ ptr, unsigned* __restrict__ lst)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    const int p0 = ptr[v], p1 = ptr[v + 1];
+    for (int i = p0 + 1; i < p1; i++) {
+        const unsigned c = lst[i];
+        int j = i - 1;
+        while (j >= p0 && lst[j] > c) { lst[j + 1] = lst[j]; j--; }
+        lst[j + 1] = c;
+    }
+}
+template <int PD>
+__global__ void __launch_bounds__(256) k_ebe_gather(int nn, const int* __restrict__ ptr, const unsigned* __restrict__ lst,
+                                                    EbeViews ev, double* __restrict__ y, const int* __restrict__ done)
+{
+    if (done && *done) return;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    double s[PD];
+#pragma unroll
+    for (int d = 0; d < PD; d++) s[d] = 0.0;
+    for (int k = ptr[v]; k < ptr[v + 1]; k++) {
+        const unsigned code = lst[k];
+        const int g = code >> 30;
+        const size_t e = (code & 0x3fffffffu) >> 3, a = code & 7u, ne = (size_t)ev.nel[g];
+#pragma unroll
+        for (int d = 0; d < PD; d++) s[d] += ev.f[g][(a * PD + d) * ne + e];
+    }
+#pragma unroll
+    for (int d = 0; d < PD; d++) y[(size_t)v * PD + d] = s[d];
+}
+// penalty rows: y_i += shift_i x_i ; their share of x.Kx goes to EBE_BC_BLOCKS extra partials
+// (config 3 has 135 k constrained dofs: one workgroup would need 190 us for them)
+constexpr int EBE_BC_BLOCKS = 64;
+__global__ void __launch_bounds__(256) k_ebe_penalty(int n, const int* __restrict__ dof, const double* __restrict__ shift,
+                                                     const double* __restrict__ x, double* __restrict__ y,
+                                                     double* __restrict__ partial, const int* __restrict__ done)
+{
+    if (done && *done) return;
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int i = dof[k];
+        if (i < 0) continue;
+        const double xi = x[i], t = shift[k] * xi;
+        y[i] += t;
+        s += t * xi;
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+static int ebe_blocks(const fem_mesh m)
+{
+    int nb = 0;
+    for (auto& g : m->groups) nb += (int)cdiv((size_t)g.nel, 256);
+    return nb + EBE_BC_BLOCKS;
+}
+
+void mat_set_mult_type_impl(fem_mat A, const char* type)
+{
+    const std::string t = type;
+    FEM_CHECK(t == "assembled" || t == "ebe", 6, "fem_mat_set_mult_type: unsupported type " + t + " (assembled|ebe)");
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const bool ebe = (t == "ebe");
+    if (ebe && A->ebe_f.empty()) {
+        fem_mesh m = A->mesh;
+        FEM_CHECK(A->n2e_ptr.p && A->n2e.p, 5, "fem_mat_set_mult_type: matrix was not created from a mesh");
+        if (!A->n2e_sorted) {
+            hipLaunchKernelGGL(k_sort_n2e, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p, A->n2e.p);
+            A->n2e_sorted = true;
+        }
+        A->ebe_f.resize(m->groups.size());
+        for (size_t g = 0; g < m->groups.size(); g++)
+            A->ebe_f[g].alloc((size_t)m->groups[g].nel * m->groups[g].npe * m->pdim);
+        A->ebe_grid = ebe_blocks(m);
+        A->ebe_partial.alloc((size_t)A->ebe_grid);
+        FEM_HIP(hipGetLastError());
+        FEM_HIP(hipStreamSynchronize(s));
+    }
+    A->mult_ebe = ebe;
+    // the Krylov solver sums A->spmv_partial[0 .. spmv_grid): size it for the product in use
+    A->spmv_grid = ebe ? A->ebe_grid : (A->nslices + 3) / 4;
+    A->spmv_partial.alloc((size_t)A->spmv_grid);
+}
+
+void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const int* done)
+{
+    fem_mesh m = A->mesh;
+    hipStream_t s = A->ctx->stream;
+    double* part = partial ? partial : A->ebe_partial.p;
+    EbeViews ev{};
+    int off = 0;
+    for (size_t gi = 0; gi < m->groups.size(); gi++) {
+        auto& g = m->groups[gi];
+        ev.f[gi] = A->ebe_f[gi].p; ev.nel[gi] = g.nel;
+        const unsigned nb = cdiv((size_t)g.nel, 256);
+        dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto) {
+            hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP()>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
+                               m->coords.p, g.E.p, g.nu.p, x, A->ebe_f[gi].p, part + off, done);
+        });
+        off += (int)nb;
+    }
+    if (m->pdim == 3)
+        hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p,
+                           A->n2e.p, ev, y, done);
+    else
+        hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p,
+                           A->n2e.p, ev, y, done);
+    // launched also when there is no penalty row: the last partials must be written
+    hipLaunchKernelGGL(k_ebe_penalty, dim3(EBE_BC_BLOCKS), dim3(256), 0, s, A->bc_saved ? A->nbc_dof : 0, A->bc_dof.p,
+                       A->bc_shift.p, x, y, part + off, done);
+}
+
 // FormElKE for a batch of elements given by their coordinates (host in/out)
 void form_el_ke_impl(fem_ctx ctx, int type, int nel, const double* ecoords, const double* E, const double* nu, double* k)
 {

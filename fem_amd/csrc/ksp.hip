@@ -28,6 +28,7 @@
 using namespace fem;
 
 void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const int* done);
+void mat_set_mult_type_impl(fem_mat A, const char* type);
 void mat_get_diagonal_raw(fem_mat A, double* d);
 
 namespace fem {
@@ -269,6 +270,7 @@ struct fem_ksp_s {
     fem_ctx ctx = nullptr;
     fem_mat A = nullptr;
     std::string type = "cg", pc = "jacobi";
+    std::string mult_type;                   // -mat_mult_type: applied to the operator at set-up when given
     // PETSc defaults (KSPCreate): rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 1e4
     double rtol = 1.0e-5, abstol = 1.0e-50, dtol = 1.0e5;
     int maxit = 10000;
@@ -324,6 +326,11 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-pc_mg_alpha") { is >> k->mg_alpha; }     // coarse-correction scaling (over-correction)
         else if (key == "-pc_mg_box") { is >> k->mg_box; FEM_CHECK(k->mg_box >= 2.0 && k->mg_box <= 16.0, 6, "-pc_mg_box must lie in [2, 16]"); }
         else if (key == "-pc_mg_omega") { is >> k->mg_omega; }     // Jacobi damping of the smoother
+        else if (key == "-mat_mult_type") {
+            is >> val;
+            FEM_CHECK(val == "assembled" || val == "ebe", 6, "unsupported -mat_mult_type " + val + " (assembled|ebe)");
+            k->mult_type = val;
+        }
         else if (key == "-ksp_rtol") { is >> k->rtol; }
         else if (key == "-ksp_atol") { is >> k->abstol; }
         else if (key == "-ksp_divtol") { is >> k->dtol; }
@@ -346,6 +353,7 @@ void ksp_set_up_impl(fem_ksp k)
     fem_mat A = k->A;
     k->n = (long long)A->nbrows * A->bs;
     const size_t n = (size_t)k->n;
+    if (!k->mult_type.empty()) mat_set_mult_type_impl(A, k->mult_type.c_str());
     // KSPPREONLY applies the preconditioner once: only meaningful with a factorisation, and a
     // factorisation under CG would only hide its cost (src/main.F90:354-358 pairs them the same way)
     const bool direct = k->pc == "lu";

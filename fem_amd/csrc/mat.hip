@@ -41,7 +41,7 @@ __global__ void __launch_bounds__(256) k_fill_n2e(GroupView gv, int gidx, const 
     for (; i < nent; i += st) {
         const int v = gv.conn[i];
         const int pos = atomicAdd(&cursor[v], 1);
-        n2e[n2e_ptr[v] + pos] = ((unsigned)gidx << 30) | (unsigned)(i / gv.npe);
+        n2e[n2e_ptr[v] + pos] = ((unsigned)gidx << 30) | ((unsigned)(i / gv.npe) << 3) | (unsigned)(i % gv.npe);
     }
 }
 
@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(256) k_node_neighbours(int nn, int nrows_padde
         for (int k = n2e_ptr[v]; k < n2e_ptr[v + 1]; k++) {
             const unsigned code = n2e[k];
             const GroupView gv = gvs.g[code >> 30];
-            const int* c = gv.conn + (size_t)(code & 0x3fffffffu) * gv.npe;
+            const int* c = gv.conn + (size_t)((code & 0x3fffffffu) >> 3) * gv.npe;
             for (int a = 0; a < gv.npe; a++) {
                 const int u = c[a];
                 int lo = 0, hi = len;
@@ -221,7 +221,8 @@ template <int BS>
 __global__ void __launch_bounds__(256) k_apply_kbc(int nbcs, const int* __restrict__ bcnode,
                                                    const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                    const int* __restrict__ bcol, double* __restrict__ val,
-                                                   const unsigned char* __restrict__ owned, double penalty)
+                                                   const unsigned char* __restrict__ owned, double penalty,
+                                                   int* __restrict__ bc_dof, double* __restrict__ bc_shift)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbcs) return;
@@ -233,9 +234,15 @@ __global__ void __launch_bounds__(256) k_apply_kbc(int nbcs, const int* __restri
         if (bcol[(size_t)(o0 + mid) * 64 + lane] < row) lo = mid + 1; else hi = mid;
     }
     const double pv = (!owned || owned[row]) ? penalty : 0.0;
-    for (int r = 0; r < BS; r++)
-        if (bcnode[(size_t)i * (1 + BS) + 1 + r] == 0)
-            val[((size_t)(o0 + lo) * BS * BS + r * BS + r) * 64 + lane] = pv;
+    for (int r = 0; r < BS; r++) {
+        const bool fixed = bcnode[(size_t)i * (1 + BS) + 1 + r] == 0;
+        double* d = &val[((size_t)(o0 + lo) * BS * BS + r * BS + r) * 64 + lane];
+        if (bc_dof) {   // first application after an assembly: remember what the INSERT replaces
+            bc_dof[(size_t)i * BS + r] = fixed ? row * BS + r : -1;
+            bc_shift[(size_t)i * BS + r] = fixed ? pv - *d : 0.0;
+        }
+        if (fixed) *d = pv;
+    }
 }
 
 }  // namespace fem
@@ -264,12 +271,17 @@ fem_mat mat_create_impl(fem_mesh mesh)
     const GroupViews gvs = make_views(mesh);
 
     // node -> incident elements (CSR on device)
-    DBuf<int> n2e_ptr((size_t)nn + 1), cursor(nn), tmp(exclusive_scan_tmp_ints((size_t)nrp + 1));
+    DBuf<int> cursor(nn), tmp(exclusive_scan_tmp_ints((size_t)nrp + 1));
+    DBuf<int>& n2e_ptr = A->n2e_ptr;
+    DBuf<unsigned>& n2e = A->n2e;
+    n2e_ptr.alloc((size_t)nn + 1);
     exclusive_scan_i32(mesh->valence.p, n2e_ptr.p, nn, tmp.p, s);
     int tot = 0;
     FEM_HIP(hipMemcpyAsync(&tot, n2e_ptr.p + nn, sizeof(int), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipStreamSynchronize(s));
-    DBuf<unsigned> n2e((size_t)std::max(tot, 1));
+    for (auto& g : mesh->groups)
+        FEM_CHECK(g.nel < (1 << 27), 4, "fem_mat_create_aij: more than 2^27 elements of one type in a domain");
+    n2e.alloc((size_t)std::max(tot, 1));
     cursor.zero(s);
     for (int g = 0; g < gvs.ng; g++) {
         const size_t nent = (size_t)gvs.g[g].nel * gvs.g[g].npe;
@@ -320,8 +332,11 @@ fem_mat mat_create_impl(fem_mesh mesh)
     return A.release();
 }
 
+void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const int* done);   // elem_kernels.hip
+
 void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const int* done)
 {
+    if (A->mult_ebe) { ebe_mult_impl(A, x, y, partial, done); return; }
     hipStream_t s = A->ctx->stream;
     if (A->bs == 3)
         hipLaunchKernelGGL(k_spmv_sell<3>, dim3(A->spmv_grid), dim3(256), 0, s, A->nslices, A->nbrows, A->boff.p,
@@ -355,12 +370,24 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs, const int* bcnode)
     DBuf<int> d_bc((size_t)nbcs * (1 + pd));
     d_bc.upload(bcnode, (size_t)nbcs * (1 + pd), s);
     const unsigned char* owned = A->mesh->halo ? A->mesh->halo->owned.p : nullptr;
+    // the element-by-element product needs (inserted value - assembled diagonal) of every penalty row;
+    // only the first ApplyKBC after an assembly sees the assembled diagonal
+    int* bcd = nullptr;
+    double* bcs = nullptr;
+    if (!A->bc_saved) {
+        A->nbc_dof = nbcs * pd;
+        A->bc_dof.alloc((size_t)A->nbc_dof); A->bc_shift.alloc((size_t)A->nbc_dof);
+        bcd = A->bc_dof.p; bcs = A->bc_shift.p;
+    } else {
+        FEM_CHECK(A->nbc_dof == nbcs * pd, 5, "fem_mat_apply_kbc: a different constraint list needs a fresh assembly");
+    }
     if (pd == 3)
         hipLaunchKernelGGL(k_apply_kbc<3>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM);
+                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs);
     else
         hipLaunchKernelGGL(k_apply_kbc<2>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM);
+                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs);
+    A->bc_saved = true;
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
 }

@@ -72,6 +72,21 @@ struct fem_mat_s {
     std::vector<int> h_boff, h_rowlen;
     fem::DBuf<double> spmv_partial;  // per-workgroup partials of the fused p.Kp
     int spmv_grid = 0;
+    // node -> incident (group, element, local node), code = group<<30 | element<<3 | local node;
+    // built by the symbolic phase, sorted (and kept) for the element-by-element product
+    fem::DBuf<int> n2e_ptr;
+    fem::DBuf<unsigned> n2e;
+    bool n2e_sorted = false;
+    // MatMult by element-by-element recomputation (`-mat_mult_type ebe`, elem_kernels.hip)
+    bool mult_ebe = false;
+    std::vector<fem::DBuf<double>> ebe_f;   // per element group: nodal forces [npe*pdim][nel]
+    fem::DBuf<double> ebe_partial;          // internal p.Kp partials when the caller wants none
+    int ebe_grid = 0;                       // workgroups of all element groups + those of the penalty rows
+    // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
+    fem::DBuf<int> bc_dof;
+    fem::DBuf<double> bc_shift;
+    int nbc_dof = 0;
+    bool bc_saved = false;
 };
 
 struct fem_ksp_s;

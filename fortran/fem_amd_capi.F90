@@ -333,6 +333,12 @@ module fem_amd_capi
       real(c_double), intent(out) :: val(*)
       integer(c_int) :: ierr
     end function
+    function fem_mat_set_mult_type(mat, mtype) bind(C, name="fem_mat_set_mult_type") result(ierr)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: mat
+      character(kind=c_char), intent(in) :: mtype(*)
+      integer(c_int) :: ierr
+    end function
     function fem_mat_get_diagonal(mat, d) bind(C, name="fem_mat_get_diagonal") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: mat, d

@@ -1,0 +1,109 @@
+"""GPU: MatMult by element-by-element recomputation (`-mat_mult_type ebe`) against the assembled
+operator and the oracle: same operator, same CG iterates up to rounding, bitwise reproducible."""
+import threading
+
+import numpy as np
+import pytest
+
+from fem_amd import capi, driver, partition
+from fem_amd.mesh import structured_hex, structured_quad, hex_to_tets, quad_to_mixed
+
+pytestmark = pytest.mark.gpu
+
+
+def _meshes():
+    return {
+        "hex5_jitter": structured_hex(5, 4, 3, jitter=0.2),
+        "hex_67nodes_x": structured_hex(66, 2, 2, jitter=0.1),
+        "quad9_jitter": structured_quad(9, 7, jitter=0.2),
+        "tet": hex_to_tets(structured_hex(4, 3, 3, jitter=0.15)),
+        "mixed_tri_qua": quad_to_mixed(structured_quad(8, 5, jitter=0.1)),
+        "hex300": structured_hex(7, 7, 6, jitter=0.1),            # more than one 256-element workgroup
+    }
+
+
+@pytest.mark.parametrize("name", list(_meshes()))
+def test_ebe_product_matches_assembled_product_and_oracle(gpu_ctx, oracle, name):
+    m = _meshes()[name]
+    rp, ci = oracle.csr_pattern(m)
+    vr = oracle.assemble(m, rp, ci, apply_bc=True)
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K = capi.Mat(dm)
+    K.assemble_elements(); K.apply_kbc()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(m.ndof)
+    X, Ya, Ye = (capi.Vec(gpu_ctx, m.ndof) for _ in range(3))
+    X.set_array(x)
+    K.mult(X, Ya)
+    K.set_mult_type("ebe")
+    K.mult(X, Ye)
+    ye = Ye.get_array()
+    K.mult(X, Ye)
+    assert np.array_equal(ye, Ye.get_array())                      # no atomics: bitwise reproducible
+    yr = oracle.spmv(rp, ci, vr, x)
+    # penalty rows carry 1e30 * x: compare every row against its own scale
+    row_scale = np.abs(oracle.spmv(rp, ci, np.abs(vr), np.abs(x)))
+    assert (np.abs(ye - yr) <= 1e-13 * row_scale).all()
+    assert (np.abs(ye - Ya.get_array()) <= 1e-13 * row_scale).all()
+    K.set_mult_type("assembled")
+    K.mult(X, Ye)
+    assert np.array_equal(Ye.get_array(), Ya.get_array())
+    for o in (X, Ya, Ye, K, dm):
+        o.destroy()
+
+
+@pytest.mark.parametrize("name", ["hex5_jitter", "quad9_jitter", "tet", "mixed_tri_qua"])
+@pytest.mark.parametrize("pc", ["jacobi", "mg -pc_mg_type additive", "mg"])
+def test_cg_with_ebe_operator_matches_oracle(gpu_ctx, oracle, name, pc):
+    m = _meshes()[name]
+    res = driver.run(m, f"-mat_mult_type ebe -pc_type {pc} -ksp_rtol 1e-13", ctx=gpu_ctx)
+    ref = driver.run(m, f"-pc_type {pc} -ksp_rtol 1e-13", ctx=gpu_ctx, recover_stress=False)
+    u, s, its = oracle.run(m, "cg", rtol=1e-13)
+    assert res.reasons[-1] == 2
+    assert np.abs(res.aggregate_u - u).max() <= 1e-10 * np.abs(u).max()
+    assert np.abs(res.aggregate_stress - s).max() <= 1e-9 * np.abs(s).max()
+    # same algorithm, only the rounding of the product differs
+    assert abs(res.its[-1] - ref.its[-1]) <= max(2, ref.its[-1] // 50)
+
+
+def test_ebe_on_a_partitioned_mesh(oracle):
+    """Element-by-element product + halo sums on four brick domains against the serial oracle."""
+    from tests.test_gpu_multidomain import _run_domains
+    world, npr = 4, (4, 3, 4)
+    grid, out = _run_domains(world, npr, 0.15, "-mat_mult_type ebe -ksp_rtol 1e-13")
+    gn = tuple(grid[d] * npr[d] for d in range(3))
+    g = structured_hex(*gn, jitter=0.15)
+    ug, sg, gits = oracle.run(g, "cg", rtol=1e-13)
+    rp, ci = oracle.csr_pattern(g)
+    val = oracle.assemble(g, rp, ci, apply_bc=True)
+    xg = np.sin(0.37 * np.arange(g.ndof + 3))[:g.ndof]
+    yg = oracle.spmv(rp, ci, val, xg).reshape(-1, 3)
+    for r, (u, s, its, reason, y, gid) in enumerate(out):
+        assert reason > 0
+        assert np.abs(u.reshape(-1, 3) - ug.reshape(-1, 3)[gid]).max() <= 1e-10 * np.abs(ug).max()
+        assert np.abs(s - sg[gid]).max() <= 1e-9 * np.abs(sg).max()
+        assert abs(its - gits[0]) <= 3
+        row_scale = np.abs(yg[gid]) + 1e-12 * np.abs(yg).max()
+        assert (np.abs(y.reshape(-1, 3) - yg[gid]) <= 1e-10 * np.abs(yg).max()).all() or \
+            (np.abs(y.reshape(-1, 3) - yg[gid]) <= 1e-12 * row_scale.max()).all()
+    for r in range(world):
+        for q in range(r + 1, world):
+            common, ir, iq = np.intersect1d(out[r][5], out[q][5], return_indices=True)
+            if common.size:
+                assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])
+
+
+def test_ebe_full_size_config3(gpu_ctx):
+    """Config 3 at full size: same iteration count (+-2) and displacement field as the assembled SpMV."""
+    m = structured_hex(149)
+    out = {}
+    for mt in ("assembled", "ebe"):
+        prob = driver.Problem(gpu_ctx, m, f"-mat_mult_type {mt} -pc_type jacobi -ksp_rtol 1e-9")
+        prob.assemble(); prob.ksp.set_up()
+        prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+        prob.ksp.solve(prob.F, prob.U)
+        assert prob.ksp.get_converged_reason() == 2
+        out[mt] = (prob.U.get_array(), prob.ksp.get_iteration_number())
+        prob.destroy()
+    assert abs(out["ebe"][1] - out["assembled"][1]) <= 2
+    assert np.abs(out["ebe"][0] - out["assembled"][0]).max() <= 1e-7 * np.abs(out["assembled"][0]).max()

@@ -27,6 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# fp64 FMA peak of MI355X: 256 CUs x 128 flop/clk x 2.4 GHz = 78.6 TFLOP/s; the data sheet quotes the
+# same figure for vector fp64 and for the f64 MFMA (the guide has no fp64 row of its own)
+FP64_PEAK_TFLOPS = 78.6
+# Element-by-element hex8 product, flops per element as coded in k_ebe_apply (FMA = 2), 8 Gauss points:
+# J 144 + adjugate/det/inverse 42 + dN/dx 144 + grad u 144 + strain/stress 26 + B^T sigma 144 = 644 per
+# point, plus 48 for x_e.f_e  
+EBE_FLOPS_PER_HEX8 = 8 * 644 + 48
 
 
 def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:
@@ -75,6 +82,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--jitter", type=float, default=0.0)
     ap.add_argument("--pc", default="jacobi", help="preconditioner of the timed (headline) solve: jacobi (north_star) | mg")
+    ap.add_argument("--mult", default="ebe", choices=["ebe", "assembled"],
+                    help="how the CG applies Mat_K: element-by-element recomputation (default, 2x faster) or the "
+                         "assembled sliced-ELL SpMV; the other one is measured beside it")
     ap.add_argument("--no-mg", action="store_true", help="skip the extra -pc_type mg measurement")
     ap.add_argument("--mg-timeout", type=float, default=240.0,
                     help="N>1 only: seconds after which the extra -pc_type mg measurement is abandoned and the "
@@ -127,7 +137,7 @@ def main():
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
     pc_opts = {"jacobi": "-pc_type jacobi", "mg": "-pc_type mg -pc_mg_type additive"}[args.pc]
-    prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} {pc_opts}", comm=comm, halo=halo)
+    prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult}", comm=comm, halo=halo)
     prob.ksp.set_profiling(True)
 
     def barrier():
@@ -141,6 +151,7 @@ def main():
             prob.K.destroy(); prob.K = None
         ta = time.perf_counter()
         prob.assemble()                      # symbolic + numeric + BC (main.F90:151-171)
+        prob.K.set_profiling(True)
         prob.ksp.set_up()
         tb = time.perf_counter()
         prob.dmesh.form_rhs(prob.F, 0.0, mesh.dt)
@@ -154,11 +165,15 @@ def main():
     t0 = time.perf_counter()
     t_asm = t_sol = 0.0
     n_spmv, spmv_ms = 0, 0.0
+    ebe_n, ebe_el, ebe_ga, ebe_pe = 0, 0.0, 0.0, 0.0
     for _ in range(args.steps):
         a, s = one_step()
         t_asm += a; t_sol += s
         k, ms, _ = prob.ksp.get_profile()
         n_spmv += k; spmv_ms += ms
+        if args.mult == "ebe":
+            pn, pel, pga, ppe = prob.K.get_profile(k)      # the products that really ran (not the no-ops after `done`)
+            ebe_n += pn; ebe_el += pel; ebe_ga += pga; ebe_pe += ppe
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -175,35 +190,73 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = ndof_global * args.steps / elapsed
 
-    out = None
-    if rank == 0:
-        alg = spmv_algorithmic_bytes(nnz, nrows)
-        avg_ms = spmv_ms / max(n_spmv, 1)
-        achieved = alg / (avg_ms * 1e-3) / 1e9
-        fmt_bytes = dev_bytes + nrows * 16.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "spmv_traffic.json")
+    # the product the headline did NOT use, timed beside it (back-to-back launches, same Mat, same stream)
+    # (local products only, no halo sum: every rank may do it on its own)
+    X, Y = capi.Vec(ctx, nrows), capi.Vec(ctx, nrows)
+    X.set_array(np.sin(0.001 * np.arange(nrows)))
+    other_kind = "assembled" if args.mult == "ebe" else "ebe"
+    prob.K.set_profiling(False)
+    prob.K.set_mult_type(other_kind)
+    prob.K.mult_timed(X, Y, 1)                              # warm-up (and the lazy buffers of the ebe product)
+    other = (other_kind, prob.K.mult_timed(X, Y, 40))
+    prob.K.set_mult_type(args.mult)
+    X.destroy(); Y.destroy()
+
+    def traffic_of(fname, n):
+        tpath = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("n") == args.n:
-                traffic = tj.get("hbm_bytes_per_launch")
+            if tj.get("n") == n:
+                return tj.get("hbm_bytes_per_launch")
+        return None
+
+    def spmv_roofline(avg_ms, launches, where):
+        alg = spmv_algorithmic_bytes(nnz, nrows)
+        achieved = alg / (avg_ms * 1e-3) / 1e9
+        fmt_bytes = dev_bytes + nrows * 16.0
+        return {"bound": "hbm", "kernel": f"k_spmv_sell<3> (assembled MatMult, {where})", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic_of("spmv_traffic.json", args.n), "algorithmic_bytes": alg, "avg_launch_ms": avg_ms,
+                "launches": launches, "format_bytes": fmt_bytes, "format_GBs": fmt_bytes / (avg_ms * 1e-3) / 1e9}
+
+    def ebe_roofline(avg_el_ms, launches, extra):
+        nel = args.n ** 3
+        flops = float(nel) * EBE_FLOPS_PER_HEX8
+        achieved = flops / (avg_el_ms * 1e-3) / 1e12
+        r = {"bound": "mfma", "pipe": "fp64 FMA (v_fma_f64; MI355X quotes one 78.6 TFLOP/s peak for vector fp64 and f64 MFMA)",
+             "kernel": "k_ebe_apply<3,8,8> (element-by-element MatMult inside KSPCG)", "achieved": achieved,
+             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+             "traffic": traffic_of("ebe_traffic.json", args.n), "algorithmic_flops": flops, "avg_launch_ms": avg_el_ms,
+             "launches": launches}
+        r.update(extra)
+        return r
+
+    out = None
+    if rank == 0:
+        avg_ms = spmv_ms / max(n_spmv, 1)                  # whole MatMult as the KSP sees it
+        if args.mult == "ebe":
+            roof = ebe_roofline(ebe_el / max(ebe_n, 1), ebe_n,
+                                {"matmult_ms": avg_ms, "gather_ms": ebe_ga / max(ebe_n, 1), "penalty_ms": ebe_pe / max(ebe_n, 1)})
+            side = {"spmv_roofline": spmv_roofline(other[1], 40, "40 back-to-back launches beside the timed solve")}
+        else:
+            roof = spmv_roofline(avg_ms, n_spmv, "inside KSPCG")
+            side = {"ebe_matmult_ms": other[1]}
         out = {
             "metric": "DOF/sec assemble+solve (3D hex linear elastic); CG SpMV GB/s vs HBM roofline",
             "value": value, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config 3: {args.n}^3 hex8 cube per GPU, E=3e10 nu=0.25, z=0 clamped, "
-                                   f"top face u_z=-0.01*n by penalty, CG/{args.pc} rtol={args.rtol:.3g}",
+                                   f"top face u_z=-0.01*n by penalty, CG/{args.pc} rtol={args.rtol:.3g}, "
+                                   f"MatMult {'element-by-element' if args.mult == 'ebe' else 'assembled SpMV'}",
                        "bricks": list(grid), "dof_global": ndof_global, "dof_per_gpu": nrows, "nnz_per_gpu": nnz,
                        "cg_iterations": its, "converged_reason": reason,
                        "ms_per_cg_iteration": t_sol / args.steps * 1e3 / max(its, 1),
                        "t_assemble_ms": t_asm / args.steps * 1e3, "t_solve_ms": t_sol / args.steps * 1e3},
-            "roofline": {"bound": "hbm", "kernel": "k_spmv_sell<3> (MatMult inside KSPCG)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": alg, "avg_launch_ms": avg_ms, "launches": n_spmv,
-                         "format_bytes": fmt_bytes, "format_GBs": fmt_bytes / (avg_ms * 1e-3) / 1e9},
+            "roofline": roof,
         }
+        out.update(side)
 
     # second measurement: the same step with the box-aggregation multigrid preconditioner
     # behind the same KSP surface -- reported beside the CG/Jacobi headline as config.pc_mg.  At N>1 the
@@ -222,7 +275,7 @@ def main():
             threading.Thread(target=watchdog, daemon=True).start()
         mg_line = None
         try:
-            prob.ksp.set_from_options("-pc_type mg -pc_mg_type additive")
+            prob.ksp.set_from_options(f"-pc_type mg -pc_mg_type additive -mat_mult_type {args.mult}")
             for _ in range(args.warmup):
                 one_step()
             barrier()
@@ -238,7 +291,7 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 el = float(tt.item())
             mits = prob.ksp.get_iteration_number()
-            mg_line = {"options": "-ksp_type cg -pc_type mg -pc_mg_type additive", "value": ndof_global * args.steps / el,
+            mg_line = {"options": f"-ksp_type cg -pc_type mg -pc_mg_type additive -mat_mult_type {args.mult}", "value": ndof_global * args.steps / el,
                        "unit": "DOF/s", "ms_per_step": el / args.steps * 1e3, "cg_iterations": mits,
                        "converged_reason": prob.ksp.get_converged_reason(),
                        "ms_per_cg_iteration": ms_ / args.steps * 1e3 / max(mits, 1),

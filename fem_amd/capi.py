@@ -61,6 +61,8 @@ _SIGS = {
     "fem_mat_get_csr": [_h, _ip, _ip, _dp],
     "fem_mat_mult": [_h, _h, _h],
     "fem_mat_set_mult_type": [_h, C.c_char_p],
+    "fem_mat_set_profiling": [_h, C.c_int],
+    "fem_mat_get_profile": [_h, C.c_int, _ip, _dp, _dp, _dp],
     "fem_mat_get_diagonal": [_h, _h],
     "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
     "fem_vec_create": [_h, C.c_longlong, C.POINTER(_h)],
@@ -396,6 +398,16 @@ class Mat:
 
     def mult(self, x: Vec, y: Vec):
         _ck(_lib.fem_mat_mult(self.h, x.h, y.h))
+
+    def set_profiling(self, on: bool):
+        _ck(_lib.fem_mat_set_profiling(self.h, 1 if on else 0))
+
+    def get_profile(self, max_products: int):
+        """(n, element_ms, gather_ms, penalty_ms) summed over the first max_products EBE products."""
+        n = C.c_int(0)
+        a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
+        _ck(_lib.fem_mat_get_profile(self.h, int(max_products), C.byref(n), C.byref(a), C.byref(b), C.byref(c)))
+        return n.value, a.value, b.value, c.value
 
     def set_mult_type(self, kind: str):
         """'assembled' (sliced block-ELL SpMV) or 'ebe' (element-by-element recomputation)."""

@@ -20,6 +20,8 @@ void mesh_set_halo_impl(fem_mesh, fem_comm, int, const int*, const int*, const i
 fem_mat mat_create_impl(fem_mesh);
 void mat_assemble_elements_impl(fem_mat);
 void mat_set_mult_type_impl(fem_mat, const char*);
+void mat_set_profiling_impl(fem_mat, int);
+void mat_get_profile_impl(fem_mat, int, int*, double*, double*, double*);
 void mat_apply_kbc_impl(fem_mat, int, const int*);
 void mat_get_csr_impl(fem_mat, int*, int*, double*);
 void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
@@ -272,6 +274,22 @@ int fem_mat_set_mult_type(fem_mat A, const char* type)
     FEM_TRY
     FEM_CHECK(A && type, 1, "null argument");
     mat_set_mult_type_impl(A, type);
+    FEM_CATCH
+}
+
+int fem_mat_set_profiling(fem_mat A, int on)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_set_profiling_impl(A, on);
+    FEM_CATCH
+}
+
+int fem_mat_get_profile(fem_mat A, int max_products, int* n, double* element_ms, double* gather_ms, double* penalty_ms)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_get_profile_impl(A, max_products, n, element_ms, gather_ms, penalty_ms);
     FEM_CATCH
 }
 

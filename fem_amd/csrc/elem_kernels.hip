@@ -646,6 +646,12 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
     fem_mesh m = A->mesh;
     hipStream_t s = A->ctx->stream;
     double* part = partial ? partial : A->ebe_partial.p;
+    auto mark = [&] {   // profiling: one event before the element kernels and one after each stage
+        if (!A->profiling) return;
+        if (A->pev_used == A->pev.size()) { hipEvent_t e; FEM_HIP(hipEventCreate(&e)); A->pev.push_back(e); }
+        FEM_HIP(hipEventRecord(A->pev[A->pev_used++], s));
+    };
+    mark();
     EbeViews ev{};
     int off = 0;
     for (size_t gi = 0; gi < m->groups.size(); gi++) {
@@ -658,15 +664,42 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
         });
         off += (int)nb;
     }
+    mark();
     if (m->pdim == 3)
         hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p,
                            A->n2e.p, ev, y, done);
     else
         hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p,
                            A->n2e.p, ev, y, done);
+    mark();
     // launched also when there is no penalty row: the last partials must be written
     hipLaunchKernelGGL(k_ebe_penalty, dim3(EBE_BC_BLOCKS), dim3(256), 0, s, A->bc_saved ? A->nbc_dof : 0, A->bc_dof.p,
                        A->bc_shift.p, x, y, part + off, done);
+    mark();
+}
+
+void mat_set_profiling_impl(fem_mat A, int on)
+{
+    A->profiling = on != 0;
+    A->pev_used = 0;
+}
+// sums over the first `max_products` element-by-element products recorded since profiling was switched on
+void mat_get_profile_impl(fem_mat A, int max_products, int* n, double* element_ms, double* gather_ms, double* penalty_ms)
+{
+    A->ctx->bind();
+    const size_t have = A->pev_used / 4, take = std::min<size_t>(have, (size_t)std::max(max_products, 0));
+    double t[3] = {0.0, 0.0, 0.0};
+    if (take) FEM_HIP(hipEventSynchronize(A->pev[4 * take - 1]));
+    for (size_t k = 0; k < take; k++)
+        for (int j = 0; j < 3; j++) {
+            float ms = 0.f;
+            FEM_HIP(hipEventElapsedTime(&ms, A->pev[4 * k + j], A->pev[4 * k + j + 1]));
+            t[j] += ms;
+        }
+    if (n) *n = (int)take;
+    if (element_ms) *element_ms = t[0];
+    if (gather_ms) *gather_ms = t[1];
+    if (penalty_ms) *penalty_ms = t[2];
 }
 
 // FormElKE for a batch of elements given by their coordinates (host in/out)

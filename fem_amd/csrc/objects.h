@@ -87,6 +87,13 @@ struct fem_mat_s {
     fem::DBuf<double> bc_shift;
     int nbc_dof = 0;
     bool bc_saved = false;
+    // HIP-event profile of the element-by-element product (fem_mat_set_profiling): four events per product
+    bool profiling = false;
+    std::vector<hipEvent_t> pev;
+    size_t pev_used = 0;
+    ~fem_mat_s() {
+        for (auto e : pev) (void)hipEventDestroy(e);
+    }
 };
 
 struct fem_ksp_s;

@@ -339,6 +339,21 @@ module fem_amd_capi
       character(kind=c_char), intent(in) :: mtype(*)
       integer(c_int) :: ierr
     end function
+    function fem_mat_set_profiling(mat, on) bind(C, name="fem_mat_set_profiling") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: mat
+      integer(c_int), value :: on
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_get_profile(mat, max_products, n, element_ms, gather_ms, penalty_ms) &
+        bind(C, name="fem_mat_get_profile") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mat
+      integer(c_int), value :: max_products
+      integer(c_int), intent(out) :: n
+      real(c_double), intent(out) :: element_ms, gather_ms, penalty_ms
+      integer(c_int) :: ierr
+    end function
     function fem_mat_get_diagonal(mat, d) bind(C, name="fem_mat_get_diagonal") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: mat, d

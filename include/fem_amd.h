@@ -133,6 +133,11 @@ int fem_mat_get_csr(fem_mat mat, int *rowptr, int *colind, double *val);
  * matrix read; needs the usual assemble + ApplyKBC first, which also serve the preconditioners);
  * deterministic, about twice as fast as the SpMV on hex8 meshes.  Also `-mat_mult_type` of the KSP. */
 int fem_mat_set_mult_type(fem_mat mat, const char *type);
+/* HIP-event profile of the element-by-element product on the product's own stream: sums over the
+ * first `max_products` products since profiling was switched on (element kernels / node gather /
+ * penalty rows, in ms). */
+int fem_mat_set_profiling(fem_mat mat, int on);
+int fem_mat_get_profile(fem_mat mat, int max_products, int *n, double *element_ms, double *gather_ms, double *penalty_ms);
 /* MatMult: y = K x (sub-assembled product + halo sum when a halo is attached). */
 int fem_mat_mult(fem_mat mat, fem_vec x, fem_vec y);
 int fem_mat_get_diagonal(fem_mat mat, fem_vec d);

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "comm.h"
+#include "scan.h"
 #include "objects.h"
 
 using namespace fem;
@@ -493,21 +494,27 @@ template <int PD, int NPE, int NIP>
 __global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int* __restrict__ conn,
                                                    const double* __restrict__ coords, const double* __restrict__ Ev,
                                                    const double* __restrict__ nuv, const double* __restrict__ x,
-                                                   double* __restrict__ f, double* __restrict__ partial,
-                                                   const int* __restrict__ done)
+                                                   const unsigned char* __restrict__ donate, double* __restrict__ f,
+                                                   double* __restrict__ partial, const int* __restrict__ done)
 {
     if (done && *done) return;
+    constexpr bool PAIR = (NPE == 8 || (NPE == 4 && PD == 2));
     __shared__ double sh[4];
     const ElemTable& tab = c_tab[type];
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     double dot = 0.0;
+    double fe[NPE][PD];
+#pragma unroll
+    for (int a = 0; a < NPE; a++)
+#pragma unroll
+        for (int d = 0; d < PD; d++) fe[a][d] = 0.0;
     if (e < (size_t)nel) {
-        double X[NPE][PD], u[NPE][PD], fe[NPE][PD];
+        double X[NPE][PD], u[NPE][PD];
 #pragma unroll
         for (int a = 0; a < NPE; a++) {
             const size_t v = (size_t)conn[e * NPE + a];
 #pragma unroll
-            for (int d = 0; d < PD; d++) { X[a][d] = coords[v * PD + d]; u[a][d] = x[v * PD + d]; fe[a][d] = 0.0; }
+            for (int d = 0; d < PD; d++) { X[a][d] = coords[v * PD + d]; u[a][d] = x[v * PD + d]; }
         }
         const DCoef D = dmat_coef(Ev[e], nuv[e]);
 #pragma unroll
@@ -534,15 +541,89 @@ __global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int*
 #pragma unroll
         for (int a = 0; a < NPE; a++)
 #pragma unroll
+            for (int d = 0; d < PD; d++) dot += u[a][d] * fe[a][d];
+    }
+    // hand-over along the wavefront (every lane takes part in the cross-lane moves): the +x face forces
+    // of lane l-1 are added to the -x face nodes of lane l (same global nodes, checked at set-up), and
+    // lane l-1 does not store them
+    bool don = false;
+    if constexpr (PAIR) {
+        don = (e < (size_t)nel) && donate[e] != 0;
+        const bool recv = (__shfl_up((int)don, 1) != 0) && ((threadIdx.x & 63) != 0);
+        constexpr int NP = NPE / 2;
+        constexpr int plus8[4] = {1, 2, 5, 6}, minus8[4] = {0, 3, 4, 7};
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const int pa = plus8[k], ma = minus8[k];   // quad4 uses the first two pairs: (1,0) (2,3)
+#pragma unroll
             for (int d = 0; d < PD; d++) {
-                f[(size_t)(a * PD + d) * nel + e] = fe[a][d];   // component-major: consecutive elements, consecutive words
-                dot += u[a][d] * fe[a][d];
+                const double v = __shfl_up(fe[pa][d], 1);
+                if (recv) fe[ma][d] += v;
             }
+        }
+    }
+    if (e < (size_t)nel) {
+#pragma unroll
+        for (int a = 0; a < NPE; a++) {
+            if (PAIR && don && is_plus_x<NPE, PD>(a)) continue;
+#pragma unroll
+            for (int d = 0; d < PD; d++) f[(size_t)(a * PD + d) * nel + e] = fe[a][d];   // component-major: coalesced
+        }
     }
     for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// donate[e] = 1 when element e+1 sits in the next lane of the same wavefront and its -x face is e's +x face
+template <int NPE>
+__global__ void __launch_bounds__(256) k_ebe_mark_donors(int nel, const int* __restrict__ conn,
+                                                         unsigned char* __restrict__ donate)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    constexpr int NP = NPE / 2;
+    constexpr int plus8[4] = {1, 2, 5, 6}, minus8[4] = {0, 3, 4, 7};
+    bool ok = ((e & 63) != 63) && (e + 1 < nel);
+    if (ok)
+        for (int k = 0; k < NP; k++)
+            ok = ok && conn[(size_t)e * NPE + plus8[k]] == conn[(size_t)(e + 1) * NPE + minus8[k]];
+    donate[e] = ok ? 1 : 0;
+}
+struct DonateViews {
+    const unsigned char* d[4];
+    int npe[4], pdim;
+};
+__device__ __forceinline__ bool ebe_entry_kept(const DonateViews& dv, unsigned code)
+{
+    const int g = code >> 30;
+    const unsigned char* d = dv.d[g];
+    if (!d) return true;
+    const size_t e = (code & 0x3fffffffu) >> 3;
+    const int a = code & 7u;
+    const bool plus = (dv.npe[g] == 8) ? (a == 1 || a == 2 || a == 5 || a == 6) : (a == 1 || a == 2);
+    return !(plus && d[e]);
+}
+// gather lists without the handed-over entries: count, (scan), fill -- order of the sorted lists kept
+__global__ void __launch_bounds__(256) k_ebe_count_kept(int nn, const int* __restrict__ ptr, const unsigned* __restrict__ lst,
+                                                        DonateViews dv, int* __restrict__ cnt)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    int c = 0;
+    for (int k = ptr[v]; k < ptr[v + 1]; k++) c += ebe_entry_kept(dv, lst[k]) ? 1 : 0;
+    cnt[v] = c;
+}
+__global__ void __launch_bounds__(256) k_ebe_fill_kept(int nn, const int* __restrict__ ptr, const unsigned* __restrict__ lst,
+                                                       DonateViews dv, const int* __restrict__ ptr2,
+                                                       unsigned* __restrict__ lst2)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    int o = ptr2[v];
+    for (int k = ptr[v]; k < ptr[v + 1]; k++)
+        if (ebe_entry_kept(dv, lst[k])) lst2[o++] = lst[k];
 }
 
 struct EbeViews {
@@ -628,8 +709,39 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
             A->n2e_sorted = true;
         }
         A->ebe_f.resize(m->groups.size());
-        for (size_t g = 0; g < m->groups.size(); g++)
-            A->ebe_f[g].alloc((size_t)m->groups[g].nel * m->groups[g].npe * m->pdim);
+        A->ebe_donate.resize(m->groups.size());
+        DonateViews dv{};
+        dv.pdim = m->pdim;
+        for (size_t g = 0; g < m->groups.size(); g++) {
+            auto& grp = m->groups[g];
+            A->ebe_f[g].alloc((size_t)grp.nel * grp.npe * m->pdim);
+            dv.npe[g] = grp.npe; dv.d[g] = nullptr;
+            if (grp.type == FEM_HEX || grp.type == FEM_QUA) {
+                A->ebe_donate[g].alloc((size_t)grp.nel);
+                if (grp.type == FEM_HEX)
+                    hipLaunchKernelGGL(k_ebe_mark_donors<8>, dim3(cdiv((size_t)grp.nel, 256)), dim3(256), 0, s, grp.nel,
+                                       grp.conn.p, A->ebe_donate[g].p);
+                else
+                    hipLaunchKernelGGL(k_ebe_mark_donors<4>, dim3(cdiv((size_t)grp.nel, 256)), dim3(256), 0, s, grp.nel,
+                                       grp.conn.p, A->ebe_donate[g].p);
+                dv.d[g] = A->ebe_donate[g].p;
+            }
+        }
+        {
+            const int nn = m->nnds;
+            DBuf<int> cnt((size_t)nn), tmp(exclusive_scan_tmp_ints((size_t)nn + 1));
+            hipLaunchKernelGGL(k_ebe_count_kept, dim3(cdiv((size_t)nn, 256)), dim3(256), 0, s, nn, A->n2e_ptr.p, A->n2e.p, dv,
+                               cnt.p);
+            A->ebe_ptr.alloc((size_t)nn + 1);
+            exclusive_scan_i32(cnt.p, A->ebe_ptr.p, nn, tmp.p, s);
+            int tot = 0;
+            FEM_HIP(hipMemcpyAsync(&tot, A->ebe_ptr.p + nn, sizeof(int), hipMemcpyDeviceToHost, s));
+            FEM_HIP(hipStreamSynchronize(s));
+            A->ebe_lst.alloc((size_t)std::max(tot, 1));
+            hipLaunchKernelGGL(k_ebe_fill_kept, dim3(cdiv((size_t)nn, 256)), dim3(256), 0, s, nn, A->n2e_ptr.p, A->n2e.p, dv,
+                               A->ebe_ptr.p, A->ebe_lst.p);
+            FEM_HIP(hipStreamSynchronize(s));   // cnt, tmp go out of scope
+        }
         A->ebe_grid = ebe_blocks(m);
         A->ebe_partial.alloc((size_t)A->ebe_grid);
         FEM_HIP(hipGetLastError());
@@ -660,17 +772,17 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
         const unsigned nb = cdiv((size_t)g.nel, 256);
         dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto) {
             hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP()>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
-                               m->coords.p, g.E.p, g.nu.p, x, A->ebe_f[gi].p, part + off, done);
+                               m->coords.p, g.E.p, g.nu.p, x, A->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
         });
         off += (int)nb;
     }
     mark();
     if (m->pdim == 3)
-        hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p,
-                           A->n2e.p, ev, y, done);
+        hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->ebe_ptr.p,
+                           A->ebe_lst.p, ev, y, done);
     else
-        hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p,
-                           A->n2e.p, ev, y, done);
+        hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->ebe_ptr.p,
+                           A->ebe_lst.p, ev, y, done);
     mark();
     // launched also when there is no penalty row: the last partials must be written
     hipLaunchKernelGGL(k_ebe_penalty, dim3(EBE_BC_BLOCKS), dim3(256), 0, s, A->bc_saved ? A->nbc_dof : 0, A->bc_dof.p,

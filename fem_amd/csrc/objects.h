@@ -80,6 +80,11 @@ struct fem_mat_s {
     // MatMult by element-by-element recomputation (`-mat_mult_type ebe`, elem_kernels.hip)
     bool mult_ebe = false;
     std::vector<fem::DBuf<double>> ebe_f;   // per element group: nodal forces [npe*pdim][nel]
+    // hex8 / quad4: an element whose +x face is the -x face of the next element of the same wavefront
+    // hands those forces over by a cross-lane move instead of storing them (halves the buffer traffic)
+    std::vector<fem::DBuf<unsigned char>> ebe_donate;   // per group [nel]
+    fem::DBuf<int> ebe_ptr;                 // gather lists without the handed-over entries
+    fem::DBuf<unsigned> ebe_lst;
     fem::DBuf<double> ebe_partial;          // internal p.Kp partials when the caller wants none
     int ebe_grid = 0;                       // workgroups of all element groups + those of the penalty rows
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)

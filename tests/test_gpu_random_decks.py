@@ -11,8 +11,11 @@ from fem_amd.mesh import Mesh, structured_hex, structured_quad, hex_to_tets, qua
 pytestmark = pytest.mark.gpu
 
 SOLVERS = ["-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14",
+           "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14 -mat_mult_type ebe",          # bench.py's headline configuration
            "-ksp_type cg -pc_type mg -pc_mg_type additive -ksp_rtol 1e-14",
+           "-ksp_type cg -pc_type mg -pc_mg_type additive -ksp_rtol 1e-14 -mat_mult_type ebe",
            "-ksp_type cg -pc_type mg -ksp_rtol 1e-14",
+           "-ksp_type cg -pc_type mg -ksp_rtol 1e-14 -mat_mult_type ebe",
            "-ksp_type preonly -pc_type lu"]
 
 
@@ -97,7 +100,8 @@ def test_random_deck_partitioned(oracle, seed):
     nl2g = [p[1] for p in parts]
     ug, sg, its = oracle.run(m, "lu")
     nsteps, pd = len(its), m.pdim
-    for opts in ("-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14", "-ksp_type cg -pc_type mg -pc_mg_type additive -ksp_rtol 1e-14",
+    for opts in ("-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14", "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14 -mat_mult_type ebe",
+                 "-ksp_type cg -pc_type mg -pc_mg_type additive -ksp_rtol 1e-14 -mat_mult_type ebe",
                  "-ksp_type cg -pc_type mg -ksp_rtol 1e-14"):
         ctxs = [capi.Context(0) for _ in range(world)]
         comms = capi.Comm.local_group(ctxs)

@@ -643,45 +643,45 @@ __global__ void __launch_bounds__(256) k_sort_n2e(int nn, const int* __restrict_
         lst[j + 1] = c;
     }
 }
+// thread = node: ordered sum of the buffer entries of the incident elements, then the node's penalty rows
+// (y_i += shift_i x_i, their share of x.Kx into one partial per workgroup)
 template <int PD>
 __global__ void __launch_bounds__(256) k_ebe_gather(int nn, const int* __restrict__ ptr, const unsigned* __restrict__ lst,
-                                                    EbeViews ev, double* __restrict__ y, const int* __restrict__ done)
-{
-    if (done && *done) return;
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nn) return;
-    double s[PD];
-#pragma unroll
-    for (int d = 0; d < PD; d++) s[d] = 0.0;
-    for (int k = ptr[v]; k < ptr[v + 1]; k++) {
-        const unsigned code = lst[k];
-        const int g = code >> 30;
-        const size_t e = (code & 0x3fffffffu) >> 3, a = code & 7u, ne = (size_t)ev.nel[g];
-#pragma unroll
-        for (int d = 0; d < PD; d++) s[d] += ev.f[g][(a * PD + d) * ne + e];
-    }
-#pragma unroll
-    for (int d = 0; d < PD; d++) y[(size_t)v * PD + d] = s[d];
-}
-// penalty rows: y_i += shift_i x_i ; their share of x.Kx goes to EBE_BC_BLOCKS extra partials
-// (config 3 has 135 k constrained dofs: one workgroup would need 190 us for them)
-constexpr int EBE_BC_BLOCKS = 64;
-__global__ void __launch_bounds__(256) k_ebe_penalty(int n, const int* __restrict__ dof, const double* __restrict__ shift,
-                                                     const double* __restrict__ x, double* __restrict__ y,
-                                                     double* __restrict__ partial, const int* __restrict__ done)
+                                                    EbeViews ev, const int* __restrict__ bc_node,
+                                                    const int* __restrict__ bc_dof, const double* __restrict__ bc_shift,
+                                                    const double* __restrict__ x, double* __restrict__ y,
+                                                    double* __restrict__ partial, const int* __restrict__ done)
 {
     if (done && *done) return;
     __shared__ double sh[4];
-    double s = 0.0;
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const int i = dof[k];
-        if (i < 0) continue;
-        const double xi = x[i], t = shift[k] * xi;
-        y[i] += t;
-        s += t * xi;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    double pen = 0.0;
+    if (v < nn) {
+        double s[PD];
+#pragma unroll
+        for (int d = 0; d < PD; d++) s[d] = 0.0;
+        for (int k = ptr[v]; k < ptr[v + 1]; k++) {
+            const unsigned code = lst[k];
+            const int g = code >> 30;
+            const size_t e = (code & 0x3fffffffu) >> 3, a = code & 7u, ne = (size_t)ev.nel[g];
+#pragma unroll
+            for (int d = 0; d < PD; d++) s[d] += ev.f[g][(a * PD + d) * ne + e];
+        }
+        const int kb = bc_node ? bc_node[v] : -1;
+        if (kb >= 0) {
+#pragma unroll
+            for (int d = 0; d < PD; d++)
+                if (bc_dof[kb + d] >= 0) {
+                    const double xi = x[(size_t)v * PD + d], t = bc_shift[kb + d] * xi;
+                    s[d] += t;
+                    pen += t * xi;
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < PD; d++) y[(size_t)v * PD + d] = s[d];
     }
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    for (int o = 32; o > 0; o >>= 1) pen += __shfl_down(pen, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = pen;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
@@ -690,7 +690,7 @@ static int ebe_blocks(const fem_mesh m)
 {
     int nb = 0;
     for (auto& g : m->groups) nb += (int)cdiv((size_t)g.nel, 256);
-    return nb + EBE_BC_BLOCKS;
+    return nb + (int)cdiv((size_t)m->nnds, 256);   // element workgroups + gather workgroups (penalty rows)
 }
 
 void mat_set_mult_type_impl(fem_mat A, const char* type)
@@ -777,17 +777,15 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
         off += (int)nb;
     }
     mark();
+    const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
     if (m->pdim == 3)
         hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->ebe_ptr.p,
-                           A->ebe_lst.p, ev, y, done);
+                           A->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
     else
         hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->ebe_ptr.p,
-                           A->ebe_lst.p, ev, y, done);
+                           A->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
     mark();
-    // launched also when there is no penalty row: the last partials must be written
-    hipLaunchKernelGGL(k_ebe_penalty, dim3(EBE_BC_BLOCKS), dim3(256), 0, s, A->bc_saved ? A->nbc_dof : 0, A->bc_dof.p,
-                       A->bc_shift.p, x, y, part + off, done);
-    mark();
+    mark();   // (the penalty rows used to be a stage of their own: the profile keeps its four marks per product)
 }
 
 void mat_set_profiling_impl(fem_mat A, int on)

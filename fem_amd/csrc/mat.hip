@@ -222,7 +222,8 @@ __global__ void __launch_bounds__(256) k_apply_kbc(int nbcs, const int* __restri
                                                    const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                    const int* __restrict__ bcol, double* __restrict__ val,
                                                    const unsigned char* __restrict__ owned, double penalty,
-                                                   int* __restrict__ bc_dof, double* __restrict__ bc_shift)
+                                                   int* __restrict__ bc_dof, double* __restrict__ bc_shift,
+                                                   int* __restrict__ bc_node)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbcs) return;
@@ -240,6 +241,7 @@ __global__ void __launch_bounds__(256) k_apply_kbc(int nbcs, const int* __restri
         if (bc_dof) {   // first application after an assembly: remember what the INSERT replaces
             bc_dof[(size_t)i * BS + r] = fixed ? row * BS + r : -1;
             bc_shift[(size_t)i * BS + r] = fixed ? pv - *d : 0.0;
+            if (r == 0) bc_node[row] = i * BS;
         }
         if (fixed) *d = pv;
     }
@@ -377,16 +379,18 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs, const int* bcnode)
     if (!A->bc_saved) {
         A->nbc_dof = nbcs * pd;
         A->bc_dof.alloc((size_t)A->nbc_dof); A->bc_shift.alloc((size_t)A->nbc_dof);
+        A->bc_node.alloc((size_t)A->nbrows);
+        FEM_HIP(hipMemsetAsync(A->bc_node.p, 0xff, sizeof(int) * (size_t)A->nbrows, s));   // -1 everywhere
         bcd = A->bc_dof.p; bcs = A->bc_shift.p;
     } else {
         FEM_CHECK(A->nbc_dof == nbcs * pd, 5, "fem_mat_apply_kbc: a different constraint list needs a fresh assembly");
     }
     if (pd == 3)
         hipLaunchKernelGGL(k_apply_kbc<3>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs);
+                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, A->bc_node.p);
     else
         hipLaunchKernelGGL(k_apply_kbc<2>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs);
+                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, A->bc_node.p);
     A->bc_saved = true;
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));

@@ -90,6 +90,7 @@ struct fem_mat_s {
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
     fem::DBuf<int> bc_dof;
     fem::DBuf<double> bc_shift;
+    fem::DBuf<int> bc_node;                 // [nbrows] offset of a node's rows in bc_dof/bc_shift, or -1
     int nbc_dof = 0;
     bool bc_saved = false;
     // HIP-event profile of the element-by-element product (fem_mat_set_profiling): four events per product

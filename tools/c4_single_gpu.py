@@ -17,7 +17,7 @@ for name in names:
     t0 = time.perf_counter()
     m = structured_hex(*shapes[name])
     print(f"{name}: mesh {shapes[name]} built on the host in {time.perf_counter()-t0:.1f} s, ndof {m.ndof}", flush=True)
-    for pc in ("jacobi", "mg -pc_mg_type additive"):
+    for pc in ("jacobi", "jacobi -mat_mult_type ebe", "mg -pc_mg_type additive", "mg -pc_mg_type additive -mat_mult_type ebe"):
         prob = driver.Problem(ctx, m, f"-pc_type {pc} -ksp_rtol 1e-9")
         ctx.synchronize(); t0 = time.perf_counter()
         prob.assemble(); prob.ksp.set_up(); ctx.synchronize()

@@ -78,6 +78,21 @@ def test_fortran_driver_with_the_reference_solver_options(tmp_path, oracle):
     assert np.abs(full[:, 2:] - np.array([105.0, 245.0, 0.0])).max() < 1e-9
 
 
+def test_fortran_driver_with_the_element_by_element_product(tmp_path, oracle):
+    """`-mat_mult_type ebe` through the Fortran driver on the mixed tri+qua deck (forces over a time window,
+    several increments): same answer as the oracle."""
+    _need(EXE)
+    deck = os.path.join(ROOT, "tests", "golden", "decks", "lin_two_quads_qs.inp")
+    p = subprocess.run([EXE, "-f", deck, "-ksp_rtol", "1e-14", "-mat_mult_type", "ebe", "-o", str(tmp_path / "0_output")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    full = np.loadtxt(tmp_path / "0_output_000000.full.txt", skiprows=1)
+    from fem_amd.inp import read_inp
+    uo, so, _ = oracle.run(read_inp(deck), "lu")
+    assert np.abs(full[:, :2].ravel() - uo).max() <= 1e-10 * np.abs(uo).max()
+    assert np.abs(full[:, 2:] - so).max() <= 1e-9 * np.abs(so).max()
+
+
 def test_plain_c_client_of_the_abi(tmp_path):
     """include/fem_amd.h consumed by gcc as C99 (no C++ types leak through the boundary)."""
     exe = tmp_path / "abi_smoke"

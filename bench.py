@@ -31,9 +31,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # same figure for vector fp64 and for the f64 MFMA (the guide has no fp64 row of its own)
 FP64_PEAK_TFLOPS = 78.6
 # Element-by-element hex8 product, flops per element as coded in k_ebe_apply (FMA = 2), 8 Gauss points:
-# J 144 + adjugate/det/inverse 42 + dN/dx 144 + grad u 144 + strain/stress 26 + B^T sigma 144 = 644 per
-# point, plus 48 for x_e.f_e  
-EBE_FLOPS_PER_HEX8 = 8 * 644 + 48
+# J 144 + G 144 (reference gradients of coordinates and x) + adjugate/det/inverse 42 + H = J^-1 G 54 +
+# strain/stress 28 + T = sigma J^-1 54 + f_a += T dNxi_a 144 = 610 per point, plus 48 for x_e.f_e
+# 
+EBE_FLOPS_PER_HEX8 = 8 * 610 + 48
 
 
 def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:

@@ -519,24 +519,84 @@ __global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int*
         const DCoef D = dmat_coef(Ev[e], nuv[e]);
 #pragma unroll
         for (int q = 0; q < NIP; q++) {
-            constexpr int CP = (PD == 2) ? 3 : 6;
-            double dN[NPE][PD], detj, sig[CP];
-            dndx_at_gp<PD, NPE>(tab.dNxi[q], X, dN, detj);
-            gp_stress<PD, NPE>(dN, u, D, sig);
-            const double wd = tab.w[q] * detj;
+            // Everything in reference coordinates, so that dN/dx (npe*pdim values per point) is never formed:
+            //   J = dNxi X, G = dNxi x_e (reference gradients), H = grad_x u = J^-1 G, sigma = D eps(H),
+            //   T = w detJ sigma J^-1, f_a += T dNxi_a.  The dNxi are wave-uniform (scalar registers).
+            double J[PD][PD], G[PD][PD];     // J[i][j] = d x_j / d xi_i,  G[i][l] = d u_l / d xi_i
 #pragma unroll
-            for (int c = 0; c < CP; c++) sig[c] *= wd;
+            for (int i = 0; i < PD; i++)
 #pragma unroll
-            for (int a = 0; a < NPE; a++) {
-                if constexpr (PD == 2) {   // Voigt xx, yy, xy
-                    fe[a][0] += dN[a][0] * sig[0] + dN[a][1] * sig[2];
-                    fe[a][1] += dN[a][1] * sig[1] + dN[a][0] * sig[2];
-                } else {                   // Voigt xx, yy, zz, xy, yz, zx
-                    fe[a][0] += dN[a][0] * sig[0] + dN[a][1] * sig[3] + dN[a][2] * sig[5];
-                    fe[a][1] += dN[a][1] * sig[1] + dN[a][0] * sig[3] + dN[a][2] * sig[4];
-                    fe[a][2] += dN[a][2] * sig[2] + dN[a][1] * sig[4] + dN[a][0] * sig[5];
+                for (int j = 0; j < PD; j++) {
+                    double sj = 0.0, sg = 0.0;
+#pragma unroll
+                    for (int a = 0; a < NPE; a++) { sj += tab.dNxi[q][i][a] * X[a][j]; sg += tab.dNxi[q][i][a] * u[a][j]; }
+                    J[i][j] = sj; G[i][j] = sg;
                 }
+            double inv[PD][PD], detj;        // inv[i][j] = d xi_j / d x_i, as in dndx_at_gp
+            if constexpr (PD == 2) {
+                detj = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+                const double rd = 1.0 / detj;
+                inv[0][0] = J[1][1] * rd; inv[0][1] = -J[0][1] * rd;
+                inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+            } else {
+                const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+                const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
+                const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+                detj = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+                const double rd = 1.0 / detj;
+                inv[0][0] = c00 * rd;
+                inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+                inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+                inv[1][0] = -c01 * rd;
+                inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+                inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+                inv[2][0] = c02 * rd;
+                inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+                inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
             }
+            double H[PD][PD];                // H[l][i] = d u_l / d x_i
+#pragma unroll
+            for (int l = 0; l < PD; l++)
+#pragma unroll
+                for (int i = 0; i < PD; i++) {
+                    double h = 0.0;
+#pragma unroll
+                    for (int j = 0; j < PD; j++) h += inv[i][j] * G[j][l];
+                    H[l][i] = h;
+                }
+            const double wd = tab.w[q] * detj;   // weights(i)*detj, src/m_local.F90:64
+            double S[PD][PD];                // stress (DMat, src/m_local.F90:204; Voigt order of BMat :160-168) * w detJ
+            if constexpr (PD == 2) {
+                S[0][0] = wd * (D.d11 * H[0][0] + D.d12 * H[1][1]);
+                S[1][1] = wd * (D.d12 * H[0][0] + D.d11 * H[1][1]);
+                S[0][1] = S[1][0] = wd * D.d44 * (H[0][1] + H[1][0]);
+            } else {
+                S[0][0] = wd * (D.d11 * H[0][0] + D.d12 * H[1][1] + D.d12 * H[2][2]);
+                S[1][1] = wd * (D.d12 * H[0][0] + D.d11 * H[1][1] + D.d12 * H[2][2]);
+                S[2][2] = wd * (D.d12 * H[0][0] + D.d12 * H[1][1] + D.d11 * H[2][2]);
+                S[0][1] = S[1][0] = wd * D.d44 * (H[0][1] + H[1][0]);
+                S[1][2] = S[2][1] = wd * D.d44 * (H[1][2] + H[2][1]);
+                S[0][2] = S[2][0] = wd * D.d44 * (H[2][0] + H[0][2]);
+            }
+            double T[PD][PD];                // T[l][j] = sum_i S[l][i] inv[i][j]
+#pragma unroll
+            for (int l = 0; l < PD; l++)
+#pragma unroll
+                for (int j = 0; j < PD; j++) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int i = 0; i < PD; i++) t += S[l][i] * inv[i][j];
+                    T[l][j] = t;
+                }
+#pragma unroll
+            for (int a = 0; a < NPE; a++)
+#pragma unroll
+                for (int l = 0; l < PD; l++) {
+                    double t = fe[a][l];
+#pragma unroll
+                    for (int j = 0; j < PD; j++) t += T[l][j] * tab.dNxi[q][j][a];
+                    fe[a][l] = t;
+                }
         }
 #pragma unroll
         for (int a = 0; a < NPE; a++)

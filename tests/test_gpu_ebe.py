@@ -107,3 +107,28 @@ def test_ebe_full_size_config3(gpu_ctx):
         prob.destroy()
     assert abs(out["ebe"][1] - out["assembled"][1]) <= 2
     assert np.abs(out["ebe"][0] - out["assembled"][0]).max() <= 1e-7 * np.abs(out["assembled"][0]).max()
+
+
+@pytest.mark.parametrize("opts", ["-pc_type jacobi", "-pc_type mg -pc_mg_type additive"])
+def test_ebe_eight_domains_medium_size(opts):
+    """The layout of config 4 (2x2x2 bricks) at 32^3 elements per brick, element-by-element product, against
+    the undivided mesh on one context: same iteration count (+-2) and the same field; interface copies
+    bitwise identical."""
+    from tests.test_gpu_multidomain import _run_domains
+    world, npr = 8, (32, 32, 32)
+    full = f"-mat_mult_type ebe {opts} -ksp_rtol 1e-11"
+    grid, out = _run_domains(world, npr, 0.1, full)
+    g = structured_hex(*(grid[d] * npr[d] for d in range(3)), jitter=0.1)
+    ctx = capi.Context(0)
+    single = driver.run(g, full, ctx=ctx, recover_stress=False)
+    ctx.destroy()
+    ug = single.aggregate_u.reshape(-1, 3)
+    for r, (u, s, its, reason, y, gid) in enumerate(out):
+        assert reason == 2
+        assert abs(its - single.its[-1]) <= 2
+        assert np.abs(u.reshape(-1, 3) - ug[gid]).max() <= 1e-8 * np.abs(ug).max()
+    for r in range(world):
+        for q in range(r + 1, world):
+            common, ir, iq = np.intersect1d(out[r][5], out[q][5], return_indices=True)
+            if common.size:
+                assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])

@@ -281,6 +281,7 @@ struct fem_ksp_s {
     std::unique_ptr<fem::BandCholesky> direct;   // -ksp_type preonly -pc_type lu|cholesky
     bool mg_additive = false;
     double mg_box = 4.0;                     // level-1 box edge in mean node spacings
+    int mg_slice_min = 32768;
     double mg_alpha = -1.0, mg_omega = 0.7;  // alpha < 0: default (1.5 over-correction for the additive form, 1 for the V-cycle)
     DBuf<KspState> state;
     KspState* h_state = nullptr;  // pinned, two poll slots
@@ -325,7 +326,8 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         }
         else if (key == "-pc_mg_alpha") { is >> k->mg_alpha; }     // coarse-correction scaling (over-correction)
         else if (key == "-pc_mg_box") { is >> k->mg_box; FEM_CHECK(k->mg_box >= 2.0 && k->mg_box <= 16.0, 6, "-pc_mg_box must lie in [2, 16]"); }
-        else if (key == "-pc_mg_omega") { is >> k->mg_omega; }     // Jacobi damping of the smoother
+        else if (key == "-pc_mg_omega") { is >> k->mg_omega; }
+        else if (key == "-pc_mg_slice_min") { is >> k->mg_slice_min; }   // partitioned meshes: see mg.h     // Jacobi damping of the smoother
         else if (key == "-mat_mult_type") {
             is >> val;
             FEM_CHECK(val == "assembled" || val == "ebe", 6, "unsupported -mat_mult_type " + val + " (assembled|ebe)");
@@ -385,6 +387,7 @@ void ksp_set_up_impl(fem_ksp k)
         k->mg->alpha = (k->mg_alpha > 0.0) ? k->mg_alpha : (k->mg_additive ? 1.5 : 1.0);
         k->mg->omega = k->mg_omega;
         k->mg->box = k->mg_box;
+        k->mg->slice_min = k->mg_slice_min;
         k->mg->setup(A);
         k->z.alloc(n);
     }

@@ -37,6 +37,7 @@ struct Multigrid {
     double omega = 0.7, alpha = 1.5;   // upper bound of the fine-level Jacobi damping (V-cycle form); scaling of the coarse correction
     double omega_fine = 0.7, lambda_fine = 0.0;   // damping actually used: min(omega, 1.6 / lambda_max estimate)
     double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
+    int slice_min = 32768;          // partitioned mesh: split the level-1 residuals among the domains from this many boxes on (-pc_mg_slice_min)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     DBuf<int> agg;                  // [nn] level-1 box of every node

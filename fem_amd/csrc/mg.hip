@@ -431,13 +431,14 @@ __global__ void __launch_bounds__(256) k_level_dinv(int nb, const double* __rest
 
 // x_b = omega * Dinv_b r_b      and      x_b += omega * Dinv_b t_b   (t already holds r - A x)
 // omega is read from device memory: it comes from the eigenvalue estimate of the set-up
+// (boxes b0 .. b1-1 only: a partitioned run splits the level-1 work among the domains)
 template <int CS, bool ADD>
-__global__ void __launch_bounds__(256) k_block_smooth(int nb, const double* __restrict__ omega,
+__global__ void __launch_bounds__(256) k_block_smooth(int nb, int b0, int b1, const double* __restrict__ omega,
                                                       const double* __restrict__ dinv, const double* __restrict__ r,
                                                       double* __restrict__ x)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+    const int b = b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= b1) return;
     const double om = omega ? *omega : 1.0;
     double v[CS];
 #pragma unroll
@@ -488,13 +489,14 @@ __global__ void k_set_omega(const double* __restrict__ n2, double* __restrict__ 
 // ---- cycle kernels ------------------------------------------------------------------------------------
 // t = r - A x on a box level (27-point block stencil, thread per box)
 template <int CS>
-__global__ void __launch_bounds__(256) k_box_residual(Grid3 g, const double* __restrict__ st, const double* __restrict__ x,
-                                                      const double* __restrict__ r, double* __restrict__ t)
+__global__ void __launch_bounds__(256) k_box_residual(Grid3 g, int b0, int b1, const double* __restrict__ st,
+                                                      const double* __restrict__ x, const double* __restrict__ r,
+                                                      double* __restrict__ t)
 {
     constexpr int CC = CS * CS;
     const int nb = g.nb();
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
+    const int b = b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= b1) return;
     double acc[CS];
 #pragma unroll
     for (int q = 0; q < CS; q++) acc[q] = r[(size_t)b * CS + q];
@@ -513,14 +515,15 @@ __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, const double* __r
 // same for the small levels, which are latency-bound with one thread per box: 32 lanes per
 // box (one stencil slot each, 27 active), fixed shuffle tree over the slots
 template <int CS>
-__global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, const double* __restrict__ st,
+__global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, int b0, int b1, const double* __restrict__ st,
                                                             const double* __restrict__ x, const double* __restrict__ r,
                                                             double* __restrict__ t)
 {
     constexpr int CC = CS * CS;
-    const int nb = g.nb();
+    const int nb = b1;   // boxes b0 .. b1-1 (the stencil arrays keep the stride of the whole level)
+    const int nball = g.nb();
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int b = gid >> 5, s = gid & 31;
+    const int b = b0 + (gid >> 5), s = gid & 31;
     double acc[CS];
 #pragma unroll
     for (int q = 0; q < CS; q++) acc[q] = 0.0;
@@ -529,7 +532,7 @@ __global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, const doubl
 #pragma unroll
         for (int q = 0; q < CS; q++)
 #pragma unroll
-            for (int p = 0; p < CS; p++) acc[q] -= st[((size_t)s * CC + q * CS + p) * nb + b] * x[(size_t)c * CS + p];
+            for (int p = 0; p < CS; p++) acc[q] -= st[((size_t)s * CC + q * CS + p) * nball + b] * x[(size_t)c * CS + p];
     }
 #pragma unroll
     for (int q = 0; q < CS; q++)
@@ -538,6 +541,15 @@ __global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, const doubl
 #pragma unroll
         for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = r[(size_t)b * CS + q] + acc[q];
     }
+}
+
+// v[i] = 0 for the entries of the boxes outside b0 .. b1-1 (before the all-reduce that re-unites the slices)
+__global__ void __launch_bounds__(256) k_zero_outside(size_t n, size_t i0, size_t i1, double* __restrict__ v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st)
+        if (i < i0 || i >= i1) v[i] = 0.0;
 }
 
 // x = omega * dinv * r
@@ -950,8 +962,8 @@ static bool setup_t(Multigrid& mg)
         const int npow = 12;
         for (int it = 0; it < npow; it++) {
             if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2);
-            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, gl, L.st.p, L.x.p, L.r.p, L.t.p);
-            hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, (const double*)nullptr,
+            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, gl, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p);
+            hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, (const double*)nullptr,
                                L.dinv.p, L.t.p, L.x.p);
         }
         hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2 + 1);
@@ -1022,25 +1034,45 @@ static void cycle_t(Multigrid& mg, size_t l)
         hipLaunchKernelGGL(k_dense_apply, dim3(g1(n * 64)), dim3(256), 0, s, (int)n, mg.cinv.p, L.r.p, L.x.p);
         return;
     }
+    // Partitioned mesh: the hierarchy is replicated, but the two residuals of level 1 -- its only expensive
+    // kernels -- are split among the domains (contiguous box ranges).  The pointwise kernels (smoothing
+    // from r, prolongation) stay replicated, so every domain has x on the neighbours of its slice without
+    // any exchange; the restricted residual of level 2 is all-reduced (1/8 of a level-1 vector), and one
+    // all-reduce of x (zero outside the slices) re-unites the last smoothing step.
+    Halo* halo = mg.A->mesh->halo.get();
+    Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
+    const bool sliced = comm && l == 0 && L.nb >= mg.slice_min;   // small levels: two more all-reduces cost more than they save
+    int b0 = 0, b1 = L.nb;
+    if (sliced) {
+        b0 = (int)((long long)L.nb * comm->rank / comm->size);
+        b1 = (int)((long long)L.nb * (comm->rank + 1) / comm->size);
+    }
+    const int nbs = b1 - b0;
     auto residual = [&] {   // small levels: 32 lanes per box (latency), large ones: one thread per box (bandwidth)
-        if (L.nb <= 16384)
-            hipLaunchKernelGGL(k_box_residual_slots<CS>, dim3(g1((size_t)L.nb * 32)), dim3(256), 0, s, g, L.st.p, L.x.p,
-                               L.r.p, L.t.p);
+        if (nbs <= 16384)
+            hipLaunchKernelGGL(k_box_residual_slots<CS>, dim3(g1((size_t)std::max(nbs, 1) * 32)), dim3(256), 0, s, g, b0, b1,
+                               L.st.p, L.x.p, L.r.p, L.t.p);
         else
-            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, L.st.p, L.x.p, L.r.p, L.t.p);
+            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(nbs)), dim3(256), 0, s, g, b0, b1, L.st.p, L.x.p, L.r.p, L.t.p);
     };
     MgLevel& C = mg.lev[l + 1];
     const Grid3 gc = grid_of(C);
-    hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, mg.omega_l.p + l, L.dinv.p, L.r.p,
-                       L.x.p);
+    hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, mg.omega_l.p + l, L.dinv.p,
+                       L.r.p, L.x.p);
+    if (sliced) L.t.zero(s);                 // the restriction below sums over all children: foreign ones count 0
     residual();
     hipLaunchKernelGGL(k_restrict_box<CS>, dim3(g1(C.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), L.t.p, C.r.p);
+    if (sliced) comm->allreduce_sum(C.r.p, C.nb * CS, s);
     cycle_t<CS>(mg, l + 1);
     hipLaunchKernelGGL(k_prolong_box<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), mg.alpha, C.x.p,
                        L.x.p);
     residual();
-    hipLaunchKernelGGL((k_block_smooth<CS, true>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, mg.omega_l.p + l, L.dinv.p, L.t.p,
-                       L.x.p);
+    hipLaunchKernelGGL((k_block_smooth<CS, true>), dim3(g1(std::max(nbs, 1))), dim3(256), 0, s, L.nb, b0, b1, mg.omega_l.p + l,
+                       L.dinv.p, L.t.p, L.x.p);
+    if (sliced) {
+        hipLaunchKernelGGL(k_zero_outside, dim3(gs(n)), dim3(256), 0, s, n, (size_t)b0 * CS, (size_t)b1 * CS, L.x.p);
+        comm->allreduce_sum(L.x.p, (int)n, s);
+    }
 }
 
 template <int BS, int PD>

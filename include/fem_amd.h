@@ -182,7 +182,7 @@ int fem_ksp_set_pc_type(fem_ksp ksp, const char *type);
 int fem_ksp_set_tolerances(fem_ksp ksp, double rtol, double abstol, double dtol, int maxits);
 /* KSPSetFromOptions :377: parses "-ksp_type cg|preonly -pc_type jacobi|none|mg|gamg|lu|cholesky
  * -ksp_rtol 1e-12 -ksp_atol .. -ksp_divtol .. -ksp_max_it .. -pc_mg_type multiplicative|additive
- * -pc_mg_alpha .. -pc_mg_omega .. -pc_mg_box .. -mat_mult_type assembled|ebe" */
+ * -pc_mg_alpha .. -pc_mg_omega .. -pc_mg_box .. -pc_mg_slice_min .. -mat_mult_type assembled|ebe" */
 int fem_ksp_set_from_options(fem_ksp ksp, const char *options);
 int fem_ksp_set_up(fem_ksp ksp);                            /* KSPSetUp :378 */
 int fem_ksp_solve(fem_ksp ksp, fem_vec b, fem_vec x);       /* KSPSolve :247 (zero initial guess) */

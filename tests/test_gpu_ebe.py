@@ -109,7 +109,7 @@ def test_ebe_full_size_config3(gpu_ctx):
     assert np.abs(out["ebe"][0] - out["assembled"][0]).max() <= 1e-7 * np.abs(out["assembled"][0]).max()
 
 
-@pytest.mark.parametrize("opts", ["-pc_type jacobi", "-pc_type mg -pc_mg_type additive"])
+@pytest.mark.parametrize("opts", ["-pc_type jacobi", "-pc_type mg -pc_mg_type additive", "-pc_type mg -pc_mg_type additive -pc_mg_slice_min 1"])
 def test_ebe_eight_domains_medium_size(opts):
     """The layout of config 4 (2x2x2 bricks) at 32^3 elements per brick, element-by-element product, against
     the undivided mesh on one context: same iteration count (+-2) and the same field; interface copies

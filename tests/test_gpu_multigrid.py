@@ -74,7 +74,9 @@ def test_mg_on_a_partitioned_mesh(oracle, world, npr, mgtype):
     single-domain multigrid run, and interface copies stay bitwise identical."""
     from tests.test_gpu_multidomain import _run_domains
     from fem_amd import partition
-    opts = f"-pc_type mg -pc_mg_type {mgtype} -ksp_rtol 1e-12"
+    # -pc_mg_slice_min 1: split the level-1 residuals among the domains although the level is tiny
+    # (the production threshold is 32768 boxes), so that the two extra all-reduces are exercised
+    opts = f"-pc_type mg -pc_mg_type {mgtype} -ksp_rtol 1e-12 -pc_mg_slice_min {1 if world == 4 else 32768}"
     grid, out = _run_domains(world, npr, 0.15, opts)
     gn = tuple(grid[d] * npr[d] for d in range(3))
     g = structured_hex(*gn, jitter=0.15)

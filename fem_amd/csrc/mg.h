@@ -42,8 +42,8 @@ struct Multigrid {
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     DBuf<int> agg;                  // [nn] level-1 box of every node
     DBuf<int> box_ptr, box_nodes;   // level-1 box -> its nodes (ascending)
-    DBuf<double> w;                 // [nn*bs] 1 on free dofs, 0 on penalty dofs
-    DBuf<double> wr;                // partitioned mesh: w on the nodes this domain owns, 0 on the other copies
+    DBuf<unsigned char> w;          // [nn*bs] 1 on free dofs, 0 on penalty dofs
+    DBuf<unsigned char> wr;         // partitioned mesh: w on the nodes this domain owns, 0 on the other copies
     DBuf<double> dinv0, t0;         // fine-level Jacobi inverse diagonal, work vector
     DBuf<double> cinv;              // dense inverse of the coarsest operator
     DBuf<double> omega_l;           // [levels] smoother damping per box level (from an eigenvalue estimate) + scratch

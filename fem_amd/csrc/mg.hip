@@ -83,26 +83,25 @@ __global__ void __launch_bounds__(256) k_sort_boxes(int nb, const int* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) k_free_weights(size_t n, const double* __restrict__ diag, double* __restrict__ w,
+__global__ void __launch_bounds__(256) k_free_weights(size_t n, const double* __restrict__ diag, unsigned char* __restrict__ w,
                                                       double* __restrict__ dinv)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) {
         const double d = diag[i];
-        w[i] = (d >= 1.0e29) ? 0.0 : 1.0;   // penalty dofs (PENALTY_PARAM = 1e30) stay out of the coarse space
+        w[i] = (d >= 1.0e29) ? 0 : 1;       // penalty dofs (PENALTY_PARAM = 1e30) stay out of the coarse space
         dinv[i] = (d != 0.0) ? 1.0 / d : 1.0;
     }
 }
 
 // restriction weights of a partitioned mesh: every shared node is counted by its owner only
-__global__ void __launch_bounds__(256) k_owner_weights(int nn, int bs, const double* __restrict__ w,
-                                                       const unsigned char* __restrict__ owned, double* __restrict__ wr)
+__global__ void __launch_bounds__(256) k_owner_weights(int nn, int bs, const unsigned char* __restrict__ w,
+                                                       const unsigned char* __restrict__ owned, unsigned char* __restrict__ wr)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nn) return;
-    const double o = owned[v] ? 1.0 : 0.0;
-    for (int r = 0; r < bs; r++) wr[(size_t)v * bs + r] = o * w[(size_t)v * bs + r];
+    for (int r = 0; r < bs; r++) wr[(size_t)v * bs + r] = owned[v] ? w[(size_t)v * bs + r] : 0;
 }
 __global__ void __launch_bounds__(256) k_count_owned(int nn, const unsigned char* __restrict__ owned, double* __restrict__ out)
 {
@@ -232,7 +231,7 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
                                                             const int* __restrict__ box_nodes, const int* __restrict__ agg,
                                                             const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                             const int* __restrict__ bcol, const double* __restrict__ val,
-                                                            const double* __restrict__ w, double* __restrict__ st,
+                                                            const unsigned char* __restrict__ w, double* __restrict__ st,
                                                             int* __restrict__ err)
 {
     constexpr int BB = BS * BS, CC = CS * CS;
@@ -254,7 +253,7 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
         double di[3] = {0.0, 0.0, 0.0}, wi[BS];
         if (have) node_offset<PD>(coords, i, cA, di);
 #pragma unroll
-        for (int r = 0; r < BS; r++) wi[r] = have ? w[(size_t)BS * i + r] : 0.0;
+        for (int r = 0; r < BS; r++) wi[r] = (have && w[(size_t)BS * i + r]) ? 1.0 : 0.0;
         int maxlen = len;
         for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
         for (int j0 = 0; j0 < maxlen || first; j0 += MG_ROW_CHUNK) {
@@ -293,7 +292,7 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
                             for (int r = 0; r < BS; r++)
 #pragma unroll
                                 for (int q = 0; q < BS; q++)
-                                    kw[r * BS + q] = wi[r] * w[(size_t)BS * c + q] * val[((o0 + j) * BB + r * BS + q) * 64 + ln];
+                                    kw[r * BS + q] = wi[r] * (double)w[(size_t)BS * c + q] * val[((o0 + j) * BB + r * BS + q) * 64 + ln];
                             // KP = (w K w) P_j : row r of K applied to the modes of node j
 #pragma unroll
                             for (int r = 0; r < BS; r++) {
@@ -575,7 +574,7 @@ __global__ void __launch_bounds__(256) k_fine_post(size_t n, double omega, const
 template <int BS, int CS, int PD>
 __global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, const double* __restrict__ coords,
                                                        const int* __restrict__ box_ptr, const int* __restrict__ box_nodes,
-                                                       const double* __restrict__ w, const double* __restrict__ r,
+                                                       const unsigned char* __restrict__ w, const double* __restrict__ r,
                                                        const double* __restrict__ kz, double* __restrict__ rc)
 {
     const int nb = g.nb();
@@ -590,7 +589,7 @@ __global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, con
         const size_t i = (size_t)v * BS;
         double f[BS], d[3], m[CS];
 #pragma unroll
-        for (int q = 0; q < BS; q++) f[q] = w[i + q] * (kz ? r[i + q] - kz[i + q] : r[i + q]);
+        for (int q = 0; q < BS; q++) f[q] = w[i + q] ? (kz ? r[i + q] - kz[i + q] : r[i + q]) : 0.0;
         node_offset<PD>(coords, v, cB, d);
         rbm_apply_t<BS, CS>(d, f, m);
 #pragma unroll
@@ -609,7 +608,7 @@ __global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, con
 template <int BS, int CS, int PD>
 __global__ void __launch_bounds__(256) k_prolong_fine(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
                                                       double alpha, const int* __restrict__ agg,
-                                                      const double* __restrict__ w, const double* __restrict__ xc,
+                                                      const unsigned char* __restrict__ w, const double* __restrict__ xc,
                                                       double* __restrict__ z)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -621,7 +620,8 @@ __global__ void __launch_bounds__(256) k_prolong_fine(int nn, Grid3 g, BoxGeom g
     rbm_apply<BS, CS>(d, xc + (size_t)b * CS, u);
     const size_t i = (size_t)v * BS;
 #pragma unroll
-    for (int q = 0; q < BS; q++) z[i + q] += alpha * w[i + q] * u[q];
+    for (int q = 0; q < BS; q++)
+        if (w[i + q]) z[i + q] += alpha * u[q];
 }
 
 // additive fine level, one pass: z_i = dinv_i r_i + alpha w_i (P_i x_1[agg(i)]), plus the partials of
@@ -629,7 +629,7 @@ __global__ void __launch_bounds__(256) k_prolong_fine(int nn, Grid3 g, BoxGeom g
 template <int BS, int CS, int PD>
 __global__ void __launch_bounds__(256) k_additive_finish(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
                                                          double alpha, const int* __restrict__ agg,
-                                                         const double* __restrict__ w, const double* __restrict__ dinv,
+                                                         const unsigned char* __restrict__ w, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ xc,
                                                          double* __restrict__ z, double* __restrict__ pzz,
                                                          double* __restrict__ pzr, const int* __restrict__ done)
@@ -647,7 +647,7 @@ __global__ void __launch_bounds__(256) k_additive_finish(int nn, Grid3 g, BoxGeo
 #pragma unroll
         for (int q = 0; q < BS; q++) {
             const double ri = r[i + q];
-            const double zi = dinv[i + q] * ri + alpha * w[i + q] * u[q];
+            const double zi = w[i + q] ? dinv[i + q] * ri + alpha * u[q] : dinv[i + q] * ri;
             z[i + q] = zi;
             zz += zi * zi; zr += zi * ri;
         }
@@ -1092,7 +1092,7 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     // partitioned mesh: r and z are consistent on every copy of a shared node; the restriction counts
     // each node once (owner weights), one all-reduce makes the level-1 residual global, the coarse
     // cycle then runs replicated and the prolongation is local again
-    const double* wr = comm ? mg.wr.p : mg.w.p;
+    const unsigned char* wr = comm ? mg.wr.p : mg.w.p;
     auto restrict_to_level1 = [&](const double* kz) {
         hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
                            mg.box_ptr.p, mg.box_nodes.p, wr, r, kz, L1.r.p);

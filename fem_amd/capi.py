@@ -48,6 +48,7 @@ _SIGS = {
     "fem_form_el_ke": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp],
     "fem_calc_el_stress": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp],
     "fem_form_el_indx": [C.c_int, C.c_int, _ip, _ip],
+    "fem_coh_apply_1": [_h, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp],
     "fem_rcm_order": [C.c_int, _ip, _ip, _ip],
     "fem_mesh_create": [_h, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp, C.c_int, _dp, C.POINTER(_h)],
     "fem_mesh_destroy": [_h],
@@ -218,6 +219,18 @@ def form_el_indx(pdim: int, enodes) -> np.ndarray:
     out = np.zeros(len(en) * pdim, dtype=np.int32)
     _ck(_lib.fem_form_el_indx(pdim, len(en), _i(en), _i(out)))
     return out
+
+
+def coh_apply_1(ctx: "Context", ecoords, u8, props, dt: float):
+    """Cohesive elements, element level (applyTract_1 / applyStiff_1 of the reference, batched): returns
+    tract[ncoh, 8], stiff[ncoh, 8, 8] and the per-integration-point record gp[ncoh, 2, 14]."""
+    ec = np.ascontiguousarray(ecoords, dtype=np.float64).reshape(-1, 8)
+    u = np.ascontiguousarray(u8, dtype=np.float64).reshape(-1, 8)
+    p = np.ascontiguousarray(props, dtype=np.float64).reshape(-1, 6)
+    n = ec.shape[0]
+    tr, st, gp = np.zeros((n, 8)), np.zeros((n, 64)), np.zeros((n, 2, 14))
+    _ck(_lib.fem_coh_apply_1(ctx.h, n, _d(ec), _d(u), _d(p), float(dt), _d(tr), _d(st), _d(gp)))
+    return tr, st.reshape(n, 8, 8).transpose(0, 2, 1), gp
 
 
 def rcm_order(ptr, adj) -> np.ndarray:

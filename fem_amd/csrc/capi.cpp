@@ -19,6 +19,7 @@ fem_mesh mesh_create_impl(fem_ctx, int, int, int, const int*, const int*, const 
 void mesh_set_halo_impl(fem_mesh, fem_comm, int, const int*, const int*, const int*);
 fem_mat mat_create_impl(fem_mesh);
 void mat_assemble_elements_impl(fem_mat);
+void coh_apply_1_impl(fem_ctx, int, const double*, const double*, const double*, double, double*, double*, double*);
 void mat_set_mult_type_impl(fem_mat, const char*);
 void mat_set_profiling_impl(fem_mat, int);
 void mat_get_profile_impl(fem_mat, int, int*, double*, double*, double*);
@@ -198,6 +199,15 @@ int fem_form_el_indx(int pdim, int n, const int* enodes, int* indx)
     FEM_CHECK(pdim == 2 || pdim == 3, 2, "fem_form_el_indx: pdim must be 2 or 3");
     for (int j = 0; j < n; j++)
         for (int d = 0; d < pdim; d++) indx[pdim * j + d] = pdim * enodes[j] + d;
+    FEM_CATCH
+}
+
+int fem_coh_apply_1(fem_ctx ctx, int ncoh, const double* ecoords, const double* u8, const double* props, double dt,
+                    double* tract, double* stiff, double* gp)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "fem_coh_apply_1: null context");
+    coh_apply_1_impl(ctx, ncoh, ecoords, u8, props, dt, tract, stiff, gp);
     FEM_CATCH
 }
 

@@ -1,0 +1,147 @@
+// fem_amd/csrc/coh.hip -- cohesive element, element level: the kinematics of the 4-node
+// zero-thickness element (getCohValues / getCohRels / getCohGaps, src/m_elems.F90:658-720), the
+// Xu-Needleman law (Seplaw_1_Tract / Seplaw_1_Stiff, src/m_seplaw.F90:15-94) and the element vectors and
+// matrices the Newton callbacks add (applyTract_1 src/m_global.F90:622-682, applyStiff_1 :762-845), batched,
+// one thread per element.  The Newton loop around them (SNES) is not built: see DESIGN.md section 8.
+// Reference behaviour is kept as written and said so: applyTract_1 ASSIGNS per integration point (the last
+// point wins), applyStiff_1 scales only its second term by sig1*sig2*N*N*w*det.
+#include "common.h"
+
+using namespace fem;
+
+namespace fem {
+
+struct CohGp {
+    double urel[2], vrel[2], gap[2], vgap[2], tract[2], stiff[4];
+};
+
+__device__ __forceinline__ void coh_shape(int gp, double (&N)[4])
+{
+    const double eta = (gp == 0) ? -0.5773502691896260 : 0.5773502691896260;   // SamPtsCoh :607
+    N[0] = 0.5 * (1 - eta); N[1] = 0.5 * (1 + eta); N[2] = N[1]; N[3] = N[0];   // ShapeFuncPrecompCoh :640-643
+}
+
+__device__ __forceinline__ void coh_point(const double* __restrict__ u8, const double* __restrict__ props, double dt,
+                                          const double (&t)[2], const double (&n)[2], int gp, CohGp& o)
+{
+    double N[4];
+    coh_shape(gp, N);
+    o.urel[0] = o.urel[1] = 0.0;
+    for (int n1 = 0; n1 < 2; n1++) {
+        const int n2 = n1 + 2;
+        for (int i = 0; i < 2; i++) o.urel[i] = o.urel[i] + N[n2] * u8[2 * n2 + i] - N[n1] * u8[2 * n1 + i];
+    }
+    o.vrel[0] = o.urel[0] / dt; o.vrel[1] = o.urel[1] / dt;
+    o.gap[0] = n[0] * o.urel[0] + n[1] * o.urel[1];
+    o.gap[1] = t[0] * o.urel[0] + t[1] * o.urel[1];
+    o.vgap[0] = n[0] * o.vrel[0] + n[1] * o.vrel[1];
+    o.vgap[1] = t[0] * o.vrel[0] + t[1] * o.vrel[1];
+    const double sw = exp(1.0) * props[0] * props[1];
+    const double dn = props[1], dtt = props[2], q = props[3], r = props[4], zeta = props[5];
+    const double g1 = o.gap[0], g2 = o.gap[1];
+    const double et = exp(-g2 * g2 / (dtt * dtt)), en = exp(-g1 / dn);
+    double c1, c2;
+    // Seplaw_1_Tract
+    c1 = (1.0 - et);
+    c1 = c1 * (1.0 - q) / (r - 1.0) * (r - g1 / dn);
+    c2 = (g1 / dn) * et;
+    o.tract[0] = (sw / dn) * en * (c2 + c1);
+    c1 = q + (r - q) / (r - 1.0) * (g1 / dn);
+    c1 = c1 * en * et;
+    c1 = c1 * 2.0 * (dn / dtt) * (sw / dn);
+    o.tract[1] = c1 * g2 / dtt;
+    o.tract[0] = o.tract[0] + zeta * props[0] * o.vgap[0] / dn;
+    // Seplaw_1_Stiff
+    c1 = (1.0 - q) / (r - 1) * (1.0 - et);
+    c1 = c1 * (r + 1.0 - g1 / dn);
+    c1 = (1.0 - g1 / dn) * et - c1;
+    double s11 = (sw / (dn * dn)) * en * c1;
+    c1 = q + (g1 / dn) * (r - q) / (r - 1.0);
+    c1 = c1 * en * et;
+    c1 = 2.0 * (sw / (dtt * dtt)) * c1;
+    const double s22 = c1 * (1.0 - 2.0 * (g2 * g2 / (dtt * dtt)));
+    c1 = -g1 / dn + (1.0 - q) / (r - 1.0) * (r - g1 / dn);
+    c1 = c1 * en * et;
+    c1 = 2.0 * (sw / (dtt * dn)) * c1;
+    const double s12 = (g2 / dtt) * c1;
+    s11 = s11 + zeta * props[0] / dn / dt;
+    o.stiff[0] = s11; o.stiff[1] = s12; o.stiff[2] = s12; o.stiff[3] = s22;   // (1,1) (2,1) (1,2) (2,2)
+}
+
+__global__ void __launch_bounds__(128) k_coh_apply_1(int ncoh, const double* __restrict__ ecoords,
+                                                     const double* __restrict__ u8, const double* __restrict__ props,
+                                                     double dt, double* __restrict__ tract, double* __restrict__ stiff,
+                                                     double* __restrict__ gp_out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ncoh) return;
+    const double* ec = ecoords + (size_t)e * 8;      // ecoords(4,2) column-major
+    const double* u = u8 + (size_t)e * 8;
+    const double* pr = props + (size_t)e * 6;
+    double t[2], n[2];
+    t[0] = 0.5 * (ec[1] - ec[0] + ec[2] - ec[3]);
+    t[1] = 0.5 * (ec[5] - ec[4] + ec[6] - ec[7]);
+    const double mag = sqrt(t[0] * t[0] + t[1] * t[1]);
+    t[0] /= mag; t[1] /= mag;
+    const double det = mag * 0.5;
+    n[0] = -t[1]; n[1] = t[0];
+    double res[8], K[64];
+    for (int k = 0; k < 8; k++) res[k] = 0.0;
+    for (int k = 0; k < 64; k++) K[k] = 0.0;
+    for (int gp = 0; gp < 2; gp++) {
+        CohGp o;
+        coh_point(u, pr, dt, t, n, gp, o);
+        if (gp_out) {
+            double* g = gp_out + ((size_t)e * 2 + gp) * 14;
+            g[0] = o.urel[0]; g[1] = o.urel[1]; g[2] = o.vrel[0]; g[3] = o.vrel[1]; g[4] = o.gap[0]; g[5] = o.gap[1];
+            g[6] = o.vgap[0]; g[7] = o.vgap[1]; g[8] = o.tract[0]; g[9] = o.tract[1];
+            g[10] = o.stiff[0]; g[11] = o.stiff[1]; g[12] = o.stiff[2]; g[13] = o.stiff[3];
+        }
+        double N[4];
+        coh_shape(gp, N);
+        double sig = 1.0;
+        for (int node = 0; node < 4; node++) {
+            if (node + 1 > 2) sig = -1.0;
+            for (int d = 0; d < 2; d++)   // "=": src/m_global.F90:668
+                res[node * 2 + d] = sig * N[node] * (o.tract[0] * n[d] + o.tract[1] * t[d]) * 1.0 * det;
+        }
+        double s1 = 1.0;
+        for (int n1 = 0; n1 < 4; n1++) {
+            if (n1 + 1 > 2) s1 = -1.0;
+            double s2 = 1.0;
+            for (int n2 = 0; n2 < 4; n2++) {
+                if (n2 + 1 > 2) s2 = -1.0;
+                for (int d1 = 0; d1 < 2; d1++)
+                    for (int d2 = 0; d2 < 2; d2++) {   // src/m_global.F90:829-831, parentheses as in the reference
+                        double& r = K[(n1 * 2 + d1) + 8 * (n2 * 2 + d2)];
+                        r = r + ((o.stiff[0] * n[d1] + o.stiff[1] * t[d1]) * n[d2]) +
+                            ((o.stiff[2] * n[d1] + o.stiff[3] * t[d1]) * t[d2]) * s1 * s2 * N[n1] * N[n2] * 1.0 * det;
+                    }
+            }
+        }
+    }
+    if (tract) for (int k = 0; k < 8; k++) tract[(size_t)e * 8 + k] = res[k];
+    if (stiff) for (int k = 0; k < 64; k++) stiff[(size_t)e * 64 + k] = K[k];
+}
+
+}  // namespace fem
+
+void coh_apply_1_impl(fem_ctx ctx, int ncoh, const double* ecoords, const double* u8, const double* props, double dt,
+                      double* tract, double* stiff, double* gp)
+{
+    if (ncoh <= 0) return;
+    FEM_CHECK(ecoords && u8 && props, 1, "fem_coh_apply_1: null input");
+    FEM_CHECK(dt > 0.0, 2, "fem_coh_apply_1: dt must be positive");
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    DBuf<double> dE((size_t)ncoh * 8), dU((size_t)ncoh * 8), dP((size_t)ncoh * 6), dT((size_t)ncoh * 8),
+        dK((size_t)ncoh * 64), dG((size_t)ncoh * 28);
+    dE.upload(ecoords, dE.n, s); dU.upload(u8, dU.n, s); dP.upload(props, dP.n, s);
+    hipLaunchKernelGGL(k_coh_apply_1, dim3(cdiv((size_t)ncoh, 128)), dim3(128), 0, s, ncoh, dE.p, dU.p, dP.p, dt, dT.p, dK.p,
+                       gp ? dG.p : (double*)nullptr);
+    FEM_HIP(hipGetLastError());
+    if (tract) dT.download(tract, dT.n, s);
+    if (stiff) dK.download(stiff, dK.n, s);
+    if (gp) dG.download(gp, dG.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}

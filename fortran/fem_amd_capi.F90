@@ -318,6 +318,15 @@ module fem_amd_capi
       integer(c_int), intent(in) :: neigh_rank(*), neigh_ptr(*), neigh_nodes(*)
       integer(c_int) :: ierr
     end function
+    function fem_coh_apply_1(ctx, ncoh, ecoords, u8, props, dt, tract, stiff, gp) bind(C, name="fem_coh_apply_1") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: ncoh
+      real(c_double), intent(in) :: ecoords(*), u8(*), props(*)
+      real(c_double), value :: dt
+      real(c_double), intent(out) :: tract(*), stiff(*), gp(*)
+      integer(c_int) :: ierr
+    end function
     function fem_rcm_order(n, ptr, adj, perm) bind(C, name="fem_rcm_order") result(ierr)
       import :: c_int
       integer(c_int), value :: n

@@ -93,6 +93,19 @@ int fem_calc_el_stress(fem_ctx ctx, int eltype, int nel, const double *ecoords, 
 /* FormElIndx :70-78 (0-based). */
 int fem_form_el_indx(int pdim, int n, const int *enodes, int *indx);
 
+/* ---- cohesive element, element level ----------------------------------------------
+ * Batched getCohValues / getCohRels / getCohGaps (src/m_elems.F90:658-720), Seplaw_1_Tract / Seplaw_1_Stiff
+ * (src/m_seplaw.F90:15-94) and the element vector / matrix of applyTract_1 (src/m_global.F90:622-682) and
+ * applyStiff_1 (:762-845) for ncoh 4-node cohesive elements.  ecoords[ncoh][8] = ecoords(4,2) column-major;
+ * u8[ncoh][8] = the eight numbers getCohRels reads (local_u(2(k-1)+i), k = 1..4: the reference hands it
+ * the rank's first four nodes, a host that wants the element's own nodes passes those); props[ncoh][6];
+ * tract[ncoh][8], stiff[ncoh][64] = result(8,8) column-major, gp[ncoh][2][14] = urel, vrel, gap, vgap,
+ * tract, stiff(2,2 column-major) per integration point; any output may be NULL.  Reference behaviour kept
+ * as written: applyTract_1 assigns per integration point (the last one wins), applyStiff_1 scales only its
+ * second term.  Host pointers. */
+int fem_coh_apply_1(fem_ctx ctx, int ncoh, const double *ecoords, const double *u8, const double *props, double dt,
+                    double *tract, double *stiff, double *gp);
+
 /* ---- mesh: local_elements/coords/mat (src/m_global.F90:40,22,21) ---------- */
 /* Uploads one domain's mesh as SoA.  eltype[nels], eptr[nels+1], conn[],
  * mat_id[nels] (0-based row of mats), coords[nnds*pdim] node-major,

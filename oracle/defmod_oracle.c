@@ -825,3 +825,137 @@ int dm_run(const dm_problem *p, int ksp_type, double rtol, double abstol, double
     free(rowptr); free(colind); free(val); free(F); free(U); free(sn);
     return step;
 }
+
+/* ---- cohesive element, element level ------------------------------------------------- */
+/* SamPtsCoh src/m_elems.F90:602-624 (CN = 0.5773502691896260, weights 1) and ShapeFuncPrecompCoh :626-647 */
+static const double COH_CN = 0.5773502691896260;
+static void coh_shape(int gp, double *N)
+{
+    const double eta = (gp == 0) ? -COH_CN : COH_CN;
+    N[0] = 0.5 * (1 - eta);
+    N[1] = 0.5 * (1 + eta);
+    N[2] = N[1];
+    N[3] = N[0];
+}
+
+void dm_coh_values(const double *ec, double *tangent, double *normal, double *det)
+{
+    /* ecoords(node, dim): ec[node + 4*dim]; src/m_elems.F90:664-672 */
+    tangent[0] = 0.5 * (ec[1] - ec[0] + ec[2] - ec[3]);
+    tangent[1] = 0.5 * (ec[4 + 1] - ec[4 + 0] + ec[4 + 2] - ec[4 + 3]);
+    const double mag = sqrt(tangent[0] * tangent[0] + tangent[1] * tangent[1]);   /* magnitude, src/m_utils.F90 */
+    tangent[0] /= mag;
+    tangent[1] /= mag;
+    *det = mag * 0.5;
+    normal[0] = -tangent[1];
+    normal[1] = tangent[0];
+}
+
+void dm_coh_rels(const double *u8, int gp, double dt, double *urel, double *vrel)
+{
+    double N[4];
+    coh_shape(gp, N);
+    urel[0] = urel[1] = 0.0;
+    for (int n1 = 0; n1 < 2; n1++) {          /* node1 = 1..nodecount/2, node2 = node1 + nodecount/2 */
+        const int n2 = n1 + 2;
+        for (int i = 0; i < 2; i++) urel[i] = urel[i] + N[n2] * u8[2 * n2 + i] - N[n1] * u8[2 * n1 + i];
+    }
+    vrel[0] = urel[0] / dt;
+    vrel[1] = urel[1] / dt;
+}
+
+void dm_coh_gaps(const double *t, const double *n, const double *urel, const double *vrel, double *gap, double *vgap)
+{
+    gap[0] = n[0] * urel[0] + n[1] * urel[1];
+    gap[1] = t[0] * urel[0] + t[1] * urel[1];
+    vgap[0] = n[0] * vrel[0] + n[1] * vrel[1];
+    vgap[1] = t[0] * vrel[0] + t[1] * vrel[1];
+}
+
+void dm_seplaw1_tract(const double *props, const double *gap, const double *vgap, double dtime, double *tract)
+{
+    (void)dtime;
+    const double sepwrk = exp(1.0) * props[0] * props[1];
+    const double dn = props[1], dt = props[2], q = props[3], r = props[4], zeta = props[5];
+    double c1, c2;
+    c1 = (1.0 - exp(-gap[1] * gap[1] / (dt * dt)));
+    c1 = c1 * (1.0 - q) / (r - 1.0) * (r - gap[0] / dn);
+    c2 = (gap[0] / dn) * exp(-gap[1] * gap[1] / (dt * dt));
+    tract[0] = (sepwrk / dn) * exp(-gap[0] / dn) * (c2 + c1);
+    c1 = q + (r - q) / (r - 1.0) * (gap[0] / dn);
+    c1 = c1 * exp(-gap[0] / dn) * exp(-gap[1] * gap[1] / (dt * dt));
+    c1 = c1 * 2.0 * (dn / dt) * (sepwrk / dn);
+    tract[1] = c1 * gap[1] / dt;
+    tract[0] = tract[0] + zeta * props[0] * vgap[0] / dn;
+}
+
+void dm_seplaw1_stiff(const double *props, const double *gap, const double *vgap, double dtime, double *stiff)
+{
+    (void)vgap;
+    const double sep_work = exp(1.0) * props[0] * props[1];
+    const double dn = props[1], dt = props[2], q = props[3], r = props[4], zeta = props[5];
+    double c1, s11, s22, s12;
+    c1 = (1.0 - q) / (r - 1) * (1.0 - exp(-gap[1] * gap[1] / (dt * dt)));
+    c1 = c1 * (r + 1.0 - gap[0] / dn);
+    c1 = (1.0 - gap[0] / dn) * exp(-gap[1] * gap[1] / (dt * dt)) - c1;
+    s11 = (sep_work / (dn * dn)) * exp(-gap[0] / dn) * c1;
+    c1 = q + (gap[0] / dn) * (r - q) / (r - 1.0);
+    c1 = c1 * exp(-gap[0] / dn) * exp(-gap[1] * gap[1] / (dt * dt));
+    c1 = 2.0 * (sep_work / (dt * dt)) * c1;
+    s22 = c1 * (1.0 - 2.0 * (gap[1] * gap[1] / (dt * dt)));
+    c1 = -gap[0] / dn + (1.0 - q) / (r - 1.0) * (r - gap[0] / dn);
+    c1 = c1 * exp(-gap[0] / dn) * exp(-gap[1] * gap[1] / (dt * dt));
+    c1 = 2.0 * (sep_work / (dt * dn)) * c1;
+    s12 = (gap[1] / dt) * c1;
+    s11 = s11 + zeta * props[0] / dn / dtime;
+    stiff[0] = s11; stiff[1] = s12; stiff[2] = s12; stiff[3] = s22;   /* (1,1) (2,1) (1,2) (2,2) */
+}
+
+void dm_coh_apply_tract_1(const double *ec, const double *u8, const double *props, double dt, double *result)
+{
+    double t[2], n[2], det, urel[2], vrel[2], gap[2], vgap[2], f[2], N[4];
+    dm_coh_values(ec, t, n, &det);
+    for (int k = 0; k < 8; k++) result[k] = 0.0;
+    for (int gp = 0; gp < 2; gp++) {
+        dm_coh_rels(u8, gp, dt, urel, vrel);
+        dm_coh_gaps(t, n, urel, vrel, gap, vgap);
+        dm_seplaw1_tract(props, gap, vgap, dt, f);
+        coh_shape(gp, N);
+        double sig = 1.0;
+        for (int node = 0; node < 4; node++) {
+            if (node + 1 > 2) sig = -1.0;
+            for (int dof = 0; dof < 2; dof++)   /* "=": every integration point overwrites, src/m_global.F90:668 */
+                result[node * 2 + dof] = sig * N[node] * (f[0] * n[dof] + f[1] * t[dof]) * 1.0 * det;
+        }
+    }
+}
+
+void dm_coh_apply_stiff_1(const double *ec, const double *u8, const double *props, double dt, double *result)
+{
+    double t[2], n[2], det, urel[2], vrel[2], gap[2], vgap[2], st[4], N[4];
+    dm_coh_values(ec, t, n, &det);
+    for (int k = 0; k < 64; k++) result[k] = 0.0;
+#define ST(i, j) st[(i) + 2 * (j)]
+    for (int gp = 0; gp < 2; gp++) {
+        dm_coh_rels(u8, gp, dt, urel, vrel);
+        dm_coh_gaps(t, n, urel, vrel, gap, vgap);
+        dm_seplaw1_stiff(props, gap, vgap, dt, st);
+        coh_shape(gp, N);
+        double sig1 = 1.0;
+        for (int n1 = 0; n1 < 4; n1++) {
+            if (n1 + 1 > 2) sig1 = -1.0;
+            double sig2 = 1.0;
+            for (int n2 = 0; n2 < 4; n2++) {
+                if (n2 + 1 > 2) sig2 = -1.0;
+                for (int d1 = 0; d1 < 2; d1++)
+                    for (int d2 = 0; d2 < 2; d2++) {
+                        /* src/m_global.F90:829-831: only the second term carries sig1*sig2*N*N*w*det */
+                        double *r = &result[(n1 * 2 + d1) + 8 * (n2 * 2 + d2)];
+                        *r = *r + ((ST(0, 0) * n[d1] + ST(1, 0) * t[d1]) * n[d2]) +
+                             ((ST(0, 1) * n[d1] + ST(1, 1) * t[d1]) * t[d2]) * sig1 * sig2 * N[n1] * N[n2] * 1.0 * det;
+                    }
+            }
+        }
+    }
+#undef ST
+}

@@ -222,6 +222,39 @@ class Oracle:
         self.L.dm_recover_nodal_stress(C.byref(p), _d(uu), _d(sn), _i(cnt))
         return sn.reshape(p.nnds, cp, order="F"), cnt
 
+    # ---- cohesive element, element level ----
+    def coh_values(self, ecoords):
+        ec = np.asfortranarray(np.asarray(ecoords, dtype=np.float64).reshape(4, 2))
+        t, n = np.zeros(2), np.zeros(2); det = C.c_double(0)
+        self.L.dm_coh_values(_d(ec), _d(t), _d(n), C.byref(det))
+        return t, n, det.value
+
+    def coh_rels(self, u8, gp, dt):
+        u = np.ascontiguousarray(u8, dtype=np.float64); ur, vr = np.zeros(2), np.zeros(2)
+        self.L.dm_coh_rels(_d(u), int(gp), C.c_double(dt), _d(ur), _d(vr))
+        return ur, vr
+
+    def coh_gaps(self, t, n, urel, vrel):
+        g, vg = np.zeros(2), np.zeros(2)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (t, n, urel, vrel)]
+        self.L.dm_coh_gaps(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(g), _d(vg))
+        return g, vg
+
+    def seplaw1(self, props, gap, vgap, dtime):
+        p, g, vg = (np.ascontiguousarray(x, dtype=np.float64) for x in (props, gap, vgap))
+        tr, st = np.zeros(2), np.zeros(4)
+        self.L.dm_seplaw1_tract(_d(p), _d(g), _d(vg), C.c_double(dtime), _d(tr))
+        self.L.dm_seplaw1_stiff(_d(p), _d(g), _d(vg), C.c_double(dtime), _d(st))
+        return tr, st.reshape(2, 2, order="F")
+
+    def coh_apply_1(self, ecoords, u8, props, dt):
+        ec = np.asfortranarray(np.asarray(ecoords, dtype=np.float64).reshape(4, 2))
+        u, p = (np.ascontiguousarray(x, dtype=np.float64) for x in (u8, props))
+        tr, st = np.zeros(8), np.zeros(64)
+        self.L.dm_coh_apply_tract_1(_d(ec), _d(u), _d(p), C.c_double(dt), _d(tr))
+        self.L.dm_coh_apply_stiff_1(_d(ec), _d(u), _d(p), C.c_double(dt), _d(st))
+        return tr, st.reshape(8, 8, order="F")
+
     def run(self, m, ksp_type="cg", rtol=DEFAULT_RTOL, abstol=1e-50, dtol=1e5, maxit=10000, nthreads=1):
         p, keep = make_problem(m)
         cp = 3 if p.pdim == 2 else 6
@@ -317,3 +350,30 @@ class RefLib:
         sn = np.zeros(nps, dtype=np.int32); a = C.c_double(0)
         self.L.ref_edge_area_nodes(t, _i(en), _d(ec), side, C.byref(a), _i(sn))
         return a.value, sn
+
+    # ---- cohesive helper routines of the reference (m_elems.F90:658-720, m_seplaw.F90) ----
+    def coh_values(self, ecoords):
+        self.init(2)
+        ec = np.asfortranarray(np.asarray(ecoords, dtype=np.float64).reshape(4, 2))
+        t, n = np.zeros(2), np.zeros(2); det = C.c_double(0)
+        self.L.ref_coh_values(_d(ec), _d(t), _d(n), C.byref(det))
+        return t, n, det.value
+
+    def coh_rels(self, u8, gp, dt):
+        self.init(2)
+        u = np.ascontiguousarray(u8, dtype=np.float64); ur, vr = np.zeros(2), np.zeros(2)
+        self.L.ref_coh_rels(_d(u), int(gp) + 1, C.c_double(dt), _d(ur), _d(vr))
+        return ur, vr
+
+    def coh_gaps(self, t, n, urel, vrel):
+        self.init(2)
+        g, vg = np.zeros(2), np.zeros(2)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (t, n, urel, vrel)]
+        self.L.ref_coh_gaps(_d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(g), _d(vg))
+        return g, vg
+
+    def seplaw1(self, props, gap, vgap, dtime):
+        p, g, vg = (np.ascontiguousarray(x, dtype=np.float64) for x in (props, gap, vgap))
+        tr, st = np.zeros(2), np.zeros(4)
+        self.L.ref_seplaw1(_d(p), _d(g), _d(vg), C.c_double(dtime), _d(tr), _d(st))
+        return tr, st.reshape(2, 2, order="F")

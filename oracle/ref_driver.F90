@@ -208,4 +208,25 @@ contains
     call getCohValues(ec, tangent, normal, det)
   end subroutine ref_coh_values
 
+  ! getCohRels, m_elems.F90:676-706.  The routine ignores `nodes` and reads local_u(2*(k-1)+i), k = 1..4:
+  ! the wrapper hands it exactly those eight numbers.
+  subroutine ref_coh_rels(local_u, nip, dt, urel, vrel) bind(C, name="ref_coh_rels")
+    real(c_double), intent(in) :: local_u(8)
+    integer(c_int), value :: nip
+    real(c_double), value :: dt
+    real(c_double), intent(out) :: urel(2), vrel(2)
+    integer :: nodes(4)
+    real(8) :: lu(8)
+    nodes = (/1, 2, 3, 4/)
+    lu = local_u
+    call getCohRels(nodes, lu, int(nip), dt, urel, vrel)
+  end subroutine ref_coh_rels
+
+  ! getCohGaps, m_elems.F90:709-720
+  subroutine ref_coh_gaps(tangent, normal, urel, vrel, gap, vgap) bind(C, name="ref_coh_gaps")
+    real(c_double), intent(in) :: tangent(2), normal(2), urel(2), vrel(2)
+    real(c_double), intent(out) :: gap(2), vgap(2)
+    call getCohGaps(tangent, normal, urel, vrel, gap, vgap)
+  end subroutine ref_coh_gaps
+
 end module ref_driver

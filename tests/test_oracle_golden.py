@@ -158,3 +158,59 @@ def test_vtk_writer_reproduces_reference_rank_files(oracle):
         # layout (line count, keywords, formats) is textually the reference's
         assert [ln.split()[0] for ln in got.splitlines()] != [] and len(got.splitlines()) == len(ref.splitlines())
         assert got.splitlines()[:5] == ref.splitlines()[:5]
+
+
+def test_cohesive_helpers_match_reference_golden(oracle):
+    """SURVEY 8 f1, element level: getCohValues / getCohRels / getCohGaps / Seplaw_1_Tract / Seplaw_1_Stiff of the
+    oracle against vectors produced by the reference's own compiled modules
+    (tests/golden/cohesive_golden.json, generator beside it)."""
+    import json
+    import os
+    d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cohesive_golden.json")))
+    assert len(d["cases"]) >= 20
+    for c in d["cases"]:
+        t, n, det = oracle.coh_values(c["ecoords"])
+        assert np.allclose(t, c["tangent"], rtol=1e-15, atol=0) and np.allclose(n, c["normal"], rtol=1e-15, atol=0)
+        assert abs(det - c["det"]) <= 1e-15 * abs(c["det"])
+        for gp, g in enumerate(c["gp"]):
+            ur, vr = oracle.coh_rels(c["u8"], gp, c["dt"])
+            gg, vg = oracle.coh_gaps(t, n, ur, vr)
+            tr, st = oracle.seplaw1(c["props"], gg, vg, c["dt"])
+            for a, b in ((ur, g["urel"]), (vr, g["vrel"]), (gg, g["gap"]), (vg, g["vgap"]), (tr, g["tract"]), (st, g["stiff"])):
+                b = np.asarray(b)
+                assert np.abs(a - b).max() <= 1e-14 * max(np.abs(b).max(), 1e-300)
+
+
+def test_cohesive_element_vector_and_matrix_follow_the_reference_as_written(oracle):
+    """applyTract_1 / applyStiff_1 (src/m_global.F90:622-682, 762-845) are restated with the reference's two
+    peculiarities; both are checked here from the pinned helpers: (1) the traction vector is the LAST
+    integration point's only, (2) the stiffness adds an unscaled first term at every node pair."""
+    rng = np.random.default_rng(7)
+    ec = np.array([[0, 0], [1.3, 0.2], [1.3, 0.2], [0, 0.0]]) + rng.uniform(-1e-3, 1e-3, (4, 2))
+    u8 = rng.uniform(-0.02, 0.02, 8)
+    props = [100.0, 0.01, 0.01, 1.0, 0.0, 0.02]
+    dt = 0.1
+    tr, K = oracle.coh_apply_1(ec, u8, props, dt)
+    t, n, det = oracle.coh_values(ec)
+    cn = 0.5773502691896260
+    N = lambda eta: np.array([0.5 * (1 - eta), 0.5 * (1 + eta), 0.5 * (1 + eta), 0.5 * (1 - eta)])  # noqa: E731
+    sig = np.array([1.0, 1.0, -1.0, -1.0])
+    pts = []
+    for gp, eta in enumerate((-cn, cn)):
+        ur, vr = oracle.coh_rels(u8, gp, dt)
+        g, vg = oracle.coh_gaps(t, n, ur, vr)
+        f, st = oracle.seplaw1(props, g, vg, dt)
+        pts.append((N(eta), f, st))
+    Nl, fl, _ = pts[-1]
+    expect = np.array([sig[a] * Nl[a] * (fl[0] * n[d] + fl[1] * t[d]) * det for a in range(4) for d in range(2)])
+    assert np.allclose(tr, expect, rtol=1e-14, atol=0)
+    Ke = np.zeros((8, 8))
+    for Ng, _, st in pts:
+        for a in range(4):
+            for b in range(4):
+                for d1 in range(2):
+                    for d2 in range(2):
+                        first = (st[0, 0] * n[d1] + st[1, 0] * t[d1]) * n[d2]
+                        second = (st[0, 1] * n[d1] + st[1, 1] * t[d1]) * t[d2] * sig[a] * sig[b] * Ng[a] * Ng[b] * det
+                        Ke[2 * a + d1, 2 * b + d2] += first + second
+    assert np.allclose(K, Ke, rtol=1e-13, atol=1e-13 * np.abs(Ke).max())

@@ -133,3 +133,29 @@ def test_config3_headline_solve_residual(gpu_ctx):
     top = top[m.coords[top, 2] == 149]
     assert np.abs(u[top, 2] + 1.49).max() < 1e-9
     R.destroy(); Dg.destroy(); prob.destroy()
+
+
+def test_config4_global_problem_on_one_gpu(gpu_ctx):
+    """BASELINE config 4's global problem (298^3 hex8, 80.2 M DOF) on ONE MI355X: the 288 GB of HBM hold the
+    57 GB matrix and the multigrid hierarchy.  Multigrid-preconditioned CG with the element-by-element product
+    must converge in a mesh-independent number of iterations, and the answer must satisfy the assembled system
+    (residual through the ASSEMBLED MatMult, i.e. both products are checked against each other at this size)."""
+    m = structured_hex(298)
+    prob = driver.Problem(gpu_ctx, m, "-pc_type mg -pc_mg_type additive -mat_mult_type ebe -ksp_rtol 1e-9")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == 2
+    assert prob.ksp.get_iteration_number() <= 90          # 62 at 149^3, 75-77 here; CG/Jacobi needs 1412
+    prob.K.set_mult_type("assembled")
+    R, D = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof)
+    prob.K.mult(prob.U, R); prob.K.get_diagonal(D)
+    r = R.get_array() - prob.F.get_array()
+    u = prob.U.get_array()
+    scale = D.get_array() * np.abs(u).max() + np.abs(prob.F.get_array()).max()
+    assert (np.abs(r) <= 1e-6 * scale).all()             # rtol 1e-9 on the preconditioned norm
+    top = np.nonzero(np.isclose(m.coords[:, 2], 298.0))[0]
+    assert np.allclose(u.reshape(-1, 3)[top, 2], u.reshape(-1, 3)[top[0], 2], rtol=0, atol=1e-9 * np.abs(u).max())
+    for o in (R, D):
+        o.destroy()
+    prob.destroy()

@@ -912,8 +912,11 @@ static bool setup_t(Multigrid& mg)
     if (comm) {
         // A_1 = sum over the domains of P_r^T K_r P_r (sub-assembled matrices, same P on shared nodes);
         // the flag travels along so that every domain raises the same error
-        FEM_CHECK((size_t)27 * CS * CS * nb < (size_t)1 << 31, 9, "pc mg: level-1 operator too large for one all-reduce");
-        comm->allreduce_sum(mg.lev[0].st.p, 27 * CS * CS * nb, s);
+        {
+            const size_t total = (size_t)27 * CS * CS * nb, chunk = (size_t)1 << 28;   // 2 GiB of doubles per call
+            for (size_t o = 0; o < total; o += chunk)
+                comm->allreduce_sum(mg.lev[0].st.p + o, (int)std::min(chunk, total - o), s);
+        }
         DBuf<double> derr(1);
         int herr0 = 0;
         err.download(&herr0, 1, s);

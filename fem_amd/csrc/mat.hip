@@ -403,6 +403,8 @@ void mat_get_csr_impl(fem_mat A, int* rowptr, int* colind, double* val)
     ctx->bind();
     hipStream_t s = ctx->stream;
     const int bs = A->bs, nn = A->nbrows;
+    FEM_CHECK(A->nblocks * bs * bs < (1LL << 31), 4,
+              "fem_mat_get_csr: the scalar CSR view has int32 row pointers; this matrix has more than 2^31 entries");
     if (rowptr) {
         long long k = 0;
         rowptr[0] = 0;

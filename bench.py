@@ -2,6 +2,7 @@
 """bench.py -- headline benchmark: DOF/s of assemble+solve on the 149^3 hex8
 linear-elastic cube (config 3 of BASELINE.json / SURVEY.md section 8d), one brick
 per GPU, plus the SpMV roofline line and the CPU (oracle port) baseline.
+`--config 2` times the 707^2 quad4 plate (config 2) the same way on one GPU.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -20,6 +21,12 @@ import os
 import sys
 import threading
 import time
+
+# the cpu_baseline leg runs OpenMP threads pinned one per physical core, spread over both sockets, so that
+# first-touch placement (oracle/cpu_baseline.c) keeps every thread's rows in its own socket's DRAM; libgomp
+# reads these when it is first loaded (numpy / torch pull it in), hence before any import
+os.environ.setdefault("OMP_PROC_BIND", "spread")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 import numpy as np
 
@@ -42,34 +49,55 @@ def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:
     return nnz * 12.0 + (nrows + 1) * 4.0 + nrows * 16.0
 
 
-def cpu_baseline(n: int, gpu_its: int, threads: int) -> dict:
-    """Oracle (C port of the reference algorithm, OpenMP) on this box's host
-    cores: full symbolic + numeric assembly of the same mesh, and a bounded
-    number of CG iterations whose per-iteration time is extrapolated to the
-    iteration count the GPU run needed."""
-    from fem_amd.mesh import structured_hex
+def host_cores() -> dict:
+    """Physical cores this process may use: distinct (socket, core) pairs among the CPUs of its affinity mask,
+    capped by the cgroup CPU quota when there is one."""
+    allowed = sorted(os.sched_getaffinity(0))
+    cores = set()
+    try:
+        for c in allowed:
+            base = f"/sys/devices/system/cpu/cpu{c}/topology/"
+            with open(base + "physical_package_id") as f:
+                pk = f.read().strip()
+            with open(base + "core_id") as f:
+                cores.add((pk, f.read().strip()))
+        nphys = len(cores)
+        sockets = len({pk for pk, _ in cores})
+    except OSError:
+        nphys, sockets = len(allowed), 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+        if q != "max":
+            quota = max(1, int(float(q) / float(per)))
+    except (OSError, ValueError):
+        pass
+    use = min(nphys, quota) if quota else nphys
+    return {"logical": len(allowed), "physical": nphys, "sockets": sockets, "cgroup_quota": quota, "use": max(1, use)}
+
+
+def cpu_baseline(mesh, label: str, gpu_its: int, threads: int, ncg: int) -> dict:
+    """Oracle port of the path (oracle/cpu_baseline.c: parallel sparsity, NUMA first touch, element loop with
+    atomics, fused parallel KSPCG/PCJACOBI) on this box's host cores: sparsity + assembly + set-up measured in
+    full, `ncg` CG iterations measured and the per-iteration time extrapolated to the iteration count the GPU
+    run needed.  The element-by-element (matrix-free) product is timed too, since the GPU headline uses it."""
     from oracle.oracle import Oracle, build
     build(ref=False)
-    o = Oracle()
-    m = structured_hex(n)
-    nnz = len(o.csr_pattern(m)[1])          # untimed counting pass (PETSc would preallocate)
-    t0 = time.perf_counter()
-    rp, ci = o.csr_pattern(m, nnz=nnz)
-    t1 = time.perf_counter()
-    val = o.assemble(m, rp, ci, nthreads=threads, apply_bc=True)
-    t2 = time.perf_counter()
-    F = o.form_rhs(m, 0.0, m.dt)
-    nit = 20
-    t3 = time.perf_counter()
-    o.ksp_cg_jacobi(rp, ci, val, F, rtol=1e-30, maxit=nit, nthreads=threads)
-    t4 = time.perf_counter()
-    per_it = (t4 - t3) / nit
-    t_total = (t2 - t0) + gpu_its * per_it
-    return {"value": m.ndof / t_total, "unit": "DOF/s", "cores": threads, "kind": "port",
-            "sample": f"same {n}^3 hex8 mesh: symbolic {t1 - t0:.2f}s + assembly {t2 - t1:.2f}s measured in full; "
-                      f"{nit} CG iterations measured ({per_it * 1e3:.1f} ms each), solve extrapolated to the GPU "
-                      f"run's {gpu_its} iterations",
-            "t_assemble_s": t2 - t0, "ms_per_cg_iteration": per_it * 1e3}
+    b = Oracle().cpu_baseline(mesh, threads, ncg, rtol=1e-30, nprod=5)
+    t_setup = b["t_pattern"] + b["t_assemble"] + b["t_setup"]
+    t_total = t_setup + gpu_its * b["t_cg_iteration"]
+    t_total_ebe = t_setup + gpu_its * (b["t_cg_iteration"] - b["t_spmv"] + b["t_ebe_product"])
+    return {"value": mesh.ndof / t_total, "unit": "DOF/s", "cores": threads, "kind": "port",
+            "sample": f"same {label} mesh: sparsity {b['t_pattern']:.2f}s + element loop/ApplyKBC {b['t_assemble']:.2f}s + "
+                      f"Jacobi/FormRHS {b['t_setup']:.2f}s measured in full; {b['its']} CG iterations measured "
+                      f"({b['t_cg_iteration'] * 1e3:.1f} ms each, SpMV {b['t_spmv'] * 1e3:.1f} ms), solve extrapolated to the "
+                      f"GPU run's {gpu_its} iterations; OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} "
+                      f"OMP_PLACES={os.environ.get('OMP_PLACES')}, first-touch placement",
+            "t_assemble_s": t_setup, "ms_per_cg_iteration": b["t_cg_iteration"] * 1e3, "ms_per_spmv": b["t_spmv"] * 1e3,
+            "spmv_GBs_csr": spmv_algorithmic_bytes(b["nnz"], mesh.ndof) / b["t_spmv"] / 1e9,
+            "matrix_free": {"ms_per_product": b["t_ebe_product"] * 1e3, "value": mesh.ndof / t_total_ebe, "unit": "DOF/s",
+                            "note": "same CG with the element-by-element product in place of the SpMV"}}
 
 
 def main():
@@ -77,33 +105,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=149, help="hex elements per brick edge (149 = config 3)")
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3],
+                    help="BASELINE.json config: 3 = 149^3 hex8 cube per GPU (the headline), 2 = 707^2 quad4 plate (1 GPU)")
+    ap.add_argument("--n", type=int, default=0, help="elements per edge (default: 149 for config 3, 707 for config 2)")
     ap.add_argument("--rtol", type=float, default=float(np.float32(1e-9)))
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="threads of the cpu_baseline leg; 0 = every physical core this process may use")
+    ap.add_argument("--cpu-cg-its", type=int, default=100, help="CG iterations the cpu_baseline leg measures")
     ap.add_argument("--jitter", type=float, default=0.0)
     ap.add_argument("--pc", default="jacobi", help="preconditioner of the timed (headline) solve: jacobi (north_star) | mg")
     ap.add_argument("--mult", default="ebe", choices=["ebe", "assembled"],
                     help="how the CG applies Mat_K: element-by-element recomputation (default, 2x faster) or the "
                          "assembled sliced-ELL SpMV; the other one is measured beside it")
+    ap.add_argument("--profile-period", type=int, default=8,
+                    help="every p-th MatMult of the timed solves is bracketed by HIP events (roofline leg)")
     ap.add_argument("--no-mg", action="store_true", help="skip the extra -pc_type mg measurement")
     ap.add_argument("--mg-timeout", type=float, default=240.0,
                     help="N>1 only: seconds after which the extra -pc_type mg measurement is abandoned and the "
                          "headline line is printed without it (the path over real RCCL peers could only be "
-                         "rehearsed with the in-process communicator)")
+                         "rehearsed with the in-process communicator); the run then exits with status 3")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: also at N=1 create the RCCL communicator and route the CG scalars through it")
     args = ap.parse_args()
+    if not args.n:
+        args.n = 149 if args.config == 3 else 707
 
     import torch
     import torch.distributed as dist
     from fem_amd import capi, driver, partition
+    from fem_amd.mesh import structured_quad
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.config == 2 and world != 1:
+        raise SystemExit("--config 2 (the 1M-DOF plate) is a single-GPU configuration")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
     torch.cuda.set_device(local_rank)
@@ -120,8 +159,14 @@ def main():
 
     ctx = capi.Context(local_rank)
     grid = partition.brick_grid(world)
-    npr = (args.n, args.n, args.n)
-    mesh = partition.brick_mesh(rank, grid, npr, jitter=args.jitter)
+    hex_case = args.config == 3
+    if hex_case:
+        npr = (args.n, args.n, args.n)
+        mesh = partition.brick_mesh(rank, grid, npr, jitter=args.jitter)
+        label = f"{args.n}^3 hex8"
+    else:
+        mesh = structured_quad(args.n, jitter=args.jitter)
+        label = f"{args.n}^2 quad4"
     comm = halo = None
     if use_comm:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
@@ -139,7 +184,8 @@ def main():
     os.close(saved_stdout)
     pc_opts = {"jacobi": "-pc_type jacobi", "mg": "-pc_type mg -pc_mg_type additive"}[args.pc]
     prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult}", comm=comm, halo=halo)
-    prob.ksp.set_profiling(True)
+    period = max(1, args.profile_period)
+    prob.ksp.set_profiling(period)
 
     def barrier():
         torch.cuda.synchronize()
@@ -151,8 +197,8 @@ def main():
         if prob.K is not None:
             prob.K.destroy(); prob.K = None
         ta = time.perf_counter()
-        prob.assemble()                      # symbolic + numeric + BC (main.F90:151-171)
-        prob.K.set_profiling(True)
+        prob.assemble()                      # MatCreateAIJ + element loop + ApplyKBC (main.F90:151-171)
+        prob.K.set_profiling(period)
         prob.ksp.set_up()
         tb = time.perf_counter()
         prob.dmesh.form_rhs(prob.F, 0.0, mesh.dt)
@@ -160,8 +206,11 @@ def main():
         ctx.synchronize()
         return tb - ta, time.perf_counter() - tb
 
+    t_first = None
     for _ in range(args.warmup):
-        one_step()
+        a, s_ = one_step()
+        if t_first is None:
+            t_first = a
     barrier()
     t0 = time.perf_counter()
     t_asm = t_sol = 0.0
@@ -173,7 +222,8 @@ def main():
         k, ms, _ = prob.ksp.get_profile()
         n_spmv += k; spmv_ms += ms
         if args.mult == "ebe":
-            pn, pel, pga, ppe = prob.K.get_profile(k)      # the products that really ran (not the no-ops after `done`)
+            # the sampled products that really ran (not the no-ops after `done`)
+            pn, pel, pga, ppe = prob.K.get_profile(prob.ksp.get_iteration_number())
             ebe_n += pn; ebe_el += pel; ebe_ga += pga; ebe_pe += ppe
     barrier()
     elapsed = time.perf_counter() - t0
@@ -186,8 +236,11 @@ def main():
     reason = prob.ksp.get_converged_reason()
     nrows, nnz, dev_bytes = prob.K.info()
     # global DOF count of the whole job (shared interface nodes counted once)
-    gn = [grid[d] * args.n + 1 for d in range(3)]
-    ndof_global = 3 * gn[0] * gn[1] * gn[2]
+    if hex_case:
+        gn = [grid[d] * args.n + 1 for d in range(3)]
+        ndof_global = 3 * gn[0] * gn[1] * gn[2]
+    else:
+        ndof_global = mesh.ndof
     ms_per_step = elapsed / args.steps * 1e3
     value = ndof_global * args.steps / elapsed
 
@@ -196,69 +249,99 @@ def main():
     X, Y = capi.Vec(ctx, nrows), capi.Vec(ctx, nrows)
     X.set_array(np.sin(0.001 * np.arange(nrows)))
     other_kind = "assembled" if args.mult == "ebe" else "ebe"
-    prob.K.set_profiling(False)
+    prob.K.set_profiling(0)
     prob.K.set_mult_type(other_kind)
     prob.K.mult_timed(X, Y, 1)                              # warm-up (and the lazy buffers of the ebe product)
     other = (other_kind, prob.K.mult_timed(X, Y, 40))
     prob.K.set_mult_type(args.mult)
     X.destroy(); Y.destroy()
 
-    def traffic_of(fname, n):
+    def traffic_of(fname):
+        """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py writes the file)."""
         tpath = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(tpath):
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("n") == n:
+            if tj.get("n") == args.n and tj.get("config", 3) == args.config:
                 return tj.get("hbm_bytes_per_launch")
         return None
+
+    bsz = 3 if hex_case else 2
+    spmv_name = f"k_spmv_sell<{bsz}>"
 
     def spmv_roofline(avg_ms, launches, where):
         alg = spmv_algorithmic_bytes(nnz, nrows)
         achieved = alg / (avg_ms * 1e-3) / 1e9
         fmt_bytes = dev_bytes + nrows * 16.0
-        return {"bound": "hbm", "kernel": f"k_spmv_sell<3> (assembled MatMult, {where})", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic_of("spmv_traffic.json", args.n), "algorithmic_bytes": alg, "avg_launch_ms": avg_ms,
-                "launches": launches, "format_bytes": fmt_bytes, "format_GBs": fmt_bytes / (avg_ms * 1e-3) / 1e9}
+        traffic = traffic_of("spmv_traffic.json" if hex_case else "spmv_traffic_c2.json")
+        r = {"bound": "hbm", "kernel": f"{spmv_name} (assembled MatMult, {where})", "achieved": achieved,
+             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "frac_note": "frac charges the SURVEY 8(d) scalar-CSR bytes (12 B per nonzero) to a block format that "
+                          "stores 4 index bytes per 9 values, so it can exceed 1; the HBM fraction proper is "
+                          "frac_of_spec_pmc (measured bytes) / frac_of_spec_format (stored bytes)",
+             "traffic": traffic, "algorithmic_bytes": alg, "avg_launch_ms": avg_ms,
+             "launches": launches, "format_bytes": fmt_bytes, "format_GBs": fmt_bytes / (avg_ms * 1e-3) / 1e9,
+             "frac_of_spec_format": fmt_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        if traffic:
+            r["pmc_GBs"] = traffic / (avg_ms * 1e-3) / 1e9
+            r["frac_of_spec_pmc"] = r["pmc_GBs"] / HBM_PEAK_GBS
+        return r
 
     def ebe_roofline(avg_el_ms, launches, extra):
-        nel = args.n ** 3
+        nel = mesh.nels
         flops = float(nel) * EBE_FLOPS_PER_HEX8
         achieved = flops / (avg_el_ms * 1e-3) / 1e12
-        r = {"bound": "mfma", "pipe": "fp64 FMA (v_fma_f64; MI355X quotes one 78.6 TFLOP/s peak for vector fp64 and f64 MFMA)",
+        r = {"bound": "fp64_valu",
+             "pipe": "fp64 vector FMA (v_fma_f64, no MFMA in the kernel); peak = 256 CUs x 128 flop/clk x 2.4 GHz, the "
+                     "data-sheet figure for vector fp64",
              "kernel": "k_ebe_apply<3,8,8> (element-by-element MatMult inside KSPCG)", "achieved": achieved,
              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-             "traffic": traffic_of("ebe_traffic.json", args.n), "algorithmic_flops": flops, "avg_launch_ms": avg_el_ms,
-             "launches": launches}
+             "traffic": traffic_of("ebe_traffic.json"), "algorithmic_flops": flops, "avg_launch_ms": avg_el_ms,
+             "launches": launches, "flops_model": "as coded (4,928 per hex8), not a minimum-flop count"}
         r.update(extra)
         return r
 
     out = None
     if rank == 0:
         avg_ms = spmv_ms / max(n_spmv, 1)                  # whole MatMult as the KSP sees it
-        if args.mult == "ebe":
+        if args.mult == "ebe" and hex_case:
             roof = ebe_roofline(ebe_el / max(ebe_n, 1), ebe_n,
-                                {"matmult_ms": avg_ms, "gather_ms": ebe_ga / max(ebe_n, 1), "penalty_ms": ebe_pe / max(ebe_n, 1)})
+                                {"matmult_ms": avg_ms, "gather_ms": ebe_ga / max(ebe_n, 1), "penalty_ms": ebe_pe / max(ebe_n, 1),
+                                 "sampled": f"every {period}th product of the timed solves"})
             side = {"spmv_roofline": spmv_roofline(other[1], 40, "40 back-to-back launches beside the timed solve")}
+        elif args.mult == "ebe":
+            # quad4: the per-element flop count of the 2-D kernel is not tabulated; the bandwidth-bound SpMV of the
+            # same matrix, timed beside the solve, carries the roofline of this configuration
+            roof = spmv_roofline(other[1], 40, "40 back-to-back launches beside the timed solve; the timed solve applies "
+                                               "Mat_K element by element")
+            roof["ebe_matmult_ms"] = avg_ms
+            side = {}
         else:
-            roof = spmv_roofline(avg_ms, n_spmv, "inside KSPCG")
+            roof = spmv_roofline(avg_ms, n_spmv, f"inside KSPCG, every {period}th launch sampled")
             side = {"ebe_matmult_ms": other[1]}
+        if hex_case:
+            workload = (f"config 3: {args.n}^3 hex8 cube per GPU, E=3e10 nu=0.25, z=0 clamped, "
+                        f"top face u_z=-0.01*n by penalty, CG/{args.pc} rtol={args.rtol:.3g}, "
+                        f"MatMult {'element-by-element' if args.mult == 'ebe' else 'assembled SpMV'}")
+        else:
+            workload = (f"config 2: {args.n}^2 quad4 plane-strain plate, E=3e10 nu=0.25, left edge clamped, f_x=1e6 on "
+                        f"every right-edge node, CG/{args.pc} rtol={args.rtol:.3g}, "
+                        f"MatMult {'element-by-element' if args.mult == 'ebe' else 'assembled SpMV'}")
         out = {
             "metric": "DOF/sec assemble+solve (3D hex linear elastic); CG SpMV GB/s vs HBM roofline",
             "value": value, "unit": "DOF/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"config 3: {args.n}^3 hex8 cube per GPU, E=3e10 nu=0.25, z=0 clamped, "
-                                   f"top face u_z=-0.01*n by penalty, CG/{args.pc} rtol={args.rtol:.3g}, "
-                                   f"MatMult {'element-by-element' if args.mult == 'ebe' else 'assembled SpMV'}",
+            "config": {"workload": workload,
                        "bricks": list(grid), "dof_global": ndof_global, "dof_per_gpu": nrows, "nnz_per_gpu": nnz,
                        "cg_iterations": its, "converged_reason": reason,
                        "ms_per_cg_iteration": t_sol / args.steps * 1e3 / max(its, 1),
-                       "t_assemble_ms": t_asm / args.steps * 1e3, "t_solve_ms": t_sol / args.steps * 1e3},
+                       "t_assemble_ms": t_asm / args.steps * 1e3, "t_solve_ms": t_sol / args.steps * 1e3,
+                       "t_assemble_first_step_ms": None if t_first is None else t_first * 1e3},
             "roofline": roof,
         }
         out.update(side)
-        if world > 1 and args.n == 149 and args.jitter == 0.0:
+        if world > 1 and args.n == 149 and args.jitter == 0.0 and hex_case:
             # weak scaling of a non-optimal-order solver: the global problem needs more iterations (measured on
             # one GPU holding the whole problem, DESIGN.md section 5: 724 / 1102 / 1048 / 1412 at N = 1 / 2 / 4 / 8)
             out["config"]["cg_iterations_at_n1"] = 724
@@ -269,7 +352,7 @@ def main():
     # behind the same KSP surface -- reported beside the CG/Jacobi headline as config.pc_mg.  At N>1 the
     # path (global box grid, all-reduced level-1 operator) has only been rehearsed with the in-process
     # communicator, so a watchdog guards the headline: if the measurement does not finish in
-    # --mg-timeout seconds every rank stops, rank 0 having printed the line without it.
+    # --mg-timeout seconds every rank stops (exit status 3), rank 0 having printed the line without it.
     if args.pc == "jacobi" and not args.no_mg:
         finished = threading.Event()
         if world > 1:
@@ -278,11 +361,12 @@ def main():
                     if out is not None:
                         out["config"]["pc_mg"] = {"error": f"abandoned after {args.mg_timeout:.0f} s"}
                         print(json.dumps(out), flush=True)
-                    os._exit(0)
+                    os._exit(3)
             threading.Thread(target=watchdog, daemon=True).start()
         mg_line = None
         try:
             prob.ksp.set_from_options(f"-pc_type mg -pc_mg_type additive -mat_mult_type {args.mult}")
+            prob.ksp.set_profiling(0)
             for _ in range(args.warmup):
                 one_step()
             barrier()
@@ -309,19 +393,21 @@ def main():
                 raise
             # the ranks are no longer in step: no further collective (not even the tear-down) is safe.
             # Rank 0 prints the headline with the error noted; a rank 0 stuck in a collective is
-            # released by its watchdog.
+            # released by its watchdog.  Exit status 3 tells the launcher the extra leg failed.
             if out is not None:
                 out["config"]["pc_mg"] = {"error": repr(e)[:300]}
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            os._exit(3)
         finished.set()
         if out is not None and mg_line is not None:
             out["config"]["pc_mg"] = mg_line
 
     if rank == 0:
         if world == 1 and not args.no_cpu:
-            threads = max(1, min(args.cpu_threads, os.cpu_count() or 1))
-            out["cpu_baseline"] = cpu_baseline(args.n, its, threads)
+            hc = host_cores()
+            threads = args.cpu_threads if args.cpu_threads > 0 else hc["use"]
+            out["cpu_baseline"] = cpu_baseline(mesh, label, its, threads, args.cpu_cg_its)
+            out["cpu_baseline"]["host"] = hc
             out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     prob.destroy()

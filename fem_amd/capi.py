@@ -412,11 +412,12 @@ class Mat:
     def mult(self, x: Vec, y: Vec):
         _ck(_lib.fem_mat_mult(self.h, x.h, y.h))
 
-    def set_profiling(self, on: bool):
-        _ck(_lib.fem_mat_set_profiling(self.h, 1 if on else 0))
+    def set_profiling(self, on):
+        """False/0 off; True/1 every product; p > 1 every p-th product."""
+        _ck(_lib.fem_mat_set_profiling(self.h, int(on)))
 
     def get_profile(self, max_products: int):
-        """(n, element_ms, gather_ms, penalty_ms) summed over the first max_products EBE products."""
+        """(n, element_ms, gather_ms, penalty_ms) summed over the n sampled ones of the first max_products EBE products."""
         n = C.c_int(0)
         a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
         _ck(_lib.fem_mat_get_profile(self.h, int(max_products), C.byref(n), C.byref(a), C.byref(b), C.byref(c)))

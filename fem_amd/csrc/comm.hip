@@ -148,23 +148,27 @@ struct LocalComm : Comm {
     }
     void exchange(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf, double* recvbuf,
                   hipStream_t s) override {
-        FEM_HIP(hipStreamSynchronize(s));
+        // A failure on one domain must not strand its peers in a barrier: the error is recorded, every
+        // domain still arrives at both barriers, and the failing one throws afterwards.
+        std::string err;
+        if (hipStreamSynchronize(s) != hipSuccess) err = "local exchange: stream synchronisation failed";
         sh->sendbuf[rank] = sendbuf; sh->neigh_rank[rank] = neigh_rank; sh->off[rank] = off; sh->nneigh[rank] = nneigh;
         sh->barrier();
-        for (int i = 0; i < nneigh; i++) {
+        for (int i = 0; i < nneigh && err.empty(); i++) {
             const int q = neigh_rank[i];
             const size_t cnt = off[i + 1] - off[i];
             int idx = -1;
             for (int k = 0; k < sh->nneigh[q]; k++)
                 if (sh->neigh_rank[q][k] == rank) idx = k;
-            FEM_CHECK(idx >= 0, 62, "local exchange: neighbour lists are not symmetric");
-            FEM_CHECK(sh->off[q][idx + 1] - sh->off[q][idx] == cnt, 62, "local exchange: interface sizes differ");
-            if (cnt)
-                FEM_HIP(hipMemcpyAsync(recvbuf + off[i], sh->sendbuf[q] + sh->off[q][idx], sizeof(double) * cnt,
-                                       hipMemcpyDeviceToDevice, s));
+            if (idx < 0) { err = "local exchange: neighbour lists are not symmetric"; break; }
+            if (sh->off[q][idx + 1] - sh->off[q][idx] != cnt) { err = "local exchange: interface sizes differ"; break; }
+            if (cnt && hipMemcpyAsync(recvbuf + off[i], sh->sendbuf[q] + sh->off[q][idx], sizeof(double) * cnt,
+                                      hipMemcpyDeviceToDevice, s) != hipSuccess)
+                err = "local exchange: device-to-device copy failed";
         }
-        FEM_HIP(hipStreamSynchronize(s));
+        if (hipStreamSynchronize(s) != hipSuccess && err.empty()) err = "local exchange: stream synchronisation failed";
         sh->barrier();
+        FEM_CHECK(err.empty(), 62, err);
     }
 };
 

@@ -818,8 +818,9 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
     fem_mesh m = A->mesh;
     hipStream_t s = A->ctx->stream;
     double* part = partial ? partial : A->ebe_partial.p;
+    const bool sample = A->profiling > 0 && (A->prod_count++ % (size_t)A->profiling) == 0;
     auto mark = [&] {   // profiling: one event before the element kernels and one after each stage
-        if (!A->profiling) return;
+        if (!sample) return;
         if (A->pev_used == A->pev.size()) { hipEvent_t e; FEM_HIP(hipEventCreate(&e)); A->pev.push_back(e); }
         FEM_HIP(hipEventRecord(A->pev[A->pev_used++], s));
     };
@@ -850,14 +851,19 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
 
 void mat_set_profiling_impl(fem_mat A, int on)
 {
-    A->profiling = on != 0;
+    A->profiling = on > 0 ? on : 0;
     A->pev_used = 0;
+    A->prod_count = 0;
 }
-// sums over the first `max_products` element-by-element products recorded since profiling was switched on
+// sums over the sampled products among the first `max_products` element-by-element products since profiling
+// was switched on (sample j is product j * period)
 void mat_get_profile_impl(fem_mat A, int max_products, int* n, double* element_ms, double* gather_ms, double* penalty_ms)
 {
     A->ctx->bind();
-    const size_t have = A->pev_used / 4, take = std::min<size_t>(have, (size_t)std::max(max_products, 0));
+    const size_t period = (size_t)std::max(A->profiling, 1);
+    const size_t have = A->pev_used / 4;
+    const size_t allowed = ((size_t)std::max(max_products, 0) + period - 1) / period;
+    const size_t take = std::min(have, allowed);
     double t[3] = {0.0, 0.0, 0.0};
     if (take) FEM_HIP(hipEventSynchronize(A->pev[4 * take - 1]));
     for (size_t k = 0; k < take; k++)
@@ -989,12 +995,27 @@ void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval,
         add_tractions();
     }
     if (nbcs > 0) {
-        for (int i = 0; i < nbcs; i++)
-            FEM_CHECK(bcnode[(size_t)i * (1 + pd)] >= 0 && bcnode[(size_t)i * (1 + pd)] < m->nnds, 3,
-                      "fem_form_rhs: BC node out of range");
-        d_bc.alloc((size_t)nbcs * (1 + pd)); d_bc.upload(bcnode, d_bc.n, s);
-        d_bcval.alloc((size_t)nbcs * pd); d_bcval.upload(bcval, d_bcval.n, s);
-        hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, pd, d_bc.p, d_bcval.p, dt, t_total, F);
+        // the reference INSERTs record after record (src/m_global.F90:439-455): where several records
+        // constrain the same dof the last one's value stands -- merged here, one record per node
+        std::vector<int> pos((size_t)m->nnds, -1), mb;
+        std::vector<double> mv;
+        for (int i = 0; i < nbcs; i++) {
+            const int* rec = bcnode + (size_t)i * (1 + pd);
+            FEM_CHECK(rec[0] >= 0 && rec[0] < m->nnds, 3, "fem_form_rhs: BC node out of range");
+            int& p = pos[rec[0]];
+            if (p < 0) {
+                p = (int)(mb.size() / (1 + pd));
+                mb.push_back(rec[0]);
+                for (int d = 0; d < pd; d++) { mb.push_back(1); mv.push_back(0.0); }
+            }
+            for (int d = 0; d < pd; d++)
+                if (rec[1 + d] == 0) { mb[(size_t)p * (1 + pd) + 1 + d] = 0; mv[(size_t)p * pd + d] = bcval[(size_t)i * pd + d]; }
+        }
+        const int nm = (int)(mb.size() / (1 + pd));
+        d_bc.alloc(mb.size()); d_bc.upload(mb.data(), mb.size(), s);
+        d_bcval.alloc(mv.size()); d_bcval.upload(mv.data(), mv.size(), s);
+        hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(nm, 256)), dim3(256), 0, s, nm, pd, d_bc.p, d_bcval.p, dt, t_total, F);
+        FEM_HIP(hipStreamSynchronize(s));   // the merged host lists die at scope end
     }
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));

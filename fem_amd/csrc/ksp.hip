@@ -95,7 +95,10 @@ __global__ void __launch_bounds__(256) k_dot_partial(const double* __restrict__ 
 __global__ void __launch_bounds__(1024) k_reduce(const double* __restrict__ p0, const double* __restrict__ p1, int n,
                                                  double* __restrict__ out, const int* __restrict__ done)
 {
-    if (done && *done) return;
+    if (done && *done) {   // the all-reduce behind a finished solve still runs: keep its operand finite
+        if (threadIdx.x == 0) { out[0] = 0.0; if (p1) out[1] = 0.0; }
+        return;
+    }
     __shared__ double sh[16];
     double s0 = 0.0, s1 = 0.0;
     for (int i = threadIdx.x; i < n; i += 1024) { s0 += p0[i]; if (p1) s1 += p1[i]; }
@@ -290,7 +293,7 @@ struct fem_ksp_s {
     int its = 0, reason = 0;
     double rnorm = 0.0;
     // profiling
-    bool profiling = false;
+    int profiling = 0;   // 0 off, p > 0: every p-th iteration's MatMult is bracketed by events
     std::vector<hipEvent_t> ev;
     int n_spmv = 0;
     double spmv_ms = 0.0, solve_ms = 0.0;
@@ -471,13 +474,16 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // p.w partials of a large SpMV grid are summed by one small kernel first; small grids
     // (and z.z / z.r, at most 1024 partials) are summed inside the consuming kernel
     const bool reduce_pw_first = comm || A->spmv_grid > 2048;
+    int queued = 0;   // iterations enqueued so far (the profile samples iteration j * period)
     auto one_iteration = [&] {
         hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
                            k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr);
-        if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+        const bool sample = k->profiling > 0 && (queued % k->profiling) == 0;
+        queued++;
+        if (sample) FEM_HIP(hipEventRecord(next_event(), s));
         mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
-        if (k->profiling) FEM_HIP(hipEventRecord(next_event(), s));
+        if (sample) FEM_HIP(hipEventRecord(next_event(), s));
         if (reduce_pw_first)
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr,
                                A->spmv_grid, &st->red[2], &st->done);
@@ -538,8 +544,8 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
         float ms = 0;
         FEM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
         k->solve_ms = ms;
-        // only the launches that actually ran (before `done`) are counted
-        const int nrun = std::min<size_t>(evn / 2, (size_t)std::max(k->its, 0));
+        // only the sampled launches that actually ran (before `done`) are counted
+        const int nrun = (int)std::min<size_t>(evn / 2, ((size_t)std::max(k->its, 0) + k->profiling - 1) / k->profiling);
         double tot = 0;
         for (int i = 0; i < nrun; i++) {
             FEM_HIP(hipEventElapsedTime(&ms, k->ev[2 * i], k->ev[2 * i + 1]));
@@ -582,7 +588,12 @@ double vec_dot(fem_vec x, fem_vec y)
 
 // accessors for capi.cpp
 fem_ksp ksp_new(fem_ctx ctx) { auto* k = new fem_ksp_s; k->ctx = ctx; return k; }
-void ksp_delete(fem_ksp k) { delete k; }
+void ksp_delete(fem_ksp k)
+{
+    // the buffers go back to the pool of the device they were allocated on
+    if (k->ctx) k->ctx->bind();
+    delete k;
+}
 void ksp_set_operators(fem_ksp k, fem_mat A) { k->A = A; k->setup_done = false; }
 void ksp_set_type(fem_ksp k, const char* t)
 {
@@ -619,7 +630,7 @@ int ksp_get_history(fem_ksp k, double* hist, int len)
     }
     return std::max(n, 0);
 }
-void ksp_set_profiling(fem_ksp k, int on) { k->profiling = on != 0; }
+void ksp_set_profiling(fem_ksp k, int on) { k->profiling = on > 0 ? on : 0; }
 void ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_ms)
 {
     if (n_spmv) *n_spmv = k->n_spmv;

@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(256) k_apply_kbc(int nbcs, const int* __restri
                                                    const int* __restrict__ bcol, double* __restrict__ val,
                                                    const unsigned char* __restrict__ owned, double penalty,
                                                    int* __restrict__ bc_dof, double* __restrict__ bc_shift,
-                                                   int* __restrict__ bc_node)
+                                                   double* __restrict__ bc_diag, int* __restrict__ bc_node)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbcs) return;
@@ -241,10 +241,33 @@ __global__ void __launch_bounds__(256) k_apply_kbc(int nbcs, const int* __restri
         if (bc_dof) {   // first application after an assembly: remember what the INSERT replaces
             bc_dof[(size_t)i * BS + r] = fixed ? row * BS + r : -1;
             bc_shift[(size_t)i * BS + r] = fixed ? pv - *d : 0.0;
+            bc_diag[(size_t)i * BS + r] = *d;
             if (r == 0) bc_node[row] = i * BS;
         }
         if (fixed) *d = pv;
     }
+}
+
+// Undo of a previous ApplyKBC (a different constraint list arrives without a fresh assembly): put the
+// assembled diagonal back on the dofs the old list had replaced.
+template <int BS>
+__global__ void __launch_bounds__(256) k_restore_kbc(int nbcs, const int* __restrict__ bcnode,
+                                                     const int* __restrict__ rowlen, const int* __restrict__ boff,
+                                                     const int* __restrict__ bcol, double* __restrict__ val,
+                                                     const double* __restrict__ bc_diag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbcs) return;
+    const int row = bcnode[(size_t)i * (1 + BS)];
+    const int o0 = boff[row >> 6], lane = row & 63, len = rowlen[row];
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (bcol[(size_t)(o0 + mid) * 64 + lane] < row) lo = mid + 1; else hi = mid;
+    }
+    for (int r = 0; r < BS; r++)
+        if (bcnode[(size_t)i * (1 + BS) + 1 + r] == 0)
+            val[((size_t)(o0 + lo) * BS * BS + r * BS + r) * 64 + lane] = bc_diag[(size_t)i * BS + r];
 }
 
 }  // namespace fem
@@ -359,39 +382,72 @@ void mat_get_diagonal_raw(fem_mat A, double* d)
                            A->boff.p, A->bcol.p, A->val.p, d);
 }
 
-void mat_apply_kbc_impl(fem_mat A, int nbcs, const int* bcnode)
+void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
 {
-    if (nbcs <= 0) return;
+    if (nbcs_in <= 0) return;
     fem_ctx ctx = A->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
     const int pd = A->bs;
-    for (int i = 0; i < nbcs; i++)
-        FEM_CHECK(bcnode[(size_t)i * (1 + pd)] >= 0 && bcnode[(size_t)i * (1 + pd)] < A->nbrows, 3,
-                  "fem_mat_apply_kbc: node id out of range");
-    DBuf<int> d_bc((size_t)nbcs * (1 + pd));
-    d_bc.upload(bcnode, (size_t)nbcs * (1 + pd), s);
+    // One record per node.  The reference INSERTs the penalty for every record in turn
+    // (src/m_global.F90:264-299), so a dof is constrained as soon as ANY record of its node
+    // flags it: records naming the same node are merged before the device sees them (the
+    // per-node tables of the element-by-element product hold one entry per node).
+    std::vector<int> merged;
+    {
+        std::vector<int> pos((size_t)A->nbrows, -1);
+        merged.reserve((size_t)nbcs_in * (1 + pd));
+        for (int i = 0; i < nbcs_in; i++) {
+            const int* rec = bcnode_in + (size_t)i * (1 + pd);
+            FEM_CHECK(rec[0] >= 0 && rec[0] < A->nbrows, 3, "fem_mat_apply_kbc: node id out of range");
+            int& p = pos[rec[0]];
+            if (p < 0) {
+                p = (int)(merged.size() / (1 + pd));
+                merged.push_back(rec[0]);
+                for (int d = 0; d < pd; d++) merged.push_back(rec[1 + d] == 0 ? 0 : 1);
+            } else {
+                for (int d = 0; d < pd; d++)
+                    if (rec[1 + d] == 0) merged[(size_t)p * (1 + pd) + 1 + d] = 0;
+            }
+        }
+    }
+    const int nbcs = (int)(merged.size() / (1 + pd));
     const unsigned char* owned = A->mesh->halo ? A->mesh->halo->owned.p : nullptr;
+    // a different list than the one already applied to this assembly: put the assembled diagonal back first
+    if (A->bc_saved && merged != A->h_bc) {
+        const int nold = (int)(A->h_bc.size() / (1 + pd));
+        DBuf<int> d_old(A->h_bc.size());
+        d_old.upload(A->h_bc.data(), A->h_bc.size(), s);
+        if (pd == 3)
+            hipLaunchKernelGGL(k_restore_kbc<3>, dim3(cdiv(nold, 256)), dim3(256), 0, s, nold, d_old.p, A->rowlen.p,
+                               A->boff.p, A->bcol.p, A->val.p, A->bc_diag.p);
+        else
+            hipLaunchKernelGGL(k_restore_kbc<2>, dim3(cdiv(nold, 256)), dim3(256), 0, s, nold, d_old.p, A->rowlen.p,
+                               A->boff.p, A->bcol.p, A->val.p, A->bc_diag.p);
+        FEM_HIP(hipStreamSynchronize(s));
+        A->bc_saved = false;
+    }
+    DBuf<int> d_bc(merged.size());
+    d_bc.upload(merged.data(), merged.size(), s);
     // the element-by-element product needs (inserted value - assembled diagonal) of every penalty row;
     // only the first ApplyKBC after an assembly sees the assembled diagonal
     int* bcd = nullptr;
-    double* bcs = nullptr;
+    double *bcs = nullptr, *bcg = nullptr;
     if (!A->bc_saved) {
         A->nbc_dof = nbcs * pd;
-        A->bc_dof.alloc((size_t)A->nbc_dof); A->bc_shift.alloc((size_t)A->nbc_dof);
+        A->bc_dof.alloc((size_t)A->nbc_dof); A->bc_shift.alloc((size_t)A->nbc_dof); A->bc_diag.alloc((size_t)A->nbc_dof);
         A->bc_node.alloc((size_t)A->nbrows);
         FEM_HIP(hipMemsetAsync(A->bc_node.p, 0xff, sizeof(int) * (size_t)A->nbrows, s));   // -1 everywhere
-        bcd = A->bc_dof.p; bcs = A->bc_shift.p;
-    } else {
-        FEM_CHECK(A->nbc_dof == nbcs * pd, 5, "fem_mat_apply_kbc: a different constraint list needs a fresh assembly");
+        bcd = A->bc_dof.p; bcs = A->bc_shift.p; bcg = A->bc_diag.p;
     }
     if (pd == 3)
         hipLaunchKernelGGL(k_apply_kbc<3>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, A->bc_node.p);
+                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
     else
         hipLaunchKernelGGL(k_apply_kbc<2>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, A->bc_node.p);
+                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
     A->bc_saved = true;
+    A->h_bc = std::move(merged);
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
 }

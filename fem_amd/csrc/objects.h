@@ -90,11 +90,14 @@ struct fem_mat_s {
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
     fem::DBuf<int> bc_dof;
     fem::DBuf<double> bc_shift;
+    fem::DBuf<double> bc_diag;              // assembled diagonal under the rows of bc_dof (undo of a changed list)
+    std::vector<int> h_bc;                  // the merged constraint list (one record per node) now applied
     fem::DBuf<int> bc_node;                 // [nbrows] offset of a node's rows in bc_dof/bc_shift, or -1
     int nbc_dof = 0;
     bool bc_saved = false;
     // HIP-event profile of the element-by-element product (fem_mat_set_profiling): four events per product
-    bool profiling = false;
+    int profiling = 0;                      // 0 off, p > 0: every p-th product is bracketed by events
+    size_t prod_count = 0;                  // products since profiling was switched on
     std::vector<hipEvent_t> pev;
     size_t pev_used = 0;
     ~fem_mat_s() {

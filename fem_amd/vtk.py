@@ -15,7 +15,8 @@ VTK_ID = {TRI: 5, QUA: 9, TET: 10, HEX: 12, COH: 9}
 
 
 def _f0(v: float, d: int) -> str:
-    """Fortran F0.d edit descriptor (no leading zero, sign kept on negative zero results)."""
+    """Fortran F0.d edit descriptor: no leading zero; a negative value that rounds to zero keeps its sign
+    (`-.000000`, as in the reference's own rank files)."""
     s = f"{v:.{d}f}"
     if s.startswith("0."):
         return s[1:]
@@ -34,7 +35,7 @@ def vtk_text(mesh: Mesh, u: np.ndarray, stress: np.ndarray, elements=None) -> st
            f"POINTS {len(used)} double"]
     for g in used:
         p = list(mesh.coords[g]) + [0.0] * (3 - pd)
-        out.append("".join(_f0(x, 3) + " " for x in p))
+        out.append(" ".join(_f0(x, 3) for x in p))      # (3(F0.3,1X)): no blank after the last value
     ncol = sum(len(mesh.element_nodes(e)) + 1 for e in els)
     out.append(f"CELLS {len(els)} {ncol}")
     for e in els:
@@ -46,11 +47,11 @@ def vtk_text(mesh: Mesh, u: np.ndarray, stress: np.ndarray, elements=None) -> st
     out.append(f"SCALARS STRESS FLOAT {cp}")
     out.append("LOOKUP_TABLE DEFAULT")
     for g in used:
-        out.append("".join(_f0(x, 6) + " " for x in stress[g]))
+        out.append(" ".join(_f0(x, 6) for x in stress[g]))
     out.append("VECTORS displacements double")
     for g in used:
         p = list(u[g]) + [0.0] * (3 - pd)
-        out.append("".join(_f0(x, 6) + " " for x in p))
+        out.append(" ".join(_f0(x, 6) for x in p))
     return "\n".join(out) + "\n"
 
 

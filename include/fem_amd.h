@@ -146,9 +146,10 @@ int fem_mat_get_csr(fem_mat mat, int *rowptr, int *colind, double *val);
  * matrix read; needs the usual assemble + ApplyKBC first, which also serve the preconditioners);
  * deterministic, about twice as fast as the SpMV on hex8 meshes.  Also `-mat_mult_type` of the KSP. */
 int fem_mat_set_mult_type(fem_mat mat, const char *type);
-/* HIP-event profile of the element-by-element product on the product's own stream: sums over the
- * first `max_products` products since profiling was switched on (element kernels / node gather /
- * penalty rows, in ms). */
+/* HIP-event profile of the element-by-element product on the product's own stream.  on = 0: off;
+ * on = p > 0: every p-th product is bracketed by events (p = 1: all of them).  get_profile sums over
+ * the n sampled products among the first `max_products` products since profiling was switched on
+ * (element kernels / node gather / penalty rows, in ms). */
 int fem_mat_set_profiling(fem_mat mat, int on);
 int fem_mat_get_profile(fem_mat mat, int max_products, int *n, double *element_ms, double *gather_ms, double *penalty_ms);
 /* MatMult: y = K x (sub-assembled product + halo sum when a halo is attached). */
@@ -204,8 +205,9 @@ int fem_ksp_get_residual_norm(fem_ksp ksp, double *rnorm);
 int fem_ksp_get_converged_reason(fem_ksp ksp, int *reason);
 /* KSPSetResidualHistory / KSPGetResidualHistory: copies min(len, its+1) norms. */
 int fem_ksp_get_residual_history(fem_ksp ksp, double *hist, int len, int *n);
-/* Per-solve HIP-event profile on the solve's stream: number of MatMult launches
- * and their summed duration, total solve duration. */
+/* Per-solve HIP-event profile on the solve's stream.  on = 0: off; on = p > 0: the MatMult of every
+ * p-th iteration is bracketed by events.  get_profile: number of sampled MatMult launches that ran,
+ * their summed duration, total solve duration. */
 int fem_ksp_set_profiling(fem_ksp ksp, int on);
 int fem_ksp_get_profile(fem_ksp ksp, int *n_spmv, double *spmv_ms, double *solve_ms);
 

@@ -267,6 +267,36 @@ class Oracle:
             raise RuntimeError(f"oracle solve failed: {nsteps}")
         return u, s.reshape(p.nnds, cp, order="F"), its[:nsteps]
 
+    # ---- bench.py's cpu_baseline leg (oracle/cpu_baseline.c) ----
+    def cpu_baseline(self, m, nthreads, ncg, rtol=DEFAULT_RTOL, nprod=0, want_arrays=False):
+        """Timed all-core run of the path; returns a dict of timings (and the matrix / iterate when asked)."""
+        p, keep = make_problem(m)
+        t = np.zeros(6); info = np.zeros(3, dtype=np.int64)
+        N = p.nnds * p.pdim
+        x = rp = ci = val = None
+        if want_arrays:
+            nnz = len(self.csr_pattern(m)[1])
+            x = np.zeros(N); rp = np.zeros(N + 1, dtype=np.int32); ci = np.zeros(nnz, dtype=np.int32); val = np.zeros(nnz)
+        self.L.dm_cpu_baseline.restype = C.c_int
+        rc = self.L.dm_cpu_baseline(C.byref(p), int(nthreads), int(ncg), C.c_double(rtol), int(nprod), _d(t),
+                                    info.ctypes.data_as(C.POINTER(C.c_longlong)),
+                                    _d(x) if want_arrays else None, _i(rp) if want_arrays else None,
+                                    _i(ci) if want_arrays else None, _d(val) if want_arrays else None)
+        if rc != 0:
+            raise RuntimeError(f"dm_cpu_baseline failed: {rc}")
+        out = {"t_pattern": t[0], "t_assemble": t[1], "t_setup": t[2], "t_cg_iteration": t[3], "t_ebe_product": t[4],
+               "t_spmv": t[5], "nnz": int(info[0]), "its": int(info[1]), "reason": int(info[2])}
+        if want_arrays:
+            out.update(x=x, rowptr=rp, colind=ci, val=val)
+        return out
+
+    def cpu_ebe_mult(self, m, x, nthreads=1):
+        p, keep = make_problem(m)
+        y = np.zeros(p.nnds * p.pdim)
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        self.L.dm_cpu_ebe_mult(C.byref(p), int(nthreads), _d(x), _d(y))
+        return y
+
 
 class RefLib:
     """The reference's own element routines (flang build of /root/reference)."""

@@ -132,3 +132,44 @@ def test_ebe_eight_domains_medium_size(opts):
             common, ir, iq = np.intersect1d(out[r][5], out[q][5], return_indices=True)
             if common.size:
                 assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])
+
+
+def test_duplicate_bc_records_and_a_changed_list(gpu_ctx, oracle):
+    """The reference INSERTs BC record after record (src/m_global.F90:264-299, :439-455): several records may name
+    one node, a dof is constrained as soon as one of them flags it, and for the force the last value stands.
+    Both products (assembled / element by element) must hold the same penalty rows as the oracle's sequential
+    INSERT; a different list applied without a fresh assembly must first give the assembled diagonal back."""
+    import copy
+    m = structured_hex(5, 4, 3, jitter=0.2)
+    top = m.bcnode[-3:].copy()
+    extra = np.array([[top[0, 0], 0, 1, 1], [top[0, 0], 1, 0, 1], [top[1, 0], 1, 1, 0], [m.bcnode[0, 0], 0, 0, 0]], dtype=np.int32)
+    m2 = copy.deepcopy(m)
+    m2.bcnode = np.vstack([m.bcnode, extra]).astype(np.int32)
+    m2.bcval = np.vstack([m.bcval, [[0.3, 9.0, 9.0], [9.0, -0.2, 9.0], [9.0, 9.0, 0.05], [0.0, 0.0, 0.0]]])
+    rp, ci = oracle.csr_pattern(m2)
+    vr = oracle.assemble(m2, rp, ci, apply_bc=True)
+    dm = capi.DeviceMesh(gpu_ctx, m2)
+    K = capi.Mat(dm)
+    K.assemble_elements(); K.apply_kbc()
+    x = np.random.default_rng(11).standard_normal(m2.ndof)
+    X, Ya, Ye, F = (capi.Vec(gpu_ctx, m2.ndof) for _ in range(4))
+    X.set_array(x)
+    row_scale = np.abs(oracle.spmv(rp, ci, np.abs(vr), np.abs(x)))
+    yr = oracle.spmv(rp, ci, vr, x)
+    K.mult(X, Ya)
+    K.set_mult_type("ebe"); K.mult(X, Ye)
+    assert (np.abs(Ya.get_array() - yr) <= 1e-13 * row_scale).all()
+    assert (np.abs(Ye.get_array() - yr) <= 1e-13 * row_scale).all()
+    dm.form_rhs(F, 0.0, m2.dt)
+    assert np.array_equal(F.get_array(), oracle.form_rhs(m2, 0.0, m2.dt))
+    # now the shorter list of `m` on the same (already penalised) matrix: the extra penalties must go away
+    vr1 = oracle.assemble(m, rp, ci, apply_bc=True)
+    yr1 = oracle.spmv(rp, ci, vr1, x)
+    rs1 = np.abs(oracle.spmv(rp, ci, np.abs(vr1), np.abs(x)))
+    K.apply_kbc(m.bcnode)
+    K.mult(X, Ye)
+    K.set_mult_type("assembled"); K.mult(X, Ya)
+    assert (np.abs(Ya.get_array() - yr1) <= 1e-13 * rs1).all()
+    assert (np.abs(Ye.get_array() - yr1) <= 1e-13 * rs1).all()
+    for o in (X, Ya, Ye, F, K, dm):
+        o.destroy()

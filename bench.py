@@ -25,6 +25,7 @@ import time
 # the cpu_baseline leg runs OpenMP threads pinned one per physical core, spread over both sockets, so that
 # first-touch placement (oracle/cpu_baseline.c) keeps every thread's rows in its own socket's DRAM; libgomp
 # reads these when it is first loaded (numpy / torch pull it in), hence before any import
+_AFFINITY_AT_START = sorted(os.sched_getaffinity(0))   # libgomp will bind the main thread to its first place
 os.environ.setdefault("OMP_PROC_BIND", "spread")
 os.environ.setdefault("OMP_PLACES", "cores")
 
@@ -50,9 +51,10 @@ def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:
 
 
 def host_cores() -> dict:
-    """Physical cores this process may use: distinct (socket, core) pairs among the CPUs of its affinity mask,
-    capped by the cgroup CPU quota when there is one."""
-    allowed = sorted(os.sched_getaffinity(0))
+    """Physical cores this process may use: distinct (socket, core) pairs among the CPUs of its affinity mask (as
+    it was when the process started), capped by the cgroup CPU quota when there is one (the GPU boxes of this pool
+    expose all 256 CPUs of a 2 x EPYC 9575F host to a job, but cpu.max grants it 16 CPUs of run time)."""
+    allowed = _AFFINITY_AT_START
     cores = set()
     try:
         for c in allowed:

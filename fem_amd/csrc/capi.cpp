@@ -266,7 +266,7 @@ int fem_mat_zero_entries(fem_mat A)
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
     A->ctx->bind();
-    A->val.zero(A->ctx->stream);
+    A->lazy_zero = true;   // materialised by the first reader; the assembly overwrites instead (fem_mat_s::values())
     A->bc_saved = false;   // the next ApplyKBC sees a freshly assembled diagonal again
     FEM_CATCH
 }

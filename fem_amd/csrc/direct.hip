@@ -462,10 +462,10 @@ void BandCholesky::setup(fem_mat A_)
     ab.alloc((size_t)n * (bw + 1));
     ab.zero(s);
     if (bs == 3)
-        hipLaunchKernelGGL(k_band_fill<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->val.p,
+        hipLaunchKernelGGL(k_band_fill<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
                            A->rowlen.p, dperm.p, bw, ab.p);
     else
-        hipLaunchKernelGGL(k_band_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->val.p,
+        hipLaunchKernelGGL(k_band_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
                            A->rowlen.p, dperm.p, bw, ab.p);
     linv.alloc((size_t)((n + NB - 1) / NB) * NB * NB);
     v0.alloc((size_t)n); v1.alloc((size_t)n); v2.alloc((size_t)n);

@@ -1,21 +1,24 @@
 // fem_amd/csrc/elem_kernels.hip -- the element hot loops as HIP kernels:
-//   * FormElKE + scatter-add into Mat_K  (src/m_local.F90:21-67, src/main.F90:157-168)
-//   * CalcElStress + RecoverNodalStress   (src/m_local.F90:93-123, src/m_global.F90:466-515)
-//   * FormRHS                             (src/m_global.F90:373-455)
+//   * FormElKE + MatSetValues(ADD) into Mat_K  (src/m_local.F90:21-67, src/main.F90:157-168): row-owner assembly
+//   * FormElKE for a caller-supplied batch     (the element-level API)
+//   * CalcElStress + RecoverNodalStress          (src/m_local.F90:93-123, src/m_global.F90:466-515)
+//   * FormRHS                                    (src/m_global.F90:373-455)
+//   * MatMult by element-by-element recomputation
 //
-// Work decomposition (one workgroup = ELB consecutive elements of one type):
-//   phase 1  thread = (element, Gauss point): gathers the element's node
-//            coordinates, forms J, det J and dN/dx (FormdNdetJ) and parks
-//            {dN/dx, w*detJ} in LDS, element index fastest (conflict-free).
-//   phase 2  thread = (element, node a): owns block row a of the element matrix,
-//            K_ab = sum_gp w detJ B_a^T D B_b, written as the closed form of the
-//            isotropic D (no explicit zeros of B are multiplied), and adds each
-//            bs x bs block into the sliced-ELL matrix through the precomputed
-//            slot map.  Lanes of a wavefront are consecutive elements, whose
-//            rows are consecutive nodes on structured numberings, so each
-//            wave-level fp64 atomic touches contiguous 256/512-byte segments.
-// The kernels are scatter-bound (fp64 atomics), not flop-bound: no MFMA.
+// Assembly (k_assemble_rows): one workgroup owns one 64-row slice of the sliced block-ELL matrix and is
+// the only writer of its values -- no atomics, every entry (padding included) stored exactly once with
+// coalesced stores, two assemblies of the same mesh bitwise equal.  Lane = (block row, incidence): each of
+// the <= LPR incident elements of a node per pass gets its own lane, which recomputes that element's
+// kinematics at every Gauss point (J, J^-1, dN/dx -- 8x redundant over the element's nodes, ~120 GFLOP
+// at config 3, against 13 GB of fp64 atomic traffic in the scatter it replaces) and the NPE blocks
+// K_ab = sum_gp w detJ B_a^T D B_b of its row, then adds them to the row's accumulators in LDS through the
+// precomputed slot map.  The LDS image of a slice has the layout of the matrix values, so the write-out is
+// a straight copy.
+// The kernels of the batch API work element-wise: phase 1 thread = (element, Gauss point) parks
+// {dN/dx, w*detJ} in LDS, phase 2 thread = (element, node a) forms block row a of the element matrix.
 #include <hip/hip_runtime.h>
+
+#include <cstdlib>
 
 #include "comm.h"
 #include "scan.h"
@@ -60,28 +63,7 @@ struct DenseSrc {  // caller-supplied ecoords(nodecount,pdim) per element, colum
 
 // ---- sinks for the element matrix ---------------------------------------------------------
 template <int PD, int NPE>
-struct MatSink {  // MatSetValues(ADD_VALUES) into the sliced block-ELL Mat_K
-    static constexpr bool PAIR = (NPE == 8 || (NPE == 4 && PD == 2));  // hex8 / quad4: x-adjacent elements share a face
-    const int* conn;
-    __device__ __forceinline__ long long pair_key(size_t e, int a, int b) const {
-        return ((long long)conn[e * NPE + a] << 32) | (long long)(unsigned)conn[e * NPE + b];
-    }
-    const uint16_t* slot;
-    const int* boff;
-    double* val;
-    __device__ __forceinline__ void add(size_t e, int a, int b, const double (&blk)[PD][PD]) const {
-        const int row = conn[e * NPE + a];
-        const size_t j = (size_t)boff[row >> 6] + slot[e * NPE * NPE + a * NPE + b];
-        double* p = val + j * (PD * PD) * 64 + (row & 63);
-#pragma unroll
-        for (int i = 0; i < PD; i++)
-#pragma unroll
-            for (int q = 0; q < PD; q++) unsafeAtomicAdd(p + (size_t)(i * PD + q) * 64, blk[i][q]);
-    }
-};
-template <int PD, int NPE>
 struct DenseSink {  // k(nd,nd) column-major per element (FormElKE's out-argument)
-    static constexpr bool PAIR = false;
     double* k;
     __device__ __forceinline__ void add(size_t e, int a, int b, const double (&blk)[PD][PD]) const {
         constexpr int ND = NPE * PD;
@@ -93,56 +75,13 @@ struct DenseSink {  // k(nd,nd) column-major per element (FormElKE's out-argumen
     }
 };
 
-// ---- wavefront pre-reduction of shared-node contributions ----------------------------------
-// A wavefront of phase 2 holds 32 consecutive elements x 2 local nodes.  On
-// structured numberings the +x face node of element e and the -x face node of
-// element e+1 are the same global node, and they sit 33 lanes apart
-// (receiver = donor + 33 mod 64).  Instead of two atomics on the same address,
-// the donor hands its value to the receiver with a cross-lane move and stays
-// silent.  The pairing is decided at run time from the node ids (and, for the
-// stiffness, the column node ids), so any mesh is handled: without a match every
-// lane simply issues its own atomic.  A lane that receives never donates (no chains).
-struct WavePair {
-    int donor_lane, recv_lane;
-    bool donate, recv;
-};
-__device__ __forceinline__ WavePair wave_pair(long long key)
-{
-    const int lane = threadIdx.x & 63;
-    WavePair p;
-    p.donor_lane = (lane + 31) & 63;
-    p.recv_lane = (lane + 33) & 63;
-    const long long kd = __shfl(key, p.donor_lane), kr = __shfl(key, p.recv_lane);
-    const bool recv_raw = (kd == key) && key >= 0, donate_raw = (kr == key) && key >= 0;
-    p.donate = donate_raw && !recv_raw;
-    // every lane must execute the cross-lane read (no short-circuit in front of it): a
-    // masked-off source lane would deliver garbage
-    const int donor_donates = __shfl((int)p.donate, p.donor_lane);
-    p.recv = recv_raw && (donor_donates != 0);
-    return p;
-}
-
-// local nodes on the +x face (quad4: 1,2; hex8: 1,2,5,6) and the column visiting order
+// local nodes on the +x face (quad4: 1,2; hex8: 1,2,5,6): the hand-over of the element-by-element product
 template <int NPE, int PD>
 __device__ __forceinline__ bool is_plus_x(int a)
 {
     if constexpr (NPE == 8) return a == 1 || a == 2 || a == 5 || a == 6;
     else if constexpr (NPE == 4 && PD == 2) return a == 1 || a == 2;
     else return false;
-}
-template <int NPE, int PD>
-__device__ __forceinline__ int column_order(bool plus, int k)
-{
-    if constexpr (NPE == 8) {
-        // pairs (+x, -x): (1,0) (2,3) (5,4) (6,7)
-        const int p[4] = {1, 2, 5, 6}, m[4] = {0, 3, 4, 7};
-        return plus ? (k < 4 ? p[k] : m[k - 4]) : (k < 4 ? m[k] : p[k - 4]);
-    } else if constexpr (NPE == 4 && PD == 2) {
-        const int p[2] = {1, 2}, m[2] = {0, 3};
-        return plus ? (k < 2 ? p[k] : m[k - 2]) : (k < 2 ? m[k] : p[k - 2]);
-    } else {
-        return k;
-    }
 }
 
 // ---- element stiffness ----------------------------------------------------------------------
@@ -166,25 +105,17 @@ __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
         G[(q * K + K - 1) * ELB + el] = tab.w[q] * detj;  // weights(i)*detj, src/m_local.F90:64
     }
     __syncthreads();
-    const bool active = (q < NPE && e < (size_t)nel);
-    if (!Sink::PAIR && !active) return;   // with pairing every lane must reach the cross-lane moves
-    const size_t es = active ? e : 0;
-    const int qa = active ? q : 0;
-    const DCoef D = dmat_coef(Ev[es], nuv[es]);
+    if (!(q < NPE && e < (size_t)nel)) return;
+    const DCoef D = dmat_coef(Ev[e], nuv[e]);
     double da[NIP][PD];  // w*detJ * dN_a/dx at every Gauss point
 #pragma unroll
     for (int g = 0; g < NIP; g++) {
         const double w = G[(g * K + K - 1) * ELB + el];
 #pragma unroll
-        for (int d = 0; d < PD; d++) da[g][d] = w * G[(g * K + qa * PD + d) * ELB + el];
+        for (int d = 0; d < PD; d++) da[g][d] = w * G[(g * K + q * PD + d) * ELB + el];
     }
-    // Column order: rows on the +x face visit the +x face columns first, rows on the -x face
-    // the matching -x face columns, so that the two lanes holding the same (row node, column
-    // node) pair of x-adjacent elements reach it in the same trip and can be paired.
-    const bool plus = is_plus_x<NPE, PD>(qa);
 #pragma unroll 1
-    for (int k = 0; k < NPE; k++) {
-        const int b = column_order<NPE, PD>(plus, k);
+    for (int b = 0; b < NPE; b++) {
         double blk[PD][PD];
 #pragma unroll
         for (int i = 0; i < PD; i++)
@@ -207,22 +138,7 @@ __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
                     blk[i][j] += (i == j) ? D.d11 * prod[i] + D.d44 * (dot - prod[i])
                                           : D.d12 * da[g][i] * db[j] + D.d44 * da[g][j] * db[i];
         }
-        if constexpr (Sink::PAIR) {
-            const long long key = active ? sink.pair_key(es, qa, b) : -1 - (long long)threadIdx.x;
-            const WavePair wp = wave_pair(key);
-            if (__any(wp.recv)) {
-#pragma unroll
-                for (int i = 0; i < PD; i++)
-#pragma unroll
-                    for (int j = 0; j < PD; j++) {
-                        const double in = __shfl(blk[i][j], wp.donor_lane);
-                        if (wp.recv) blk[i][j] += in;
-                    }
-            }
-            if (active && !wp.donate) sink.add(es, qa, b, blk);
-        } else {
-            sink.add(es, qa, b, blk);
-        }
+        sink.add(e, q, b, blk);
     }
 }
 
@@ -288,12 +204,13 @@ __device__ __forceinline__ void gp_stress(const double (&dN)[NPE][PD], const dou
 }
 
 // NODAL = false: write Gauss-point stresses estress(nip,cpdim) per element (CalcElStress).
-// NODAL = true : extrapolate to the nodes with N2^-1 (RecoverNodalStress) and
-//                add into stress_node(nnds,cpdim) (column-major, as the reference).
+// NODAL = true : extrapolate to the element's nodes with N2^-1 (RecoverNodalStress) and park them in an
+//                element-major buffer out[(a*CP + c)*nel + e] (consecutive elements write consecutive words);
+//                k_stress_gather then sums every node's entries in a fixed order -- no atomics.
 template <int PD, int NPE, int NIP, int ELB, bool NODAL, class Src, class USrc>
 __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
     k_stress(int type, int nel, Src src, USrc usrc, const double* __restrict__ Ev, const double* __restrict__ nuv,
-             const int* __restrict__ conn, double* __restrict__ out, size_t nn)
+             double* __restrict__ out)
 {
     constexpr int CP = (PD == 2) ? 3 : 6;
     __shared__ double S[NODAL ? NIP * CP * ELB : 1];
@@ -316,25 +233,48 @@ __global__ void __launch_bounds__(ELB*(NIP > NPE ? NIP : NPE))
     }
     if constexpr (NODAL) {
         __syncthreads();
-        const bool active = (q < NPE && e < (size_t)nel);
-        const long long v = active ? (long long)conn[e * NPE + q] : -1 - (long long)threadIdx.x;
-        const WavePair wp = wave_pair(v);   // all lanes take part in the cross-lane moves
+        if (q < NPE && e < (size_t)nel) {
 #pragma unroll
-        for (int c = 0; c < CP; c++) {
-            double sn = 0.0;
-            if (active) {
+            for (int c = 0; c < CP; c++) {
+                double sn = 0.0;
                 if constexpr (NIP == NPE) {  // sigma_node = N2^-1 sigma_gp, src/m_global.F90:506-509
 #pragma unroll
                     for (int g = 0; g < NIP; g++) sn += tab.n2inv[q][g] * S[(g * CP + c) * ELB + el];
                 } else {  // nip == 1: copy, src/m_global.F90:510-513
                     sn = S[c * ELB + el];
                 }
+                out[(size_t)(q * CP + c) * nel + e] = sn;
             }
-            const double from_donor = __shfl(sn, wp.donor_lane);
-            if (wp.recv) sn += from_donor;
-            if (active && !wp.donate) unsafeAtomicAdd(out + (size_t)c * nn + (size_t)v, sn);
         }
     }
+}
+
+struct StressViews {
+    const double* f[4];
+    int nel[4];
+};
+// thread = node: stress_node(n,:) = sum over the incident elements (ascending (group, element) order) of their
+// extrapolated values at n (src/main.F90:258-268), optionally divided by the valence (:277-279) in the same pass
+template <int CP>
+__global__ void __launch_bounds__(256) k_stress_gather(int nn, const int* __restrict__ ptr, const unsigned* __restrict__ lst,
+                                                       StressViews sv, const double* __restrict__ valence,
+                                                       double* __restrict__ S)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    double s[CP];
+#pragma unroll
+    for (int c = 0; c < CP; c++) s[c] = 0.0;
+    for (int k = ptr[v]; k < ptr[v + 1]; k++) {
+        const unsigned code = lst[k];
+        const int g = code >> 30;
+        const size_t e = (code & 0x3fffffffu) >> 3, a = code & 7u, ne = (size_t)sv.nel[g];
+#pragma unroll
+        for (int c = 0; c < CP; c++) s[c] += sv.f[g][(a * CP + c) * ne + e];
+    }
+    const double rv = valence ? valence[v] : 1.0;
+#pragma unroll
+    for (int c = 0; c < CP; c++) S[(size_t)c * nn + v] = valence ? s[c] / rv : s[c];
 }
 
 __global__ void __launch_bounds__(256) k_divide_by_valence(size_t nn, int cp, double* __restrict__ s,
@@ -462,21 +402,256 @@ static void dispatch_type(int type, F&& f)
     }
 }
 
-// main.F90:157-168 for the whole mesh
+// ---- row-owner assembly (main.F90:157-168 for the whole mesh) ----------------------------------------
+namespace fem {
+
+struct AsmGroup {
+    const int* conn;
+    const double *E, *nu;
+    const uint16_t* slot;
+    int type, npe;
+};
+struct AsmGroups {
+    AsmGroup g[4];
+    int ng;
+};
+
+// The NPE blocks K_ab (b = 0..NPE-1) of element e for its local node a:
+//   M_ab = sum_gp (w detJ dN_a/dx) (dN_b/dx)^T, then K_ab = d12 M + d44 M^T + (d11 - d12 - d44) diag(M) + d44 tr(M) I
+// (the closed form of B_a^T D B_b for the isotropic D of DMat, src/m_local.F90:204-228: the material enters after
+// the quadrature sum).  J^-1 is recomputed here for every (element, node) pair; dN/dx is never stored.
+template <int PD, int NPE, int NIP, int TYPE>
+__device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __restrict__ coords, size_t e, int a,
+                                           double (&K)[NPE][PD][PD])
+{
+    const ElemTable& tab = c_tab[TYPE];
+    double X[NPE][PD];
+#pragma unroll
+    for (int b = 0; b < NPE; b++) {
+        const size_t v = (size_t)gv.conn[e * NPE + b];
+#pragma unroll
+        for (int d = 0; d < PD; d++) X[b][d] = coords[v * PD + d];
+    }
+#pragma unroll
+    for (int b = 0; b < NPE; b++)
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int j = 0; j < PD; j++) K[b][i][j] = 0.0;
+#pragma unroll 1
+    for (int g = 0; g < NIP; g++) {
+        double J[PD][PD];
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int j = 0; j < PD; j++) {
+                double sj = 0.0;
+#pragma unroll
+                for (int b = 0; b < NPE; b++) sj += tab.dNxi[g][i][b] * X[b][j];
+                J[i][j] = sj;
+            }
+        double inv[PD][PD], detj;        // inv[i][j] = d xi_j / d x_i, as in dndx_at_gp (FormdNdetJ)
+        if constexpr (PD == 2) {
+            detj = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+            const double rd = 1.0 / detj;
+            inv[0][0] = J[1][1] * rd; inv[0][1] = -J[0][1] * rd;
+            inv[1][0] = -J[1][0] * rd; inv[1][1] = J[0][0] * rd;
+        } else {
+            const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+            const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
+            const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+            detj = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+            const double rd = 1.0 / detj;
+            inv[0][0] = c00 * rd;
+            inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
+            inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
+            inv[1][0] = -c01 * rd;
+            inv[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * rd;
+            inv[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * rd;
+            inv[2][0] = c02 * rd;
+            inv[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * rd;
+            inv[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * rd;
+        }
+        const double wd = tab.w[g] * detj;   // weights(i)*detj, src/m_local.F90:64
+        double da[PD];                       // the row's own node: a differs from lane to lane
+#pragma unroll
+        for (int i = 0; i < PD; i++) {
+            double t = 0.0;
+#pragma unroll
+            for (int j = 0; j < PD; j++) t += inv[i][j] * tab.dNxi[g][j][a];
+            da[i] = wd * t;
+        }
+#pragma unroll
+        for (int b = 0; b < NPE; b++) {
+            double db[PD];
+#pragma unroll
+            for (int i = 0; i < PD; i++) {
+                double t = 0.0;
+#pragma unroll
+                for (int j = 0; j < PD; j++) t += inv[i][j] * tab.dNxi[g][j][b];
+                db[i] = t;
+            }
+#pragma unroll
+            for (int i = 0; i < PD; i++)
+#pragma unroll
+                for (int j = 0; j < PD; j++) K[b][i][j] += da[i] * db[j];
+        }
+    }
+    const DCoef D = dmat_coef(gv.E[e], gv.nu[e]);
+#pragma unroll
+    for (int b = 0; b < NPE; b++) {
+        double M[PD][PD], tr = 0.0;
+#pragma unroll
+        for (int i = 0; i < PD; i++) {
+#pragma unroll
+            for (int j = 0; j < PD; j++) M[i][j] = K[b][i][j];
+            tr += M[i][i];
+        }
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int j = 0; j < PD; j++)
+                K[b][i][j] = (i == j) ? D.d11 * M[i][i] + D.d44 * (tr - M[i][i]) : D.d12 * M[i][j] + D.d44 * M[j][i];
+    }
+}
+
+// One incidence per lane: its element's blocks into the accumulators of its row.  The LDS image holds one row
+// after the other, acc[row*RS + j*BB + c] with an odd row stride RS = 1 (mod 32) where the budget allows: the lanes of
+// a row (different slots j) and the rows of a half-wave then spread over the banks (two-way conflicts at worst on
+// hex8 grids, against eight-way with the rows innermost), and the write-out, which walks the rows, is conflict free.
+// Lanes of one wave-instruction hold different rows, or the same row and different local columns b -- which are
+// different slots unless the slice is flagged `serial`, where the lanes of a row take turns.
+template <int PD, int NPE, int NIP, int TYPE, int LPR>
+__device__ __forceinline__ void rows_add(bool mine, unsigned code, const AsmGroup& gv, const double* __restrict__ coords,
+                                         double* __restrict__ accrow, int k, int j0, int ww, bool serial)
+{
+    constexpr int BB = PD * PD;
+    double K[NPE][PD][PD];
+    int sl[NPE];
+    if (mine) {
+        const size_t e = (size_t)((code & 0x3fffffffu) >> 3);
+        const int a = (int)(code & 7u);
+        row_blocks<PD, NPE, NIP, TYPE>(gv, coords, e, a, K);
+        const uint16_t* sp = gv.slot + (e * NPE + a) * NPE;
+#pragma unroll
+        for (int b = 0; b < NPE; b++) sl[b] = (int)sp[b] - j0;
+    }
+    auto add_all = [&] {
+#pragma unroll
+        for (int b = 0; b < NPE; b++)
+            if ((unsigned)sl[b] < (unsigned)ww) {
+                double* q = accrow + sl[b] * BB;
+#pragma unroll
+                for (int i = 0; i < PD; i++)
+#pragma unroll
+                    for (int j = 0; j < PD; j++) q[i * PD + j] += K[b][i][j];
+            }
+    };
+    if (!serial) {
+        if (mine) add_all();
+    } else {
+        for (int kk = 0; kk < LPR; kk++)
+            if (mine && k == kk) add_all();   // one wave: its LDS operations complete in order
+    }
+}
+
+// ROWS block rows per workgroup (a 64-row slice is shared by 64/ROWS workgroups), LPR lanes per row.
+template <int PD, int LPR, int ROWS>
+__global__ void __launch_bounds__(ROWS* LPR, 2)   // two waves per SIMD: at most 256 registers per lane
+    k_assemble_rows(int nn, const int* __restrict__ boff, const int* __restrict__ n2e_ptr, const unsigned* __restrict__ n2e,
+                    AsmGroups gs, const double* __restrict__ coords, const unsigned char* __restrict__ slice_serial, int wcap,
+                    int rs_pad, int add, double* __restrict__ val)
+{
+    constexpr int BB = PD * PD, TPB = ROWS * LPR, PARTS = 64 / ROWS;
+    extern __shared__ double acc[];   // [ROWS][RS]: the image of this workgroup's rows of the slice
+    __shared__ int s_maxcnt;
+    const int t = threadIdx.x, rl = t / LPR, k = t % LPR;
+    const int sl = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
+    const int row = sl * 64 + part * ROWS + rl;
+    const int o0 = boff[sl], W = boff[sl + 1] - o0;
+    const bool valid = row < nn;
+    const int p0 = valid ? n2e_ptr[row] : 0;
+    const int cnt = valid ? n2e_ptr[row + 1] - p0 : 0;
+    if (t == 0) s_maxcnt = 0;
+    __syncthreads();
+    if (k == 0 && cnt > 0) atomicMax(&s_maxcnt, cnt);
+    __syncthreads();
+    const int npass = (s_maxcnt + LPR - 1) / LPR;
+    const bool serial = slice_serial[sl] != 0;
+    for (int j0 = 0; j0 < W; j0 += wcap) {   // one window unless a slice is wider than the LDS image allows
+        const int ww = min(wcap, W - j0), len = ww * BB;
+        // row stride: odd, and = 1 (mod 32) when the padding fits (rs_pad)
+        const int RS = rs_pad ? ((len + 30) / 32) * 32 + 1 : (len | 1);
+        for (int i = t; i < ROWS * RS; i += TPB) acc[i] = 0.0;
+        __syncthreads();
+        for (int pass = 0; pass < npass; pass++) {
+            const int idx = pass * LPR + k;
+            const bool act = idx < cnt;
+            const unsigned code = act ? n2e[p0 + idx] : 0u;
+            const int gi = (int)(code >> 30);
+            for (int g = 0; g < gs.ng; g++) {
+                const bool mine = act && gi == g;
+                if (!__any(mine)) continue;
+                const AsmGroup& gv = gs.g[g];
+                double* accrow = acc + rl * RS;
+                if constexpr (PD == 3) {
+                    if (gv.type == FEM_HEX) rows_add<3, 8, 8, FEM_HEX, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
+                    else rows_add<3, 4, 1, FEM_TET, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
+                } else {
+                    if (gv.type == FEM_QUA) rows_add<2, 4, 4, FEM_QUA, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
+                    else rows_add<2, 3, 1, FEM_TRI, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
+                }
+            }
+        }
+        __syncthreads();
+        // write-out: entry (j, c) of the ROWS rows is ROWS consecutive words of val
+        double* dst = val + (size_t)(o0 + j0) * BB * 64 + part * ROWS;
+        for (int i = t; i < len * ROWS; i += TPB) {
+            const int jc = i / ROWS, r = i % ROWS;
+            double* q = dst + (size_t)jc * 64 + r;
+            const double v = acc[r * RS + jc];
+            *q = add ? *q + v : v;   // MatSetValues(ADD_VALUES) on a matrix that already holds values
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace fem
+
 void mat_assemble_elements_impl(fem_mat A)
 {
     fem_mesh m = A->mesh;
     fem_ctx ctx = A->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
-    for (auto& g : m->groups) {
+    const MatPattern& P = *A->pat;
+    AsmGroups gs{};
+    gs.ng = (int)m->groups.size();
+    for (int i = 0; i < gs.ng; i++) {
+        auto& g = m->groups[i];
         FEM_CHECK(g.slot.p, 5, "fem_mat_assemble_elements: matrix pattern was not built for this mesh");
-        dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto ELB) {
-            launch_ke<PD(), NPE(), NIP(), ELB()>(g.type, g.nel, MeshSrc<PD(), NPE()>{g.conn.p, m->coords.p}, g.E.p,
-                                                 g.nu.p, MatSink<PD(), NPE()>{g.conn.p, g.slot.p, A->boff.p, A->val.p},
-                                                 s);
-        });
+        gs.g[i] = AsmGroup{g.conn.p, g.E.p, g.nu.p, g.slot.p, g.type, g.npe};
     }
+    const int add = A->lazy_zero ? 0 : 1;
+    constexpr int LDS_BUDGET = 76 * 1024;   // two workgroups per CU (160 KiB)
+    // FEM_AMD_ASM_WCAP (tests): a smaller accumulator window, so that small decks exercise the multi-window path
+    // a slice wider than the LDS image takes
+    static const int wcap_env = std::getenv("FEM_AMD_ASM_WCAP") ? std::atoi(std::getenv("FEM_AMD_ASM_WCAP")) : 0;
+    auto launch = [&](auto kernel, int bb, int rows, int tpb) {
+        const int per_row = LDS_BUDGET / (rows * 8);                 // doubles per row of the image
+        int wcap = std::max(1, std::min(P.maxw, (per_row - 1) / bb));
+        if (wcap_env > 0) wcap = std::min(wcap, wcap_env);
+        const int len = wcap * bb;
+        const int rs_pad = (((len + 30) / 32) * 32 + 1 <= per_row) ? 1 : 0;
+        const int RS = rs_pad ? ((len + 30) / 32) * 32 + 1 : (len | 1);
+        const size_t shmem = (size_t)rows * RS * sizeof(double);
+        FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(kernel, dim3((unsigned)A->nslices * (64 / rows)), dim3(tpb), shmem, s, m->nnds, A->boff.p,
+                           A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p);
+    };
+    if (m->pdim == 3) launch(k_assemble_rows<3, 8, 32>, 9, 32, 256);
+    else launch(k_assemble_rows<2, 4, 64>, 4, 64, 256);
+    A->lazy_zero = false;
     FEM_HIP(hipGetLastError());
 }
 
@@ -690,19 +865,6 @@ struct EbeViews {
     const double* f[4];
     int nel[4];
 };
-// ascending codes inside every node's list (the symbolic phase fills them with an atomic cursor)
-__global__ void __launch_bounds__(256) k_sort_n2e(int nn, const int* __restrict__ ptr, unsigned* __restrict__ lst)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= nn) return;
-    const int p0 = ptr[v], p1 = ptr[v + 1];
-    for (int i = p0 + 1; i < p1; i++) {
-        const unsigned c = lst[i];
-        int j = i - 1;
-        while (j >= p0 && lst[j] > c) { lst[j + 1] = lst[j]; j--; }
-        lst[j + 1] = c;
-    }
-}
 // thread = node: ordered sum of the buffer entries of the incident elements, then the node's penalty rows
 // (y_i += shift_i x_i, their share of x.Kx into one partial per workgroup)
 template <int PD>
@@ -761,30 +923,25 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
     ctx->bind();
     hipStream_t s = ctx->stream;
     const bool ebe = (t == "ebe");
-    if (ebe && A->ebe_f.empty()) {
-        fem_mesh m = A->mesh;
+    fem_mesh m = A->mesh;
+    MatPattern& P = *A->pat;
+    if (ebe && !P.ebe_ready) {   // connectivity-only part: hand-over flags and gather lists, once per mesh
         FEM_CHECK(A->n2e_ptr.p && A->n2e.p, 5, "fem_mat_set_mult_type: matrix was not created from a mesh");
-        if (!A->n2e_sorted) {
-            hipLaunchKernelGGL(k_sort_n2e, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->n2e_ptr.p, A->n2e.p);
-            A->n2e_sorted = true;
-        }
-        A->ebe_f.resize(m->groups.size());
-        A->ebe_donate.resize(m->groups.size());
+        P.ebe_donate.resize(m->groups.size());
         DonateViews dv{};
         dv.pdim = m->pdim;
         for (size_t g = 0; g < m->groups.size(); g++) {
             auto& grp = m->groups[g];
-            A->ebe_f[g].alloc((size_t)grp.nel * grp.npe * m->pdim);
             dv.npe[g] = grp.npe; dv.d[g] = nullptr;
             if (grp.type == FEM_HEX || grp.type == FEM_QUA) {
-                A->ebe_donate[g].alloc((size_t)grp.nel);
+                P.ebe_donate[g].alloc((size_t)grp.nel);
                 if (grp.type == FEM_HEX)
                     hipLaunchKernelGGL(k_ebe_mark_donors<8>, dim3(cdiv((size_t)grp.nel, 256)), dim3(256), 0, s, grp.nel,
-                                       grp.conn.p, A->ebe_donate[g].p);
+                                       grp.conn.p, P.ebe_donate[g].p);
                 else
                     hipLaunchKernelGGL(k_ebe_mark_donors<4>, dim3(cdiv((size_t)grp.nel, 256)), dim3(256), 0, s, grp.nel,
-                                       grp.conn.p, A->ebe_donate[g].p);
-                dv.d[g] = A->ebe_donate[g].p;
+                                       grp.conn.p, P.ebe_donate[g].p);
+                dv.d[g] = P.ebe_donate[g].p;
             }
         }
         {
@@ -792,20 +949,27 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
             DBuf<int> cnt((size_t)nn), tmp(exclusive_scan_tmp_ints((size_t)nn + 1));
             hipLaunchKernelGGL(k_ebe_count_kept, dim3(cdiv((size_t)nn, 256)), dim3(256), 0, s, nn, A->n2e_ptr.p, A->n2e.p, dv,
                                cnt.p);
-            A->ebe_ptr.alloc((size_t)nn + 1);
-            exclusive_scan_i32(cnt.p, A->ebe_ptr.p, nn, tmp.p, s);
+            P.ebe_ptr.alloc((size_t)nn + 1);
+            exclusive_scan_i32(cnt.p, P.ebe_ptr.p, nn, tmp.p, s);
             int tot = 0;
-            FEM_HIP(hipMemcpyAsync(&tot, A->ebe_ptr.p + nn, sizeof(int), hipMemcpyDeviceToHost, s));
+            FEM_HIP(hipMemcpyAsync(&tot, P.ebe_ptr.p + nn, sizeof(int), hipMemcpyDeviceToHost, s));
             FEM_HIP(hipStreamSynchronize(s));
-            A->ebe_lst.alloc((size_t)std::max(tot, 1));
+            P.ebe_lst.alloc((size_t)std::max(tot, 1));
             hipLaunchKernelGGL(k_ebe_fill_kept, dim3(cdiv((size_t)nn, 256)), dim3(256), 0, s, nn, A->n2e_ptr.p, A->n2e.p, dv,
-                               A->ebe_ptr.p, A->ebe_lst.p);
+                               P.ebe_ptr.p, P.ebe_lst.p);
             FEM_HIP(hipStreamSynchronize(s));   // cnt, tmp go out of scope
         }
-        A->ebe_grid = ebe_blocks(m);
-        A->ebe_partial.alloc((size_t)A->ebe_grid);
+        P.ebe_grid = ebe_blocks(m);
         FEM_HIP(hipGetLastError());
         FEM_HIP(hipStreamSynchronize(s));
+        P.ebe_ready = true;
+    }
+    if (ebe && A->ebe_f.empty()) {   // this Mat's element-force buffers
+        A->ebe_f.resize(m->groups.size());
+        for (size_t g = 0; g < m->groups.size(); g++)
+            A->ebe_f[g].alloc((size_t)m->groups[g].nel * m->groups[g].npe * m->pdim);
+        A->ebe_grid = P.ebe_grid;
+        A->ebe_partial.alloc((size_t)A->ebe_grid);
     }
     A->mult_ebe = ebe;
     // the Krylov solver sums A->spmv_partial[0 .. spmv_grid): size it for the product in use
@@ -833,18 +997,18 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
         const unsigned nb = cdiv((size_t)g.nel, 256);
         dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto) {
             hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP()>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
-                               m->coords.p, g.E.p, g.nu.p, x, A->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
+                               m->coords.p, g.E.p, g.nu.p, x, A->pat->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
         });
         off += (int)nb;
     }
     mark();
     const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
     if (m->pdim == 3)
-        hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->ebe_ptr.p,
-                           A->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
+        hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->pat->ebe_ptr.p,
+                           A->pat->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
     else
-        hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->ebe_ptr.p,
-                           A->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
+        hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->pat->ebe_ptr.p,
+                           A->pat->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
     mark();
     mark();   // (the penalty rows used to be a stage of their own: the profile keeps its four marks per product)
 }
@@ -911,12 +1075,16 @@ void calc_el_stress_impl(fem_ctx ctx, int type, int nel, const double* ecoords, 
         constexpr int TPB = ELB() * (NIP() > NPE() ? NIP() : NPE());
         hipLaunchKernelGGL((k_stress<PD(), NPE(), NIP(), ELB(), false, DenseSrc<PD(), NPE()>, DenseU<PD(), NPE()>>),
                            dim3(cdiv(nel, ELB())), dim3(TPB), 0, s, type, nel, DenseSrc<PD(), NPE()>{dX.p},
-                           DenseU<PD(), NPE()>{dU.p}, dE.p, dnu.p, (const int*)nullptr, dS.p, (size_t)0);
+                           DenseU<PD(), NPE()>{dU.p}, dE.p, dnu.p, dS.p);
     });
     FEM_HIP(hipGetLastError());
     dS.download(estress, dS.n, s);
     FEM_HIP(hipStreamSynchronize(s));
 }
+
+// node -> incident elements of the mesh's pattern (built by the first fem_mat_create_aij; a mesh that never had
+// a Mat gets it here)
+std::shared_ptr<fem::MatPattern> mesh_pattern(fem_mesh m);
 
 // main.F90:253-292 on the device: S(nnds,cpdim) column-major
 void recover_nodal_stress_dev(fem_mesh m, const double* U, double* S)
@@ -925,21 +1093,36 @@ void recover_nodal_stress_dev(fem_mesh m, const double* U, double* S)
     ctx->bind();
     hipStream_t s = ctx->stream;
     const size_t nn = (size_t)m->nnds;
-    FEM_HIP(hipMemsetAsync(S, 0, sizeof(double) * nn * m->cpdim, s));
-    for (auto& g : m->groups) {
+    const auto P = mesh_pattern(m);
+    std::vector<DBuf<double>> buf(m->groups.size());
+    StressViews sv{};
+    for (size_t gi = 0; gi < m->groups.size(); gi++) {
+        auto& g = m->groups[gi];
+        buf[gi].alloc((size_t)g.nel * g.npe * m->cpdim);
+        sv.f[gi] = buf[gi].p; sv.nel[gi] = g.nel;
         dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto ELB) {
             constexpr int TPB = ELB() * (NIP() > NPE() ? NIP() : NPE());
             hipLaunchKernelGGL((k_stress<PD(), NPE(), NIP(), ELB(), true, MeshSrc<PD(), NPE()>, MeshU<PD(), NPE()>>),
                                dim3(cdiv(g.nel, ELB())), dim3(TPB), 0, s, g.type, g.nel,
                                MeshSrc<PD(), NPE()>{g.conn.p, m->coords.p}, MeshU<PD(), NPE()>{g.conn.p, U}, g.E.p,
-                               g.nu.p, g.conn.p, S, nn);
+                               g.nu.p, buf[gi].p);
         });
     }
-    // cross-domain sum of the partial nodal sums (replaces Mat_Stress ADD + assembly, src/main.F90:286-289)
-    halo_sum(m, S, m->cpdim, 1, nn);
-    hipLaunchKernelGGL(k_divide_by_valence, dim3(std::min<unsigned>(cdiv(nn * m->cpdim, 256), 8192)), dim3(256), 0, s, nn,
-                       m->cpdim, S, m->valence_d.p);
+    // single domain: the division by the valence rides on the gather; partitioned meshes sum the partial nodal
+    // sums across domains first (replaces Mat_Stress ADD + assembly, src/main.F90:286-289)
+    const bool multi = m->halo && m->halo->comm->size > 1;
+    const double* val = multi ? nullptr : m->valence_d.p;
+    if (m->cpdim == 6)
+        hipLaunchKernelGGL(k_stress_gather<6>, dim3(cdiv(nn, 256)), dim3(256), 0, s, m->nnds, P->n2e_ptr.p, P->n2e.p, sv, val, S);
+    else
+        hipLaunchKernelGGL(k_stress_gather<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, m->nnds, P->n2e_ptr.p, P->n2e.p, sv, val, S);
+    if (multi) {
+        halo_sum(m, S, m->cpdim, 1, nn);
+        hipLaunchKernelGGL(k_divide_by_valence, dim3(std::min<unsigned>(cdiv(nn * m->cpdim, 256), 8192)), dim3(256), 0, s, nn,
+                           m->cpdim, S, m->valence_d.p);
+    }
     FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));   // the element buffers go back to the pool at scope end
 }
 
 void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval, int nfrcs, const int* fnode,

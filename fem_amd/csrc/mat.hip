@@ -45,6 +45,42 @@ __global__ void __launch_bounds__(256) k_fill_n2e(GroupView gv, int gidx, const 
     }
 }
 
+// One thread per node: (1) ascending codes inside the node's incidence list (k_fill_n2e fills it with
+// an atomic cursor); (2) the largest valence; (3) the row-owner assembly gives every incidence of a row
+// its own lane, `lpr` lanes per row and pass, and lets the lanes of a pass add local column b in the same
+// instruction: where two incidences of one pass hold the same node at the same local index b (never on
+// structured numberings), the slice is flagged and its lanes take turns instead.
+__global__ void __launch_bounds__(256) k_sort_and_flag(int nn, const int* __restrict__ ptr, unsigned* __restrict__ lst,
+                                                       GroupViews gvs, int lpr, unsigned char* __restrict__ slice_serial,
+                                                       int* __restrict__ max_valence)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    const int p0 = ptr[v], p1 = ptr[v + 1];
+    for (int i = p0 + 1; i < p1; i++) {
+        const unsigned c = lst[i];
+        int j = i - 1;
+        while (j >= p0 && lst[j] > c) { lst[j + 1] = lst[j]; j--; }
+        lst[j + 1] = c;
+    }
+    atomicMax(max_valence, p1 - p0);
+    bool clash = false;
+    for (int q0 = p0; q0 < p1 && !clash; q0 += lpr) {
+        const int q1 = min(q0 + lpr, p1);
+        for (int i = q0; i < q1 && !clash; i++) {
+            const GroupView gi = gvs.g[lst[i] >> 30];
+            const int* ci = gi.conn + (size_t)((lst[i] & 0x3fffffffu) >> 3) * gi.npe;
+            for (int j = i + 1; j < q1 && !clash; j++) {
+                const GroupView gj = gvs.g[lst[j] >> 30];
+                const int* cj = gj.conn + (size_t)((lst[j] & 0x3fffffffu) >> 3) * gj.npe;
+                const int nb = min(gi.npe, gj.npe);
+                for (int b = 0; b < nb; b++) clash = clash || (ci[b] == cj[b]);
+            }
+        }
+    }
+    if (clash) slice_serial[v >> 6] = 1;
+}
+
 // One thread per node: sorted unique list of the nodes of all incident elements.
 // FILL = false: write the list length.  FILL = true: write the slice-ELL column ids.
 template <bool FILL>
@@ -282,23 +318,23 @@ static GroupViews make_views(fem_mesh m)
     return gv;
 }
 
-fem_mat mat_create_impl(fem_mesh mesh)
+// The symbolic phase: everything that follows from the connectivity alone.
+static std::shared_ptr<MatPattern> build_pattern(fem_mesh mesh)
 {
-    FEM_CHECK(mesh, 1, "fem_mat_create_aij: null mesh");
     fem_ctx ctx = mesh->ctx;
-    ctx->bind();
     hipStream_t s = ctx->stream;
-    std::unique_ptr<fem_mat_s> A(new fem_mat_s);
-    A->mesh = mesh; A->ctx = ctx; A->bs = mesh->pdim; A->nbrows = mesh->nnds;
+    FEM_HIP(hipEventRecord(ctx->t0, s));
+    auto P = std::make_shared<MatPattern>();
+    P->bs = mesh->pdim; P->nbrows = mesh->nnds;
     const int nn = mesh->nnds;
-    A->nslices = (nn + 63) / 64;
-    const int nrp = A->nslices * 64;
+    P->nslices = (nn + 63) / 64;
+    const int nrp = P->nslices * 64;
     const GroupViews gvs = make_views(mesh);
 
-    // node -> incident elements (CSR on device)
+    // node -> incident elements (CSR on device), ascending codes inside every list
     DBuf<int> cursor(nn), tmp(exclusive_scan_tmp_ints((size_t)nrp + 1));
-    DBuf<int>& n2e_ptr = A->n2e_ptr;
-    DBuf<unsigned>& n2e = A->n2e;
+    DBuf<int>& n2e_ptr = P->n2e_ptr;
+    DBuf<unsigned>& n2e = P->n2e;
     n2e_ptr.alloc((size_t)nn + 1);
     exclusive_scan_i32(mesh->valence.p, n2e_ptr.p, nn, tmp.p, s);
     int tot = 0;
@@ -313,47 +349,76 @@ fem_mat mat_create_impl(fem_mesh mesh)
         hipLaunchKernelGGL(k_fill_n2e, dim3(std::min<unsigned>(cdiv(nent, 256), 8192)), dim3(256), 0, s, gvs.g[g], g,
                            n2e_ptr.p, cursor.p, n2e.p);
     }
-    // row lengths, slice widths, slice offsets
-    A->rowlen.alloc(nn);
-    DBuf<int> err(1), width(A->nslices);
+    // row lengths (and the sort of the incidence lists, the serialisation flags of the row-owner
+    // assembly, the largest valence), slice widths, slice offsets
+    P->rowlen.alloc(nn);
+    P->slice_serial.alloc((size_t)P->nslices);
+    P->slice_serial.zero(s);
+    DBuf<int> err(2), width(P->nslices);
     err.zero(s);
+    hipLaunchKernelGGL(k_sort_and_flag, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, n2e_ptr.p, n2e.p, gvs,
+                       mesh->pdim == 3 ? 8 : 4, P->slice_serial.p, err.p + 1);
     hipLaunchKernelGGL(k_node_neighbours<false>, dim3(cdiv(nrp, 256)), dim3(256), 0, s, nn, nrp, n2e_ptr.p, n2e.p, gvs,
-                       A->rowlen.p, (const int*)nullptr, (int*)nullptr, err.p);
-    hipLaunchKernelGGL(k_slice_width, dim3(cdiv(A->nslices, 256)), dim3(256), 0, s, nn, A->nslices, A->rowlen.p,
+                       P->rowlen.p, (const int*)nullptr, (int*)nullptr, err.p);
+    hipLaunchKernelGGL(k_slice_width, dim3(cdiv(P->nslices, 256)), dim3(256), 0, s, nn, P->nslices, P->rowlen.p,
                        width.p);
-    A->boff.alloc((size_t)A->nslices + 1);
-    exclusive_scan_i32(width.p, A->boff.p, A->nslices, tmp.p, s);
-    A->h_boff.resize((size_t)A->nslices + 1);
-    A->h_rowlen.resize(nn);
-    int herr = 0;
-    A->boff.download(A->h_boff.data(), A->h_boff.size(), s);
-    A->rowlen.download(A->h_rowlen.data(), nn, s);
-    err.download(&herr, 1, s);
+    P->boff.alloc((size_t)P->nslices + 1);
+    exclusive_scan_i32(width.p, P->boff.p, P->nslices, tmp.p, s);
+    P->h_boff.resize((size_t)P->nslices + 1);
+    P->h_rowlen.resize(nn);
+    int herr[2] = {0, 0};
+    P->boff.download(P->h_boff.data(), P->h_boff.size(), s);
+    P->rowlen.download(P->h_rowlen.data(), nn, s);
+    err.download(herr, 2, s);
     FEM_HIP(hipStreamSynchronize(s));
-    FEM_CHECK(!herr, 4, "fem_mat_create_aij: a node has more than " + std::to_string(MAXNB) + " neighbour nodes");
-    const long long tb = A->h_boff[A->nslices];
-    FEM_CHECK(tb * 64 * A->bs * A->bs < (1LL << 40), 4, "fem_mat_create_aij: matrix too large");
-    A->padded_blocks = tb * 64;
-    A->nblocks = 0;
+    FEM_CHECK(!herr[0], 4, "fem_mat_create_aij: a node has more than " + std::to_string(MAXNB) + " neighbour nodes");
+    P->max_valence = herr[1];
+    const long long tb = P->h_boff[P->nslices];
+    FEM_CHECK(tb * 64 * P->bs * P->bs < (1LL << 40), 4, "fem_mat_create_aij: matrix too large");
+    P->padded_blocks = tb * 64;
+    P->nblocks = 0;
     int maxw = 0;
-    for (int v = 0; v < nn; v++) { A->nblocks += A->h_rowlen[v]; maxw = std::max(maxw, A->h_rowlen[v]); }
+    for (int v = 0; v < nn; v++) { P->nblocks += P->h_rowlen[v]; maxw = std::max(maxw, P->h_rowlen[v]); }
     FEM_CHECK(maxw < 65536, 4, "fem_mat_create_aij: row too long for 16-bit slots");
-    A->bcol.alloc((size_t)A->padded_blocks);
-    A->val.alloc((size_t)A->padded_blocks * A->bs * A->bs);
+    P->maxw = maxw;
+    P->bcol.alloc((size_t)P->padded_blocks);
     hipLaunchKernelGGL(k_node_neighbours<true>, dim3(cdiv(nrp, 256)), dim3(256), 0, s, nn, nrp, n2e_ptr.p, n2e.p, gvs,
-                       A->rowlen.p, A->boff.p, A->bcol.p, err.p);
-    A->val.zero(s);
+                       P->rowlen.p, P->boff.p, P->bcol.p, err.p);
     // per-element slot maps (consumed by the assembly kernels)
     for (auto& g : mesh->groups) {
         const size_t tot_s = (size_t)g.nel * g.npe * g.npe;
         g.slot.alloc(tot_s);
         hipLaunchKernelGGL(k_slots, dim3(std::min<unsigned>(cdiv(tot_s, 256), 16384)), dim3(256), 0, s,
-                           GroupView{g.conn.p, g.npe, g.nel}, A->rowlen.p, A->boff.p, A->bcol.p, g.slot.p);
+                           GroupView{g.conn.p, g.npe, g.nel}, P->rowlen.p, P->boff.p, P->bcol.p, g.slot.p);
     }
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipEventRecord(ctx->t1, s));
+    FEM_HIP(hipStreamSynchronize(s));
+    float ms = 0.f;
+    FEM_HIP(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    P->t_symbolic_ms = ms;
+    return P;
+}
+
+std::shared_ptr<MatPattern> mesh_pattern(fem_mesh mesh)
+{
+    mesh->ctx->bind();
+    if (!mesh->pattern) mesh->pattern = build_pattern(mesh);
+    return mesh->pattern;
+}
+
+fem_mat mat_create_impl(fem_mesh mesh)
+{
+    FEM_CHECK(mesh, 1, "fem_mat_create_aij: null mesh");
+    fem_ctx ctx = mesh->ctx;
+    ctx->bind();
+    if (!mesh->pattern) mesh->pattern = build_pattern(mesh);
+    std::unique_ptr<fem_mat_s> A(new fem_mat_s(mesh->pattern));
+    A->mesh = mesh; A->ctx = ctx;
+    A->val.alloc((size_t)A->padded_blocks * A->bs * A->bs);
+    A->lazy_zero = true;   // a new Mat is zero (MatCreateAIJ); see fem_mat_s::values()
     A->spmv_grid = (A->nslices + 3) / 4;
     A->spmv_partial.alloc((size_t)A->spmv_grid);
-    FEM_HIP(hipGetLastError());
-    FEM_HIP(hipStreamSynchronize(s));
     return A.release();
 }
 
@@ -365,10 +430,10 @@ void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const 
     hipStream_t s = A->ctx->stream;
     if (A->bs == 3)
         hipLaunchKernelGGL(k_spmv_sell<3>, dim3(A->spmv_grid), dim3(256), 0, s, A->nslices, A->nbrows, A->boff.p,
-                           A->bcol.p, A->val.p, x, y, partial, done);
+                           A->bcol.p, A->values(), x, y, partial, done);
     else
         hipLaunchKernelGGL(k_spmv_sell<2>, dim3(A->spmv_grid), dim3(256), 0, s, A->nslices, A->nbrows, A->boff.p,
-                           A->bcol.p, A->val.p, x, y, partial, done);
+                           A->bcol.p, A->values(), x, y, partial, done);
 }
 
 void mat_get_diagonal_raw(fem_mat A, double* d)
@@ -376,10 +441,10 @@ void mat_get_diagonal_raw(fem_mat A, double* d)
     hipStream_t s = A->ctx->stream;
     if (A->bs == 3)
         hipLaunchKernelGGL(k_get_diag<3>, dim3(cdiv(A->nbrows, 256)), dim3(256), 0, s, A->nbrows, A->rowlen.p,
-                           A->boff.p, A->bcol.p, A->val.p, d);
+                           A->boff.p, A->bcol.p, A->values(), d);
     else
         hipLaunchKernelGGL(k_get_diag<2>, dim3(cdiv(A->nbrows, 256)), dim3(256), 0, s, A->nbrows, A->rowlen.p,
-                           A->boff.p, A->bcol.p, A->val.p, d);
+                           A->boff.p, A->bcol.p, A->values(), d);
 }
 
 void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
@@ -420,10 +485,10 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
         d_old.upload(A->h_bc.data(), A->h_bc.size(), s);
         if (pd == 3)
             hipLaunchKernelGGL(k_restore_kbc<3>, dim3(cdiv(nold, 256)), dim3(256), 0, s, nold, d_old.p, A->rowlen.p,
-                               A->boff.p, A->bcol.p, A->val.p, A->bc_diag.p);
+                               A->boff.p, A->bcol.p, A->values(), A->bc_diag.p);
         else
             hipLaunchKernelGGL(k_restore_kbc<2>, dim3(cdiv(nold, 256)), dim3(256), 0, s, nold, d_old.p, A->rowlen.p,
-                               A->boff.p, A->bcol.p, A->val.p, A->bc_diag.p);
+                               A->boff.p, A->bcol.p, A->values(), A->bc_diag.p);
         FEM_HIP(hipStreamSynchronize(s));
         A->bc_saved = false;
     }
@@ -442,10 +507,10 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
     }
     if (pd == 3)
         hipLaunchKernelGGL(k_apply_kbc<3>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
+                           A->bcol.p, A->values(), owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
     else
         hipLaunchKernelGGL(k_apply_kbc<2>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
-                           A->bcol.p, A->val.p, owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
+                           A->bcol.p, A->values(), owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
     A->bc_saved = true;
     A->h_bc = std::move(merged);
     FEM_HIP(hipGetLastError());
@@ -471,7 +536,7 @@ void mat_get_csr_impl(fem_mat A, int* rowptr, int* colind, double* val)
     std::vector<int> hc((size_t)A->padded_blocks);
     std::vector<double> hv;
     A->bcol.download(hc.data(), hc.size(), s);
-    if (val) { hv.resize((size_t)A->padded_blocks * bs * bs); A->val.download(hv.data(), hv.size(), s); }
+    if (val) { hv.resize((size_t)A->padded_blocks * bs * bs); (void)A->values(); A->val.download(hv.data(), hv.size(), s); }
     FEM_HIP(hipStreamSynchronize(s));
     size_t k = 0;
     for (int v = 0; v < nn; v++) {

@@ -907,7 +907,7 @@ static bool setup_t(Multigrid& mg)
     new_level(g, H);
     if (PD == 2) mg.lev[0].lo[2] = -0.5 * H;
     hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, geom_of(mg.lev[0]),
-                       mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->val.p,
+                       mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->values(),
                        mg.w.p, mg.lev[0].st.p, err.p);
     if (comm) {
         // A_1 = sum over the domains of P_r^T K_r P_r (sub-assembled matrices, same P on shared nodes);

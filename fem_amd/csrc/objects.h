@@ -17,6 +17,7 @@ struct TypeGroup {
 };
 
 struct Comm;  // comm.h
+struct MatPattern;
 
 // Interface lists of one domain (multi-domain runs).
 struct Halo {
@@ -48,6 +49,7 @@ struct fem_mesh_s {
     std::vector<int> h_eltype, h_eptr, h_conn;
     std::vector<int> elem_group, elem_pos;  // element -> (group index, position in group)
     std::unique_ptr<fem::Halo> halo;
+    std::shared_ptr<fem::MatPattern> pattern;   // symbolic phase result, built by the first fem_mat_create_aij
 };
 
 struct fem_vec_s {
@@ -56,37 +58,70 @@ struct fem_vec_s {
     fem::DBuf<double> d;
 };
 
-// Mat_K in sliced block-ELL: block rows = nodes, bs = pdim, slices of 64 rows.
-//   bcol[(boff[s]+j)*64 + lane]                      block column (node) ids
-//   val [((boff[s]+j)*bs*bs + r*bs + c)*64 + lane]   fp64 entries
-struct fem_mat_s {
-    fem_mesh mesh = nullptr;
-    fem_ctx ctx = nullptr;
+namespace fem {
+
+// Everything about Mat_K that depends on the connectivity alone (the product of MatCreateAIJ's
+// preallocation, src/main.F90:153-156, and of the implicit pattern growth of MatSetValues): built once
+// per mesh by the symbolic phase and shared by every Mat created from that mesh -- the reference, too,
+// creates Mat_K once (src/main.F90:154) and re-runs only the element loop.
+//   bcol[(boff[s]+j)*64 + lane]   block column (node) ids of the sliced block-ELL layout
+struct MatPattern {
     int bs = 0, nbrows = 0, nslices = 0;
     long long nblocks = 0;        // true (unpadded) number of bs x bs blocks
     long long padded_blocks = 0;  // boff[nslices]*64
-    fem::DBuf<int> boff;          // [nslices+1]
-    fem::DBuf<int> bcol;
-    fem::DBuf<double> val;
-    fem::DBuf<int> rowlen;        // [nbrows] blocks per block row
+    int maxw = 0;                 // widest slice (blocks per row)
+    DBuf<int> boff;               // [nslices+1]
+    DBuf<int> bcol;
+    DBuf<int> rowlen;             // [nbrows] blocks per block row
     std::vector<int> h_boff, h_rowlen;
+    // node -> incident (group, element, local node), code = group<<30 | element<<3 | local node,
+    // ascending inside every node's list
+    DBuf<int> n2e_ptr;
+    DBuf<unsigned> n2e;
+    // row-owner assembly (elem_kernels.hip): slices in which two lanes of one row would add the same
+    // local column in the same pass (same node at the same local index of two incident elements)
+    DBuf<unsigned char> slice_serial;   // [nslices]
+    int max_valence = 0;
+    // MatMult by element-by-element recomputation: hand-over flags and gather lists
+    bool ebe_ready = false;
+    std::vector<DBuf<unsigned char>> ebe_donate;   // per group [nel]
+    DBuf<int> ebe_ptr;
+    DBuf<unsigned> ebe_lst;
+    int ebe_grid = 0;             // workgroups of all element groups + those of the node gather
+    double t_symbolic_ms = 0.0;   // wall time of the symbolic phase that built this pattern
+};
+
+}  // namespace fem
+
+// Mat_K in sliced block-ELL: block rows = nodes, bs = pdim, slices of 64 rows.
+//   val [((boff[s]+j)*bs*bs + r*bs + c)*64 + lane]   fp64 entries
+struct fem_mat_s {
+    std::shared_ptr<fem::MatPattern> pat;
+    fem_mesh mesh = nullptr;
+    fem_ctx ctx = nullptr;
+    int bs = 0, nbrows = 0, nslices = 0;
+    long long nblocks = 0, padded_blocks = 0;
+    // views into the shared pattern
+    fem::DBuf<int>&boff, &bcol, &rowlen;
+    std::vector<int>&h_boff, &h_rowlen;
+    fem::DBuf<int>& n2e_ptr;
+    fem::DBuf<unsigned>& n2e;
+    fem::DBuf<double> val;
+    // MatZeroEntries is lazy: the row-owner assembly overwrites every entry (padding included), so a
+    // zeroed matrix that is assembled next never pays for the memset; every other reader goes through
+    // values(), which materialises the zeros first.
+    bool lazy_zero = false;
+    double* values() {
+        if (lazy_zero) { val.zero(ctx->stream); lazy_zero = false; }
+        return val.p;
+    }
     fem::DBuf<double> spmv_partial;  // per-workgroup partials of the fused p.Kp
     int spmv_grid = 0;
-    // node -> incident (group, element, local node), code = group<<30 | element<<3 | local node;
-    // built by the symbolic phase, sorted (and kept) for the element-by-element product
-    fem::DBuf<int> n2e_ptr;
-    fem::DBuf<unsigned> n2e;
-    bool n2e_sorted = false;
     // MatMult by element-by-element recomputation (`-mat_mult_type ebe`, elem_kernels.hip)
     bool mult_ebe = false;
     std::vector<fem::DBuf<double>> ebe_f;   // per element group: nodal forces [npe*pdim][nel]
-    // hex8 / quad4: an element whose +x face is the -x face of the next element of the same wavefront
-    // hands those forces over by a cross-lane move instead of storing them (halves the buffer traffic)
-    std::vector<fem::DBuf<unsigned char>> ebe_donate;   // per group [nel]
-    fem::DBuf<int> ebe_ptr;                 // gather lists without the handed-over entries
-    fem::DBuf<unsigned> ebe_lst;
     fem::DBuf<double> ebe_partial;          // internal p.Kp partials when the caller wants none
-    int ebe_grid = 0;                       // workgroups of all element groups + those of the penalty rows
+    int ebe_grid = 0;
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
     fem::DBuf<int> bc_dof;
     fem::DBuf<double> bc_shift;
@@ -100,6 +135,10 @@ struct fem_mat_s {
     size_t prod_count = 0;                  // products since profiling was switched on
     std::vector<hipEvent_t> pev;
     size_t pev_used = 0;
+    explicit fem_mat_s(std::shared_ptr<fem::MatPattern> p)
+        : pat(std::move(p)), bs(pat->bs), nbrows(pat->nbrows), nslices(pat->nslices), nblocks(pat->nblocks),
+          padded_blocks(pat->padded_blocks), boff(pat->boff), bcol(pat->bcol), rowlen(pat->rowlen), h_boff(pat->h_boff),
+          h_rowlen(pat->h_rowlen), n2e_ptr(pat->n2e_ptr), n2e(pat->n2e) {}
     ~fem_mat_s() {
         for (auto e : pev) (void)hipEventDestroy(e);
     }

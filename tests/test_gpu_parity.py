@@ -91,6 +91,59 @@ def test_assembled_matrix_matches_oracle(gpu_ctx, oracle, name):
 
 
 @pytest.mark.parametrize("name", list(_meshes()))
+def test_assembly_is_bitwise_reproducible_and_adds(gpu_ctx, oracle, name):
+    """The row-owner assembly has one writer per matrix entry and a fixed summation order: two assemblies of one
+    mesh are bitwise equal (also across two Mats), MatZeroEntries really zeroes (it is lazy inside), and a second
+    element loop without MatZeroEntries ADDs (MatSetValues(ADD_VALUES), src/main.F90:162)."""
+    m = _meshes()[name]
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K, K2 = capi.Mat(dm), capi.Mat(dm)
+    assert np.all(K.get_csr()[2] == 0.0)                          # a new Mat is zero
+    K.assemble_elements()
+    v1 = K.get_csr()[2]
+    K2.assemble_elements()
+    assert np.array_equal(K2.get_csr()[2], v1)
+    K.zero_entries(); K.assemble_elements()
+    assert np.array_equal(K.get_csr()[2], v1)
+    K.assemble_elements()                                          # no zeroing in between: the values add up
+    assert np.array_equal(K.get_csr()[2], v1 + v1)
+    K.zero_entries()
+    assert np.all(K.get_csr()[2] == 0.0)
+    rp, ci = oracle.csr_pattern(m)
+    vr = oracle.assemble(m, rp, ci, apply_bc=False)
+    assert np.abs(v1 - vr).max() <= 1e-13 * np.abs(vr).max()
+    for o in (K, K2, dm):
+        o.destroy()
+
+
+def test_assembly_through_a_narrow_accumulator_window(oracle):
+    """A slice wider than the LDS image is assembled window by window; forced here by FEM_AMD_ASM_WCAP in a child
+    process (the cap is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import numpy as np
+from fem_amd import capi
+from fem_amd.mesh import structured_hex, hex_to_tets
+from oracle.oracle import Oracle
+o = Oracle(); ctx = capi.Context(0)
+for m in (structured_hex(5, 4, 3, jitter=0.2), hex_to_tets(structured_hex(4, 3, 3, jitter=0.15))):
+    rp, ci = o.csr_pattern(m); vr = o.assemble(m, rp, ci, apply_bc=False)
+    dm = capi.DeviceMesh(ctx, m); K = capi.Mat(dm); K.assemble_elements()
+    g = K.get_csr()
+    assert np.array_equal(g[0], rp) and np.array_equal(g[1], ci)
+    assert np.abs(g[2] - vr).max() <= 1e-13 * np.abs(vr).max()
+    K.destroy(); dm.destroy()
+ctx.destroy(); print('WINDOWED-OK')
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FEM_AMD_ASM_WCAP="5", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert "WINDOWED-OK" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("name", list(_meshes()))
 def test_rhs_matches_oracle(gpu_ctx, oracle, name):
     m = _meshes()[name]
     dm = capi.DeviceMesh(gpu_ctx, m)

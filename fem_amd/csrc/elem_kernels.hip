@@ -422,7 +422,7 @@ struct AsmGroups {
 // the quadrature sum).  J^-1 is recomputed here for every (element, node) pair; dN/dx is never stored.
 template <int PD, int NPE, int NIP, int TYPE>
 __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __restrict__ coords, size_t e, int a,
-                                           double (&K)[NPE][PD][PD])
+                                           double (&K)[NPE][PD][PD], uint2& s01, uint2& s23)
 {
     const ElemTable& tab = c_tab[TYPE];
     double X[NPE][PD];
@@ -438,8 +438,21 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
         for (int i = 0; i < PD; i++)
 #pragma unroll
             for (int j = 0; j < PD; j++) K[b][i][j] = 0.0;
+    double Em = 0.0, num = 0.0;
 #pragma unroll 1
     for (int g = 0; g < NIP; g++) {
+        if (g == (NIP > 2 ? NIP - 2 : 0)) {   // what the epilogue needs, a little ahead of it: E, nu and the row's slots
+            const uint16_t* sp = gv.slot + (e * NPE + a) * NPE;
+            if constexpr (NPE == 8) {
+                const uint4 q = *reinterpret_cast<const uint4*>(sp);
+                s01 = make_uint2(q.x, q.y); s23 = make_uint2(q.z, q.w);
+            } else if constexpr (NPE == 4) {
+                s01 = *reinterpret_cast<const uint2*>(sp);
+            } else {
+                s01 = make_uint2((unsigned)sp[0] | ((unsigned)sp[1] << 16), (unsigned)sp[2]);
+            }
+            Em = gv.E[e]; num = gv.nu[e];
+        }
         double J[PD][PD];
 #pragma unroll
         for (int i = 0; i < PD; i++)
@@ -497,7 +510,7 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
                 for (int j = 0; j < PD; j++) K[b][i][j] += da[i] * db[j];
         }
     }
-    const DCoef D = dmat_coef(gv.E[e], gv.nu[e]);
+    const DCoef D = dmat_coef(Em, num);
 #pragma unroll
     for (int b = 0; b < NPE; b++) {
         double M[PD][PD], tr = 0.0;
@@ -527,25 +540,25 @@ __device__ __forceinline__ void rows_add(bool mine, unsigned code, const AsmGrou
 {
     constexpr int BB = PD * PD;
     double K[NPE][PD][PD];
-    int sl[NPE];
+    uint2 s01 = make_uint2(0, 0), s23 = make_uint2(0, 0);   // the row's NPE slots, 16 bits each
     if (mine) {
         const size_t e = (size_t)((code & 0x3fffffffu) >> 3);
         const int a = (int)(code & 7u);
-        row_blocks<PD, NPE, NIP, TYPE>(gv, coords, e, a, K);
-        const uint16_t* sp = gv.slot + (e * NPE + a) * NPE;
-#pragma unroll
-        for (int b = 0; b < NPE; b++) sl[b] = (int)sp[b] - j0;
+        row_blocks<PD, NPE, NIP, TYPE>(gv, coords, e, a, K, s01, s23);
     }
+    const unsigned sw[4] = {s01.x, s01.y, s23.x, s23.y};
     auto add_all = [&] {
 #pragma unroll
-        for (int b = 0; b < NPE; b++)
-            if ((unsigned)sl[b] < (unsigned)ww) {
-                double* q = accrow + sl[b] * BB;
+        for (int b = 0; b < NPE; b++) {
+            const int slb = (int)((sw[b >> 1] >> ((b & 1) * 16)) & 0xffffu) - j0;
+            if ((unsigned)slb < (unsigned)ww) {
+                double* q = accrow + slb * BB;
 #pragma unroll
                 for (int i = 0; i < PD; i++)
 #pragma unroll
                     for (int j = 0; j < PD; j++) q[i * PD + j] += K[b][i][j];
             }
+        }
     };
     if (!serial) {
         if (mine) add_all();
@@ -558,25 +571,25 @@ __device__ __forceinline__ void rows_add(bool mine, unsigned code, const AsmGrou
 // ROWS block rows per workgroup (a 64-row slice is shared by 64/ROWS workgroups), LPR lanes per row.
 template <int PD, int LPR, int ROWS>
 __global__ void __launch_bounds__(ROWS* LPR, 2)   // two waves per SIMD: at most 256 registers per lane
-    k_assemble_rows(int nn, const int* __restrict__ boff, const int* __restrict__ n2e_ptr, const unsigned* __restrict__ n2e,
-                    AsmGroups gs, const double* __restrict__ coords, const unsigned char* __restrict__ slice_serial, int wcap,
-                    int rs_pad, int add, double* __restrict__ val)
+    k_assemble_rows(int nn, int nparts_real, int npass, const int* __restrict__ boff, const int* __restrict__ n2e_ptr,
+                    const unsigned* __restrict__ n2e, AsmGroups gs, const double* __restrict__ coords,
+                    const unsigned char* __restrict__ slice_serial, int wcap, int rs_pad, int add, double* __restrict__ val)
 {
     constexpr int BB = PD * PD, TPB = ROWS * LPR, PARTS = 64 / ROWS;
     extern __shared__ double acc[];   // [ROWS][RS]: the image of this workgroup's rows of the slice
-    __shared__ int s_maxcnt;
     const int t = threadIdx.x, rl = t / LPR, k = t % LPR;
-    const int sl = blockIdx.x / PARTS, part = blockIdx.x % PARTS;
+    // Workgroups b and b + 8 share an XCD (and its L2): hand every XCD a contiguous eighth of the parts, so that
+    // neighbouring parts -- which read the same elements' nodes and coordinates -- meet in one L2.  Speed only.
+    const int nparts = gridDim.x;
+    const int chunk = (nparts + 7) / 8;
+    const int part_id = ((int)blockIdx.x % 8) * chunk + (int)blockIdx.x / 8;
+    if (part_id >= nparts_real) return;
+    const int sl = part_id / PARTS, part = part_id % PARTS;
     const int row = sl * 64 + part * ROWS + rl;
     const int o0 = boff[sl], W = boff[sl + 1] - o0;
     const bool valid = row < nn;
     const int p0 = valid ? n2e_ptr[row] : 0;
     const int cnt = valid ? n2e_ptr[row + 1] - p0 : 0;
-    if (t == 0) s_maxcnt = 0;
-    __syncthreads();
-    if (k == 0 && cnt > 0) atomicMax(&s_maxcnt, cnt);
-    __syncthreads();
-    const int npass = (s_maxcnt + LPR - 1) / LPR;
     const bool serial = slice_serial[sl] != 0;
     for (int j0 = 0; j0 < W; j0 += wcap) {   // one window unless a slice is wider than the LDS image allows
         const int ww = min(wcap, W - j0), len = ww * BB;
@@ -604,13 +617,14 @@ __global__ void __launch_bounds__(ROWS* LPR, 2)   // two waves per SIMD: at most
             }
         }
         __syncthreads();
-        // write-out: entry (j, c) of the ROWS rows is ROWS consecutive words of val
+        // write-out: entry (j, c) of the ROWS rows is ROWS consecutive words of val; two rows (16 bytes) per lane
         double* dst = val + (size_t)(o0 + j0) * BB * 64 + part * ROWS;
-        for (int i = t; i < len * ROWS; i += TPB) {
-            const int jc = i / ROWS, r = i % ROWS;
-            double* q = dst + (size_t)jc * 64 + r;
-            const double v = acc[r * RS + jc];
-            *q = add ? *q + v : v;   // MatSetValues(ADD_VALUES) on a matrix that already holds values
+        for (int i = t; i < len * (ROWS / 2); i += TPB) {
+            const int jc = i / (ROWS / 2), r = (i % (ROWS / 2)) * 2;
+            double2* q = reinterpret_cast<double2*>(dst + (size_t)jc * 64 + r);
+            double2 v = make_double2(acc[r * RS + jc], acc[(r + 1) * RS + jc]);
+            if (add) { const double2 o = *q; v.x += o.x; v.y += o.y; }   // ADD_VALUES on a matrix that already holds values
+            *q = v;
         }
         __syncthreads();
     }
@@ -646,7 +660,10 @@ void mat_assemble_elements_impl(fem_mat A)
         const int RS = rs_pad ? ((len + 30) / 32) * 32 + 1 : (len | 1);
         const size_t shmem = (size_t)rows * RS * sizeof(double);
         FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(kernel, dim3((unsigned)A->nslices * (64 / rows)), dim3(tpb), shmem, s, m->nnds, A->boff.p,
+        const int nparts = A->nslices * (64 / rows), lpr = tpb / rows;
+        const int npass = std::max(1, (P.max_valence + lpr - 1) / lpr);
+        const int grid = ((nparts + 7) / 8) * 8;   // the XCD-wise part map wants a multiple of 8
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(tpb), shmem, s, m->nnds, nparts, npass, A->boff.p,
                            A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p);
     };
     if (m->pdim == 3) launch(k_assemble_rows<3, 8, 32>, 9, 32, 256);

@@ -96,6 +96,26 @@ _SIGS = {
     "fem_ksp_get_profile": [_h, _ip, _dp, _dp],
     "fem_recover_nodal_stress": [_h, _h, _dp],
     "fem_recover_nodal_stress_vec": [_h, _h, _h],
+    "fem_mesh_set_cohesive": [_h, _ip, C.c_int, _dp],
+    "fem_mat_duplicate": [_h, C.POINTER(_h)],
+    "fem_mat_copy": [_h, _h],
+    "fem_mat_add_cohesive": [_h, _h, C.c_double, C.c_int, _ip],
+    "fem_vec_add_cohesive_traction": [_h, _h, C.c_double, C.c_int, _ip, _h],
+    "fem_enforce_bc_force": [_h, C.c_int, _ip, _dp, C.c_double, C.c_double, _h],
+    "fem_mat_mult_add": [_h, _h, _h, _h],
+    "fem_vec_scale": [_h, C.c_double],
+    "fem_snes_create": [_h, C.POINTER(_h)],
+    "fem_snes_destroy": [_h],
+    "fem_snes_get_ksp": [_h, C.POINTER(_h)],
+    "fem_snes_set_function": [_h, _h, C.c_void_p, C.c_void_p],
+    "fem_snes_set_jacobian": [_h, _h, _h, C.c_void_p, C.c_void_p],
+    "fem_snes_set_from_options": [_h, C.c_char_p],
+    "fem_snes_solve": [_h, _h],
+    "fem_snes_get_iteration_number": [_h, _ip],
+    "fem_snes_get_converged_reason": [_h, _ip],
+    "fem_snes_get_function_norm": [_h, _dp],
+    "fem_snes_get_linear_solve_iterations": [_h, _ip],
+    "fem_snes_get_number_function_evals": [_h, _ip],
     "fem_comm_create_self": [_h, C.POINTER(_h)],
     "fem_comm_get_unique_id": [C.c_char_p],
     "fem_comm_create_rccl": [_h, C.c_int, C.c_int, C.c_char_p, C.POINTER(_h)],
@@ -301,6 +321,24 @@ class DeviceMesh:
         _ck(_lib.fem_mesh_create(ctx.h, mesh.pdim, mesh.nels, mesh.nnds, _i(et), _i(ep), _i(cn), _i(mi), _d(co),
                                  ma.shape[0], _d(ma), C.byref(self.h)))
 
+    def set_cohesive(self, mesh=None):
+        """Cohesive elements of the deck (el%nlMat, cohMats): before the first Mat is created."""
+        m = mesh or self.mesh
+        nl = _i32(m.nlmat if m.nlmat is not None else np.zeros(m.nels))
+        props = _f64(np.asarray([pr for _, pr in m.cohmats], dtype=np.float64).reshape(-1, 6))
+        _ck(_lib.fem_mesh_set_cohesive(self.h, _i(nl), props.shape[0], _d(props)))
+
+    def add_cohesive_traction(self, u_total: "Vec", dt: float, R: "Vec", rels_mode: int = 0, rels_nodes=None):
+        """The element loop of CalcResidual (src/m_global.F90:186-205)."""
+        rn = None if rels_nodes is None else _i32(rels_nodes)
+        _ck(_lib.fem_vec_add_cohesive_traction(self.h, u_total.h, dt, int(rels_mode), None if rn is None else _i(rn), R.h))
+
+    def enforce_bc_force(self, R: "Vec", dt: float, mesh=None):
+        """EnforceBCForce(Residual, dt) (src/m_global.F90:439-455)."""
+        m = mesh or self.mesh
+        bn, bv = _i32(m.bcnode), _f64(m.bcval)
+        _ck(_lib.fem_enforce_bc_force(self.h, bn.shape[0], _i(bn), _d(bv), dt, m.t, R.h))
+
     def set_halo(self, comm: Comm, neigh_rank, neigh_ptr, neigh_nodes):
         nr, npx, nn = _i32(neigh_rank), _i32(neigh_ptr), _i32(neigh_nodes)
         _ck(_lib.fem_mesh_set_halo(self.h, comm.h, len(nr), _i(nr), _i(npx), _i(nn)))
@@ -364,6 +402,9 @@ class Vec:
     def axpy(self, a: float, x: "Vec"):
         _ck(_lib.fem_vec_axpy(self.h, a, x.h))
 
+    def scale(self, a: float):
+        _ck(_lib.fem_vec_scale(self.h, a))
+
     def dot(self, y: "Vec") -> float:
         d = C.c_double(0)
         _ck(_lib.fem_vec_dot(self.h, y.h, C.byref(d)))
@@ -383,10 +424,32 @@ class Vec:
 class Mat:
     """Mat_K: MatCreateAIJ (src/main.F90:154) + the assembly loop (:157-171)."""
 
-    def __init__(self, dmesh: DeviceMesh):
+    def __init__(self, dmesh: DeviceMesh, handle=None):
         self.dmesh = dmesh
         self.h = _h()
-        _ck(_lib.fem_mat_create_aij(dmesh.h, C.byref(self.h)))
+        if handle is not None:
+            self.h = handle
+        else:
+            _ck(_lib.fem_mat_create_aij(dmesh.h, C.byref(self.h)))
+
+    def duplicate(self) -> "Mat":
+        """MatDuplicate(..., MAT_COPY_VALUES, ...) (src/main.F90:197)."""
+        h = _h()
+        _ck(_lib.fem_mat_duplicate(self.h, C.byref(h)))
+        return Mat(self.dmesh, handle=h)
+
+    def copy_to(self, other: "Mat"):
+        """MatCopy(self, other, SAME_NONZERO_PATTERN) (src/m_global.F90:123)."""
+        _ck(_lib.fem_mat_copy(self.h, other.h))
+
+    def add_cohesive(self, u_total: "Vec", dt: float, rels_mode: int = 0, rels_nodes=None):
+        """The element loop of CalcJacobian (src/m_global.F90:127-147)."""
+        rn = None if rels_nodes is None else _i32(rels_nodes)
+        _ck(_lib.fem_mat_add_cohesive(self.h, u_total.h, dt, int(rels_mode), None if rn is None else _i(rn)))
+
+    def mult_add(self, x: "Vec", y: "Vec", z: "Vec"):
+        """MatMultAdd: z = y + A x (src/m_global.F90:224)."""
+        _ck(_lib.fem_mat_mult_add(self.h, x.h, y.h, z.h))
 
     def zero_entries(self):
         _ck(_lib.fem_mat_zero_entries(self.h))
@@ -444,10 +507,14 @@ class Mat:
 class KSP:
     """Krylov (SetupKSPSolver src/main.F90:339-403; KSPSolve :247)."""
 
-    def __init__(self, ctx: Context):
+    def __init__(self, ctx: Context, handle=None):
         self.ctx = ctx
         self.h = _h()
-        _ck(_lib.fem_ksp_create(ctx.h, C.byref(self.h)))
+        self.owned = handle is None
+        if handle is not None:
+            self.h = handle
+        else:
+            _ck(_lib.fem_ksp_create(ctx.h, C.byref(self.h)))
 
     def set_operators(self, A: Mat):
         _ck(_lib.fem_ksp_set_operators(self.h, A.h))
@@ -499,6 +566,99 @@ class KSP:
         return n.value, a.value, b.value
 
     def destroy(self):
-        if self.h:
+        if self.h and self.owned:
             _ck(_lib.fem_ksp_destroy(self.h))
+        self.h = _h()
+
+
+SNES_FUNCTION_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+SNES_JACOBIAN_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+
+
+def _borrow_vec(ctx, h) -> "Vec":
+    """A Vec the library passes to a callback (not owned here: destroy() is never called on it)."""
+    v = Vec.__new__(Vec)
+    v.ctx = ctx
+    v.h = _h(h)
+    n = C.c_longlong(0)
+    _ck(_lib.fem_vec_get_size(v.h, C.byref(n)))
+    v.n = n.value
+    return v
+
+
+class SNES:
+    """Solver (src/main.F90:200-206, :242-243): Newton line search with the host's CalcResidual / CalcJacobian."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.h = _h()
+        _ck(_lib.fem_snes_create(ctx.h, C.byref(self.h)))
+        self._keep = []
+
+    def get_ksp(self) -> KSP:
+        h = _h()
+        _ck(_lib.fem_snes_get_ksp(self.h, C.byref(h)))
+        return KSP(self.ctx, handle=h)
+
+    def set_function(self, r: Vec, fn):
+        """fn(x, f) fills the residual f for the iterate x (both borrowed Vec handles)."""
+        def tramp(_snes, x, f, _ctx):
+            try:
+                fn(_borrow_vec(self.ctx, x), _borrow_vec(self.ctx, f))
+                return 0
+            except Exception as e:   # noqa: BLE001 -- reported through the C return code
+                self.error = e
+                return 1
+        cb = SNES_FUNCTION_CB(tramp)
+        self._keep.append(cb)
+        _ck(_lib.fem_snes_set_function(self.h, r.h, C.cast(cb, C.c_void_p), None))
+
+    def set_jacobian(self, J: Mat, fn):
+        """fn(x, J) fills the Jacobian for the iterate x."""
+        def tramp(_snes, x, j, _p, _ctx):
+            try:
+                fn(_borrow_vec(self.ctx, x), J)
+                return 0
+            except Exception as e:   # noqa: BLE001
+                self.error = e
+                return 1
+        cb = SNES_JACOBIAN_CB(tramp)
+        self._keep.append(cb)
+        _ck(_lib.fem_snes_set_jacobian(self.h, J.h, J.h, C.cast(cb, C.c_void_p), None))
+
+    def set_from_options(self, options: str):
+        _ck(_lib.fem_snes_set_from_options(self.h, options.encode()))
+
+    def solve(self, x: Vec):
+        self.error = None
+        rc = _lib.fem_snes_solve(self.h, x.h)
+        if rc and self.error is not None:
+            raise self.error
+        _ck(rc)
+
+    def _geti(self, f):
+        v = C.c_int(0)
+        _ck(f(self.h, C.byref(v)))
+        return v.value
+
+    def get_iteration_number(self) -> int:
+        return self._geti(_lib.fem_snes_get_iteration_number)
+
+    def get_converged_reason(self) -> int:
+        return self._geti(_lib.fem_snes_get_converged_reason)
+
+    def get_linear_solve_iterations(self) -> int:
+        return self._geti(_lib.fem_snes_get_linear_solve_iterations)
+
+    def get_number_function_evals(self) -> int:
+        return self._geti(_lib.fem_snes_get_number_function_evals)
+
+    def get_function_norm(self) -> float:
+        v = C.c_double(0)
+        _ck(_lib.fem_snes_get_function_norm(self.h, C.byref(v)))
+        return v.value
+
+    def destroy(self):
+        if self.h:
+            _ck(_lib.fem_snes_destroy(self.h))
             self.h = _h()

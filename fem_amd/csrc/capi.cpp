@@ -53,6 +53,25 @@ void comm_get_unique_id_impl(char*);
 fem_comm comm_create_rccl_impl(fem_ctx, int, int, const char*);
 void comm_create_local_group_impl(int, const fem_ctx*, fem_comm*);
 
+void mesh_set_cohesive_impl(fem_mesh, const int*, int, const double*);
+void mat_add_cohesive_impl(fem_mat, const double*, double, int, const int*);
+void vec_add_cohesive_traction_impl(fem_mesh, const double*, double, int, const int*, double*);
+void enforce_bc_force_impl(fem_mesh, int, const int*, const double*, double, double, double*);
+void vec_scale(fem_vec, double);
+void vec_waxpy(fem_vec w, double a, fem_vec x, fem_vec y);
+extern "C" {
+typedef int (*fem_snes_function_cb_t)(fem_snes, fem_vec, fem_vec, void*);
+typedef int (*fem_snes_jacobian_cb_t)(fem_snes, fem_vec, fem_mat, fem_mat, void*);
+}
+fem_snes snes_new(fem_ctx);
+void snes_delete(fem_snes);
+void snes_set_function(fem_snes, fem_vec, fem_snes_function_cb_t, void*);
+void snes_set_jacobian(fem_snes, fem_mat, fem_mat, fem_snes_jacobian_cb_t, void*);
+fem_ksp snes_get_ksp(fem_snes);
+void snes_set_from_options_impl(fem_snes, const char*);
+void snes_solve_impl(fem_snes, fem_vec);
+void snes_get_result(fem_snes, int*, int*, double*, int*, int*);
+
 namespace fem {
 static thread_local std::string g_last_error;
 void set_last_error(const std::string& m) { g_last_error = m; }
@@ -579,6 +598,172 @@ int fem_ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_m
 {
     FEM_TRY
     ksp_get_profile(k, n_spmv, spmv_ms, solve_ms);
+    FEM_CATCH
+}
+
+// ---- cohesive elements + Newton ---------------------------------------------------------------
+int fem_mesh_set_cohesive(fem_mesh mesh, const int* nlmat, int ncohmats, const double* props)
+{
+    FEM_TRY
+    mesh_set_cohesive_impl(mesh, nlmat, ncohmats, props);
+    FEM_CATCH
+}
+
+int fem_mat_duplicate(fem_mat A, fem_mat* B)
+{
+    FEM_TRY
+    FEM_CHECK(A && B, 1, "fem_mat_duplicate: null argument");
+    std::unique_ptr<fem_mat_s> D(mat_create_impl(A->mesh));
+    const int rc = fem_mat_copy(A, D.get());
+    if (rc) return rc;
+    *B = D.release();
+    FEM_CATCH
+}
+
+int fem_mat_copy(fem_mat src, fem_mat dst)
+{
+    FEM_TRY
+    FEM_CHECK(src && dst && src->pat.get() == dst->pat.get(), 8, "fem_mat_copy: the matrices do not share a mesh (pattern)");
+    src->ctx->bind();
+    FEM_HIP(hipMemcpyAsync(dst->val.p, src->values(), src->val.bytes(), hipMemcpyDeviceToDevice, src->ctx->stream));
+    dst->lazy_zero = false;
+    dst->unsymmetric = src->unsymmetric;
+    // the copy holds the same penalty rows; a later ApplyKBC on it starts from what it finds
+    dst->bc_saved = false;
+    FEM_CATCH
+}
+
+int fem_mat_add_cohesive(fem_mat J, fem_vec u_total, double dt, int rels_mode, const int* rels_nodes)
+{
+    FEM_TRY
+    FEM_CHECK(J && u_total && u_total->n == (long long)J->nbrows * J->bs, 8, "fem_mat_add_cohesive: vector size mismatch");
+    mat_add_cohesive_impl(J, u_total->d.p, dt, rels_mode, rels_nodes);
+    FEM_CATCH
+}
+
+int fem_vec_add_cohesive_traction(fem_mesh mesh, fem_vec u_total, double dt, int rels_mode, const int* rels_nodes, fem_vec R)
+{
+    FEM_TRY
+    FEM_CHECK(mesh && u_total && R, 1, "fem_vec_add_cohesive_traction: null handle");
+    const long long n = (long long)mesh->nnds * mesh->pdim;
+    FEM_CHECK(u_total->n == n && R->n == n, 8, "fem_vec_add_cohesive_traction: vector size mismatch");
+    vec_add_cohesive_traction_impl(mesh, u_total->d.p, dt, rels_mode, rels_nodes, R->d.p);
+    FEM_CATCH
+}
+
+int fem_enforce_bc_force(fem_mesh mesh, int nbcs, const int* bcnode, const double* bcval, double dt, double t_total, fem_vec R)
+{
+    FEM_TRY
+    FEM_CHECK(mesh && R && R->n == (long long)mesh->nnds * mesh->pdim, 8, "fem_enforce_bc_force: vector size mismatch");
+    enforce_bc_force_impl(mesh, nbcs, bcnode, bcval, dt, t_total, R->d.p);
+    FEM_CATCH
+}
+
+int fem_mat_mult_add(fem_mat A, fem_vec x, fem_vec y, fem_vec z)
+{
+    FEM_TRY
+    FEM_CHECK(A && x && y && z, 1, "null handle");
+    const long long n = (long long)A->nbrows * A->bs;
+    FEM_CHECK(x->n == n && y->n == n && z->n == n && x != z, 8, "fem_mat_mult_add: vector size mismatch (or x aliases z)");
+    A->ctx->bind();
+    fem::DBuf<double> t((size_t)n);
+    mat_mult_raw(A, x->d.p, t.p, nullptr, nullptr);
+    halo_sum(A->mesh, t.p, A->bs, A->bs, 1);
+    fem_vec_s tv; tv.ctx = A->ctx; tv.n = n; tv.d = std::move(t);
+    vec_waxpy(z, 1.0, &tv, y);
+    FEM_HIP(hipStreamSynchronize(A->ctx->stream));
+    FEM_CATCH
+}
+
+int fem_vec_scale(fem_vec v, double alpha)
+{
+    FEM_TRY
+    FEM_CHECK(v, 1, "null vector");
+    vec_scale(v, alpha);
+    FEM_CATCH
+}
+
+int fem_snes_create(fem_ctx ctx, fem_snes* snes)
+{
+    FEM_TRY
+    FEM_CHECK(ctx && snes, 1, "null argument");
+    *snes = snes_new(ctx);
+    FEM_CATCH
+}
+int fem_snes_destroy(fem_snes sn)
+{
+    FEM_TRY
+    snes_delete(sn);
+    FEM_CATCH
+}
+int fem_snes_get_ksp(fem_snes sn, fem_ksp* ksp)
+{
+    FEM_TRY
+    FEM_CHECK(sn && ksp, 1, "null argument");
+    *ksp = snes_get_ksp(sn);
+    FEM_CATCH
+}
+int fem_snes_set_function(fem_snes sn, fem_vec r, fem_snes_function_cb_t f, void* c)
+{
+    FEM_TRY
+    FEM_CHECK(sn && r && f, 1, "null argument");
+    snes_set_function(sn, r, f, c);
+    FEM_CATCH
+}
+int fem_snes_set_jacobian(fem_snes sn, fem_mat J, fem_mat P, fem_snes_jacobian_cb_t j, void* c)
+{
+    FEM_TRY
+    FEM_CHECK(sn && J && j, 1, "null argument");
+    snes_set_jacobian(sn, J, P, j, c);
+    FEM_CATCH
+}
+int fem_snes_set_from_options(fem_snes sn, const char* options)
+{
+    FEM_TRY
+    FEM_CHECK(sn, 1, "null handle");
+    snes_set_from_options_impl(sn, options);
+    FEM_CATCH
+}
+int fem_snes_solve(fem_snes sn, fem_vec x)
+{
+    FEM_TRY
+    FEM_CHECK(sn && x, 1, "null handle");
+    snes_solve_impl(sn, x);
+    FEM_CATCH
+}
+int fem_snes_get_iteration_number(fem_snes sn, int* its)
+{
+    FEM_TRY
+    FEM_CHECK(sn, 1, "null handle");
+    snes_get_result(sn, its, nullptr, nullptr, nullptr, nullptr);
+    FEM_CATCH
+}
+int fem_snes_get_converged_reason(fem_snes sn, int* reason)
+{
+    FEM_TRY
+    FEM_CHECK(sn, 1, "null handle");
+    snes_get_result(sn, nullptr, reason, nullptr, nullptr, nullptr);
+    FEM_CATCH
+}
+int fem_snes_get_function_norm(fem_snes sn, double* fnorm)
+{
+    FEM_TRY
+    FEM_CHECK(sn, 1, "null handle");
+    snes_get_result(sn, nullptr, nullptr, fnorm, nullptr, nullptr);
+    FEM_CATCH
+}
+int fem_snes_get_linear_solve_iterations(fem_snes sn, int* lits)
+{
+    FEM_TRY
+    FEM_CHECK(sn, 1, "null handle");
+    snes_get_result(sn, nullptr, nullptr, nullptr, lits, nullptr);
+    FEM_CATCH
+}
+int fem_snes_get_number_function_evals(fem_snes sn, int* nf)
+{
+    FEM_TRY
+    FEM_CHECK(sn, 1, "null handle");
+    snes_get_result(sn, nullptr, nullptr, nullptr, nullptr, nf);
     FEM_CATCH
 }
 

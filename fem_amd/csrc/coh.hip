@@ -2,10 +2,11 @@
 // zero-thickness element (getCohValues / getCohRels / getCohGaps, src/m_elems.F90:658-720), the
 // Xu-Needleman law (Seplaw_1_Tract / Seplaw_1_Stiff, src/m_seplaw.F90:15-94) and the element vectors and
 // matrices the Newton callbacks add (applyTract_1 src/m_global.F90:622-682, applyStiff_1 :762-845), batched,
-// one thread per element.  The Newton loop around them (SNES) is not built: see DESIGN.md section 8.
+// one thread per element; and the same on the mesh's own cohesive elements for the Newton callbacks
+// (CalcJacobian src/m_global.F90:127-147, CalcResidual :186-205; the SNES loop is snes.cpp).
 // Reference behaviour is kept as written and said so: applyTract_1 ASSIGNS per integration point (the last
 // point wins), applyStiff_1 scales only its second term by sig1*sig2*N*N*w*det.
-#include "common.h"
+#include "objects.h"
 
 using namespace fem;
 
@@ -68,16 +69,12 @@ __device__ __forceinline__ void coh_point(const double* __restrict__ u8, const d
     o.stiff[0] = s11; o.stiff[1] = s12; o.stiff[2] = s12; o.stiff[3] = s22;   // (1,1) (2,1) (1,2) (2,2)
 }
 
-__global__ void __launch_bounds__(128) k_coh_apply_1(int ncoh, const double* __restrict__ ecoords,
-                                                     const double* __restrict__ u8, const double* __restrict__ props,
-                                                     double dt, double* __restrict__ tract, double* __restrict__ stiff,
-                                                     double* __restrict__ gp_out)
+// element vector (applyTract_1) and matrix (applyStiff_1) of one cohesive element: ec = ecoords(4,2) column-major,
+// u = the eight numbers getCohRels reads, pr = the six law parameters
+__device__ __forceinline__ void coh_element(const double* __restrict__ ec, const double* __restrict__ u,
+                                            const double* __restrict__ pr, double dt, double (&res)[8], double (&K)[64],
+                                            double* __restrict__ gp_rec)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ncoh) return;
-    const double* ec = ecoords + (size_t)e * 8;      // ecoords(4,2) column-major
-    const double* u = u8 + (size_t)e * 8;
-    const double* pr = props + (size_t)e * 6;
     double t[2], n[2];
     t[0] = 0.5 * (ec[1] - ec[0] + ec[2] - ec[3]);
     t[1] = 0.5 * (ec[5] - ec[4] + ec[6] - ec[7]);
@@ -85,14 +82,13 @@ __global__ void __launch_bounds__(128) k_coh_apply_1(int ncoh, const double* __r
     t[0] /= mag; t[1] /= mag;
     const double det = mag * 0.5;
     n[0] = -t[1]; n[1] = t[0];
-    double res[8], K[64];
     for (int k = 0; k < 8; k++) res[k] = 0.0;
     for (int k = 0; k < 64; k++) K[k] = 0.0;
     for (int gp = 0; gp < 2; gp++) {
         CohGp o;
         coh_point(u, pr, dt, t, n, gp, o);
-        if (gp_out) {
-            double* g = gp_out + ((size_t)e * 2 + gp) * 14;
+        if (gp_rec) {
+            double* g = gp_rec + (size_t)gp * 14;
             g[0] = o.urel[0]; g[1] = o.urel[1]; g[2] = o.vrel[0]; g[3] = o.vrel[1]; g[4] = o.gap[0]; g[5] = o.gap[1];
             g[6] = o.vgap[0]; g[7] = o.vgap[1]; g[8] = o.tract[0]; g[9] = o.tract[1];
             g[10] = o.stiff[0]; g[11] = o.stiff[1]; g[12] = o.stiff[2]; g[13] = o.stiff[3];
@@ -120,8 +116,68 @@ __global__ void __launch_bounds__(128) k_coh_apply_1(int ncoh, const double* __r
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(128) k_coh_apply_1(int ncoh, const double* __restrict__ ecoords,
+                                                     const double* __restrict__ u8, const double* __restrict__ props,
+                                                     double dt, double* __restrict__ tract, double* __restrict__ stiff,
+                                                     double* __restrict__ gp_out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ncoh) return;
+    double res[8], K[64];
+    coh_element(ecoords + (size_t)e * 8, u8 + (size_t)e * 8, props + (size_t)e * 6, dt, res, K,
+                gp_out ? gp_out + (size_t)e * 28 : (double*)nullptr);
     if (tract) for (int k = 0; k < 8; k++) tract[(size_t)e * 8 + k] = res[k];
     if (stiff) for (int k = 0; k < 64; k++) stiff[(size_t)e * 64 + k] = K[k];
+}
+
+struct RelsNodes {
+    int v[4];
+};
+// The mesh's cohesive elements inside the Newton callbacks.  STIFF = false: R(node j) += nodeTraction (CalcResidual,
+// src/m_global.F90:200-203: ApplyNodalForce(Residual, ..., .true.)); STIFF = true: Jacobian += appliedStiff, 64
+// MatSetValue(ADD_VALUES) per element (:140-146).  getCohRels reads local_u(2(k-1)+i), k = 1..4 -- four fixed nodes of
+// the rank (rels_mode 0: `rn`, by default the first four), not the element's (src/m_elems.F90:697-704); rels_mode 1
+// hands it the element's own nodes.  fp64 atomics: a node may sit in several cohesive elements.
+template <bool STIFF>
+__global__ void __launch_bounds__(128) k_coh_mesh(int ncoh, const int* __restrict__ conn, const double* __restrict__ props,
+                                                  const double* __restrict__ coords, const double* __restrict__ utot, double dt,
+                                                  int rels_mode, RelsNodes rn, double* __restrict__ R,
+                                                  const int* __restrict__ rowlen, const int* __restrict__ boff,
+                                                  const int* __restrict__ bcol, double* __restrict__ val)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= ncoh) return;
+    const int* nd = conn + (size_t)e * 4;
+    double ec[8], u[8], res[8], K[64];
+    for (int a = 0; a < 4; a++) {
+        ec[a] = coords[(size_t)nd[a] * 2]; ec[a + 4] = coords[(size_t)nd[a] * 2 + 1];
+        const int v = rels_mode ? nd[a] : rn.v[a];
+        u[2 * a] = utot[(size_t)v * 2]; u[2 * a + 1] = utot[(size_t)v * 2 + 1];
+    }
+    coh_element(ec, u, props + (size_t)e * 6, dt, res, K, nullptr);
+    if constexpr (!STIFF) {
+        for (int j = 0; j < 4; j++)
+            for (int d = 0; d < 2; d++) unsafeAtomicAdd(R + (size_t)nd[j] * 2 + d, res[2 * j + d]);
+    } else {
+        for (int n1 = 0; n1 < 4; n1++) {
+            const int row = nd[n1];
+            const int o0 = boff[row >> 6], lane = row & 63, len = rowlen[row];
+            for (int n2 = 0; n2 < 4; n2++) {
+                const int col = nd[n2];
+                int lo = 0, hi = len;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (bcol[(size_t)(o0 + mid) * 64 + lane] < col) lo = mid + 1; else hi = mid;
+                }
+                double* blk = val + (size_t)(o0 + lo) * 4 * 64 + lane;
+                for (int d1 = 0; d1 < 2; d1++)
+                    for (int d2 = 0; d2 < 2; d2++)
+                        unsafeAtomicAdd(blk + (size_t)(d1 * 2 + d2) * 64, K[(n1 * 2 + d1) + 8 * (n2 * 2 + d2)]);
+            }
+        }
+    }
 }
 
 }  // namespace fem
@@ -144,4 +200,75 @@ void coh_apply_1_impl(fem_ctx ctx, int ncoh, const double* ecoords, const double
     if (stiff) dK.download(stiff, dK.n, s);
     if (gp) dG.download(gp, dG.n, s);
     FEM_HIP(hipStreamSynchronize(s));
+}
+
+// fem_mesh_set_cohesive: the cohesive elements of the deck (type coh in the element list the mesh was created from)
+void mesh_set_cohesive_impl(fem_mesh m, const int* nlmat, int ncohmats, const double* props)
+{
+    FEM_CHECK(m && nlmat, 1, "fem_mesh_set_cohesive: null argument");
+    FEM_CHECK(!m->pattern, 5, "fem_mesh_set_cohesive: call it before the first fem_mat_create_aij (the sparsity holds the "
+                              "cohesive node pairs)");
+    FEM_CHECK(ncohmats >= 0 && (ncohmats == 0 || props), 2, "fem_mesh_set_cohesive: bad material table");
+    m->ctx->bind();
+    hipStream_t s = m->ctx->stream;
+    std::vector<int> conn;
+    std::vector<double> pr;
+    for (int e = 0; e < m->nels; e++) {
+        if (nlmat[e] == 0) continue;   // el%nlMat == 0: linear element (src/m_global.F90:130)
+        FEM_CHECK(m->h_eltype[e] == FEM_COH, 3, "fem_mesh_set_cohesive: nlMat set on an element that is not of type coh");
+        FEM_CHECK(m->pdim == 2, 3, "fem_mesh_set_cohesive: cohesive elements are 2-D (4 nodes)");
+        FEM_CHECK(nlmat[e] >= 1 && nlmat[e] <= ncohmats, 3, "fem_mesh_set_cohesive: cohesive material out of range");
+        for (int a = 0; a < 4; a++) {
+            const int v = m->h_conn[m->h_eptr[e] + a];
+            FEM_CHECK(v >= 0 && v < m->nnds, 3, "fem_mesh_set_cohesive: node id out of range");
+            conn.push_back(v);
+        }
+        for (int q = 0; q < 6; q++) pr.push_back(props[(size_t)(nlmat[e] - 1) * 6 + q]);
+    }
+    m->ncoh = (int)(conn.size() / 4);
+    m->h_coh_conn = conn;
+    if (m->ncoh) {
+        m->coh_conn.alloc(conn.size()); m->coh_conn.upload(conn.data(), conn.size(), s);
+        m->coh_props.alloc(pr.size()); m->coh_props.upload(pr.data(), pr.size(), s);
+        FEM_HIP(hipStreamSynchronize(s));
+    }
+}
+
+static RelsNodes rels_of(fem_mesh m, int rels_mode, const int* rels_nodes)
+{
+    RelsNodes rn{{0, 1, 2, 3}};   // "the first four local nodes of the rank"
+    if (rels_nodes) for (int a = 0; a < 4; a++) rn.v[a] = rels_nodes[a];
+    if (!rels_mode)
+        for (int a = 0; a < 4; a++) FEM_CHECK(rn.v[a] >= 0 && rn.v[a] < m->nnds, 3, "cohesive: rels node out of range");
+    return rn;
+}
+
+// CalcJacobian's element loop (src/m_global.F90:127-147) on Jacobian J
+void mat_add_cohesive_impl(fem_mat J, const double* utot, double dt, int rels_mode, const int* rels_nodes)
+{
+    fem_mesh m = J->mesh;
+    if (m->ncoh == 0) return;
+    FEM_CHECK(dt > 0.0, 2, "fem_mat_add_cohesive: dt must be positive");
+    J->ctx->bind();
+    hipStream_t s = J->ctx->stream;
+    const RelsNodes rn = rels_of(m, rels_mode, rels_nodes);
+    hipLaunchKernelGGL(k_coh_mesh<true>, dim3(cdiv((size_t)m->ncoh, 128)), dim3(128), 0, s, m->ncoh, m->coh_conn.p, m->coh_props.p,
+                       m->coords.p, utot, dt, rels_mode, rn, (double*)nullptr, J->rowlen.p, J->boff.p, J->bcol.p, J->values());
+    J->unsymmetric = true;
+    J->bc_saved = false;   // ApplyKBC comes next and sees a new diagonal
+    FEM_HIP(hipGetLastError());
+}
+
+// CalcResidual's element loop (src/m_global.F90:186-205) on R
+void vec_add_cohesive_traction_impl(fem_mesh m, const double* utot, double dt, int rels_mode, const int* rels_nodes, double* R)
+{
+    if (m->ncoh == 0) return;
+    FEM_CHECK(dt > 0.0, 2, "fem_vec_add_cohesive_traction: dt must be positive");
+    m->ctx->bind();
+    hipStream_t s = m->ctx->stream;
+    const RelsNodes rn = rels_of(m, rels_mode, rels_nodes);
+    hipLaunchKernelGGL(k_coh_mesh<false>, dim3(cdiv((size_t)m->ncoh, 128)), dim3(128), 0, s, m->ncoh, m->coh_conn.p, m->coh_props.p,
+                       m->coords.p, utot, dt, rels_mode, rn, R, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                       (double*)nullptr);
+    FEM_HIP(hipGetLastError());
 }

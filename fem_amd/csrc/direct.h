@@ -36,6 +36,30 @@ struct BandCholesky {
     size_t device_bytes() const { return perm_dof.bytes() + ab.bytes() + linv.bytes() + v0.bytes() + v1.bytes() + v2.bytes(); }
 };
 
+// The same options on a Mat that is not symmetric (the Newton Jacobian: Mat_K + cohesive tangents, whose reference
+// formula scales only one of its two terms, src/m_global.F90:830-831): general band LU with partial pivoting, as
+// LAPACK's dgbtf2 -- row k is exchanged with the largest entry of column k among the kl rows below, the fill stays
+// inside kl + ku super-diagonals.  One workgroup walks the columns (the dependency chain is the matrix order), its
+// threads share the rank-1 update of the (kl x (kl+ku)) window: meant for the reference's cohesive decks and their
+// tilings (config 5: 16,000 dofs, half bandwidth 15), where it finishes in milliseconds; large 3-D decks are not its job.
+// A pivot below 1e-6 of the largest finite-size entry is treated the way the reference asks MUMPS to treat it
+// (ICNTL(24) = 1, CNTL(3) = 1e-6, src/main.F90:368-371): the unknown is fixed to zero.
+struct BandLU {
+    fem_mat A = nullptr;
+    int bs = 0;
+    long long n = 0;
+    int kl = 0;                 // half bandwidth in dofs after renumbering (kl = ku)
+    int wb = 0;                 // stored row width: 3 kl + 1
+    bool failed = false;
+    DBuf<int> perm_dof;         // [n] new position of every dof
+    DBuf<double> ab;            // [n*wb] row i holds columns i-kl .. i+2kl
+    DBuf<int> ipiv;             // [n]
+    DBuf<double> v0;            // work vector
+    DBuf<int> flag;
+    void setup(fem_mat A);
+    void solve(const double* b, double* x);
+};
+
 // reverse Cuthill-McKee ordering of an undirected graph given as CSR adjacency (host)
 std::vector<int> rcm_order(int n, const std::vector<int>& ptr, const std::vector<int>& adj);
 

@@ -490,6 +490,186 @@ void BandCholesky::setup(fem_mat A_)
     failed = hflag != 0;
 }
 
+// ---- general band LU (unsymmetric Jacobians) ------------------------------------------------------------------
+// full band of the renumbered matrix: element (i, j) at ab[i*wb + j - i + kl]
+template <int BS>
+__global__ void __launch_bounds__(256) k_bandfull_fill(int nn, const int* __restrict__ boff, const int* __restrict__ bcol,
+                                                       const double* __restrict__ val, const int* __restrict__ rowlen,
+                                                       const int* __restrict__ perm, int kl, int wb, double* __restrict__ ab)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nn) return;
+    const int ln = i & 63, len = rowlen[i], o0 = boff[i >> 6];
+    const long long pi = perm[i];
+    for (int j = 0; j < len; j++) {
+        const long long pj = perm[bcol[(size_t)(o0 + j) * 64 + ln]];
+        for (int r = 0; r < BS; r++)
+            for (int c = 0; c < BS; c++) {
+                const long long gi = pi * BS + r, gj = pj * BS + c;
+                ab[gi * wb + (gj - gi + kl)] = val[((size_t)(o0 + j) * BS * BS + r * BS + c) * 64 + ln];
+            }
+    }
+}
+
+// largest entry that is not a penalty (scale of the null-pivot test)
+__global__ void __launch_bounds__(256) k_band_amax(size_t n, const double* __restrict__ ab, double* __restrict__ out)
+{
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 256) { const double a = fabs(ab[i]); if (a < 1e29 && a > m) m = a; }
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
+    if (threadIdx.x == 0) *out = sh[0];
+}
+
+// dgbtf2: one workgroup, column by column
+__global__ void __launch_bounds__(256) k_band_lu(long long n, int kl, int wb, double* __restrict__ ab, int* __restrict__ ipiv,
+                                                 const double* __restrict__ amax, int* __restrict__ flag)
+{
+    __shared__ double s_piv;
+    __shared__ int s_p;
+    const double tiny = 1e-6 * (*amax);
+    const int ku2 = 2 * kl;   // upper band incl. fill
+    for (long long k = 0; k < n; k++) {
+        const int km = (int)min((long long)kl, n - 1 - k);       // rows below
+        const int nc = (int)min((long long)ku2, n - 1 - k);      // columns to the right
+        if (threadIdx.x == 0) {
+            int p = 0;
+            double best = fabs(ab[k * wb + kl]);
+            for (int r = 1; r <= km; r++) {
+                const double a = fabs(ab[(k + r) * wb + (kl - r)]);
+                if (a > best) { best = a; p = r; }
+            }
+            s_p = p; s_piv = best;
+            ipiv[k] = (int)(k + p);
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (s_piv <= tiny) {   // null pivot: the unknown is fixed to zero (row and column dropped)
+            if (threadIdx.x == 0) { ipiv[k] = -1 - (int)k; atomicAdd(flag, 0); }
+            for (int r = threadIdx.x + 1; r <= km; r += 256) ab[(k + r) * wb + (kl - r)] = 0.0;
+            for (int c = threadIdx.x + 1; c <= nc; c += 256) ab[k * wb + kl + c] = 0.0;
+            if (threadIdx.x == 0) ab[k * wb + kl] = 1.0;
+            __syncthreads();
+            continue;
+        }
+        if (p > 0)   // exchange rows k and k+p over columns k .. k+nc
+            for (int c = threadIdx.x; c <= nc; c += 256) {
+                double* a = ab + k * wb + kl + c;
+                double* b = ab + (k + p) * wb + (kl - p) + c;
+                const double t = *a; *a = *b; *b = t;
+            }
+        __syncthreads();
+        const double rp = 1.0 / ab[k * wb + kl];
+        for (int r = threadIdx.x + 1; r <= km; r += 256) ab[(k + r) * wb + (kl - r)] *= rp;   // multipliers
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < km * nc; idx += 256) {
+            const int r = idx / nc + 1, c = idx % nc + 1;
+            ab[(k + r) * wb + (kl - r) + c] -= ab[(k + r) * wb + (kl - r)] * ab[k * wb + kl + c];
+        }
+        __syncthreads();
+    }
+}
+
+// dgbtrs: forward with the row exchanges, then backward; one workgroup
+__global__ void __launch_bounds__(256) k_band_lu_solve(long long n, int kl, int wb, const double* __restrict__ ab,
+                                                       const int* __restrict__ ipiv, double* __restrict__ x)
+{
+    const int ku2 = 2 * kl;
+    for (long long k = 0; k < n; k++) {
+        const int km = (int)min((long long)kl, n - 1 - k);
+        const int pv = ipiv[k];
+        if (pv < 0) {   // fixed unknown
+            if (threadIdx.x == 0) x[k] = 0.0;
+            __syncthreads();
+            continue;
+        }
+        if (threadIdx.x == 0 && pv != k) { const double t = x[k]; x[k] = x[pv]; x[pv] = t; }
+        __syncthreads();
+        const double xk = x[k];
+        for (int r = threadIdx.x + 1; r <= km; r += 256) x[k + r] -= ab[(k + r) * wb + (kl - r)] * xk;
+        __syncthreads();
+    }
+    for (long long k = n - 1; k >= 0; k--) {
+        if (ipiv[k] < 0) { __syncthreads(); continue; }
+        if (threadIdx.x == 0) x[k] = x[k] / ab[k * wb + kl];
+        __syncthreads();
+        const double xk = x[k];
+        const int up = (int)min((long long)ku2, k);
+        for (int r = threadIdx.x + 1; r <= up; r += 256) x[k - r] -= ab[(k - r) * wb + kl + r] * xk;
+        __syncthreads();
+    }
+}
+
+void BandLU::setup(fem_mat A_)
+{
+    A = A_; bs = A->bs;
+    const int nn = A->nbrows;
+    n = (long long)nn * bs;
+    FEM_CHECK(!(A->mesh->halo && A->mesh->halo->comm->size > 1), 9, "pc lu: the direct solve is single-domain");
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    std::vector<int> hc((size_t)A->padded_blocks);
+    A->bcol.download(hc.data(), hc.size(), s);
+    FEM_HIP(hipStreamSynchronize(s));
+    std::vector<int> ptr(nn + 1, 0), adj;
+    for (int v = 0; v < nn; v++) ptr[v + 1] = ptr[v] + A->h_rowlen[v];
+    adj.resize((size_t)ptr[nn]);
+    for (int v = 0; v < nn; v++) {
+        const size_t o0 = (size_t)A->h_boff[v >> 6];
+        for (int j = 0; j < A->h_rowlen[v]; j++) adj[(size_t)ptr[v] + j] = hc[(o0 + j) * 64 + (v & 63)];
+    }
+    std::vector<int> perm = rcm_order(nn, ptr, adj);
+    long long bwn = 0, bw_nat = 0;
+    for (int v = 0; v < nn; v++)
+        for (int e = ptr[v]; e < ptr[v + 1]; e++) {
+            bwn = std::max(bwn, (long long)std::abs(perm[v] - perm[adj[e]]));
+            bw_nat = std::max(bw_nat, (long long)std::abs(v - adj[e]));
+        }
+    if (bw_nat <= bwn) { for (int v = 0; v < nn; v++) perm[v] = v; bwn = bw_nat; }
+    kl = (int)std::min<long long>(bwn * bs + bs - 1, std::max<long long>(n - 1, 0));
+    wb = 3 * kl + 1;
+    size_t free_b = 0, total_b = 0;
+    pool_trim();
+    FEM_HIP(hipMemGetInfo(&free_b, &total_b));
+    const double need = (double)n * wb * sizeof(double);
+    FEM_CHECK(need < 0.8 * (double)free_b, 9, "pc lu: the band of the unsymmetric factor needs " +
+                                                  std::to_string((long long)(need / 1048576.0)) + " MiB: use -ksp_type bcgs");
+    DBuf<int> dperm((size_t)nn);
+    dperm.upload(perm.data(), perm.size(), s);
+    perm_dof.alloc((size_t)n);
+    hipLaunchKernelGGL(k_perm_dof, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, bs, dperm.p, perm_dof.p);
+    ab.alloc((size_t)n * wb);
+    ab.zero(s);
+    if (bs == 3)
+        hipLaunchKernelGGL(k_bandfull_fill<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
+                           A->rowlen.p, dperm.p, kl, wb, ab.p);
+    else
+        hipLaunchKernelGGL(k_bandfull_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
+                           A->rowlen.p, dperm.p, kl, wb, ab.p);
+    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 1); flag.alloc(1);
+    flag.zero(s);
+    hipLaunchKernelGGL(k_band_amax, dim3(1), dim3(256), 0, s, (size_t)n * wb, ab.p, v0.p + n);
+    hipLaunchKernelGGL(k_band_lu, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p + n, flag.p);
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));
+    failed = false;
+}
+
+void BandLU::solve(const double* b, double* x)
+{
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const unsigned g = cdiv((size_t)n, 256);
+    hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);
+    hipLaunchKernelGGL(k_band_lu_solve, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
+    hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, v0.p, x);
+    FEM_HIP(hipGetLastError());
+}
+
 void BandCholesky::solve(const double* b, double* x)
 {
     fem_ctx ctx = A->ctx;

@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(256) k_stress_gather(int nn, const int* __rest
     }
     const double rv = valence ? valence[v] : 1.0;
 #pragma unroll
-    for (int c = 0; c < CP; c++) S[(size_t)c * nn + v] = valence ? s[c] / rv : s[c];
+    for (int c = 0; c < CP; c++) S[(size_t)c * nn + v] = (valence && rv != 0.0) ? s[c] / rv : s[c];   // (no solid element: 0)
 }
 
 __global__ void __launch_bounds__(256) k_divide_by_valence(size_t nn, int cp, double* __restrict__ s,
@@ -282,7 +282,10 @@ __global__ void __launch_bounds__(256) k_divide_by_valence(size_t nn, int cp, do
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t tot = nn * cp, st = (size_t)gridDim.x * blockDim.x;
-    for (; i < tot; i += st) s[i] /= valence[i % nn];  // stress_node(i,:)/global_count_node, src/main.F90:277-279
+    for (; i < tot; i += st) {   // stress_node(i,:)/global_count_node, src/main.F90:277-279
+        const double rv = valence[i % nn];
+        if (rv != 0.0) s[i] /= rv;
+    }
 }
 
 // ---- FormRHS -------------------------------------------------------------------------------------
@@ -1142,6 +1145,42 @@ void recover_nodal_stress_dev(fem_mesh m, const double* U, double* S)
     FEM_HIP(hipStreamSynchronize(s));   // the element buffers go back to the pool at scope end
 }
 
+// EnforceBCForce (src/m_global.F90:439-455): INSERT PENALTY*val*dt/t on the constrained dofs of F
+void enforce_bc_force_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval, double dt, double t_total, double* F)
+{
+    if (nbcs <= 0) return;
+    fem_ctx ctx = m->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int pd = m->pdim;
+    DBuf<int> d_bc;
+    DBuf<double> d_bcval;
+    {
+        // the reference INSERTs record after record (src/m_global.F90:439-455): where several records
+        // constrain the same dof the last one's value stands -- merged here, one record per node
+        std::vector<int> pos((size_t)m->nnds, -1), mb;
+        std::vector<double> mv;
+        for (int i = 0; i < nbcs; i++) {
+            const int* rec = bcnode + (size_t)i * (1 + pd);
+            FEM_CHECK(rec[0] >= 0 && rec[0] < m->nnds, 3, "fem_form_rhs: BC node out of range");
+            int& p = pos[rec[0]];
+            if (p < 0) {
+                p = (int)(mb.size() / (1 + pd));
+                mb.push_back(rec[0]);
+                for (int d = 0; d < pd; d++) { mb.push_back(1); mv.push_back(0.0); }
+            }
+            for (int d = 0; d < pd; d++)
+                if (rec[1 + d] == 0) { mb[(size_t)p * (1 + pd) + 1 + d] = 0; mv[(size_t)p * pd + d] = bcval[(size_t)i * pd + d]; }
+        }
+        const int nm = (int)(mb.size() / (1 + pd));
+        d_bc.alloc(mb.size()); d_bc.upload(mb.data(), mb.size(), s);
+        d_bcval.alloc(mv.size()); d_bcval.upload(mv.data(), mv.size(), s);
+        hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(nm, 256)), dim3(256), 0, s, nm, pd, d_bc.p, d_bcval.p, dt, t_total, F);
+        FEM_HIP(hipStreamSynchronize(s));   // the merged host lists die at scope end
+    }
+    FEM_HIP(hipGetLastError());
+}
+
 void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval, int nfrcs, const int* fnode,
                    const double* fval, int ntrcs, const int* telsd, const double* tval, double t_total, double t_init,
                    double dt, double* F)
@@ -1152,8 +1191,8 @@ void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval,
     const int pd = m->pdim;
     const double t_end = t_init + dt;
     FEM_HIP(hipMemsetAsync(F, 0, sizeof(double) * (size_t)m->nnds * pd, s));
-    DBuf<int> d_fnode, d_bc, d_tt, d_tn, d_ts;
-    DBuf<double> d_fval, d_bcval, d_tval;
+    DBuf<int> d_fnode, d_tt, d_tn, d_ts;
+    DBuf<double> d_fval, d_tval;
     auto add_forces = [&] {
         if (nfrcs <= 0) return;
         for (int i = 0; i < nfrcs; i++)
@@ -1194,29 +1233,7 @@ void form_rhs_impl(fem_mesh m, int nbcs, const int* bcnode, const double* bcval,
         add_forces();
         add_tractions();
     }
-    if (nbcs > 0) {
-        // the reference INSERTs record after record (src/m_global.F90:439-455): where several records
-        // constrain the same dof the last one's value stands -- merged here, one record per node
-        std::vector<int> pos((size_t)m->nnds, -1), mb;
-        std::vector<double> mv;
-        for (int i = 0; i < nbcs; i++) {
-            const int* rec = bcnode + (size_t)i * (1 + pd);
-            FEM_CHECK(rec[0] >= 0 && rec[0] < m->nnds, 3, "fem_form_rhs: BC node out of range");
-            int& p = pos[rec[0]];
-            if (p < 0) {
-                p = (int)(mb.size() / (1 + pd));
-                mb.push_back(rec[0]);
-                for (int d = 0; d < pd; d++) { mb.push_back(1); mv.push_back(0.0); }
-            }
-            for (int d = 0; d < pd; d++)
-                if (rec[1 + d] == 0) { mb[(size_t)p * (1 + pd) + 1 + d] = 0; mv[(size_t)p * pd + d] = bcval[(size_t)i * pd + d]; }
-        }
-        const int nm = (int)(mb.size() / (1 + pd));
-        d_bc.alloc(mb.size()); d_bc.upload(mb.data(), mb.size(), s);
-        d_bcval.alloc(mv.size()); d_bcval.upload(mv.data(), mv.size(), s);
-        hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(nm, 256)), dim3(256), 0, s, nm, pd, d_bc.p, d_bcval.p, dt, t_total, F);
-        FEM_HIP(hipStreamSynchronize(s));   // the merged host lists die at scope end
-    }
+    enforce_bc_force_impl(m, nbcs, bcnode, bcval, dt, t_total, F);
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
 }

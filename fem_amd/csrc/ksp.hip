@@ -267,6 +267,47 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState
     if (threadIdx.x == 0) { pzz[blockIdx.x] = zz; pzr[blockIdx.x] = zr; }
 }
 
+// ---- BiCGStab kernels (KSPBCGS, for the unsymmetric Newton Jacobian) ---------------------------------------------
+__global__ void __launch_bounds__(256) k_bcgs_init(size_t n, const double* __restrict__ b, const double* __restrict__ dinv,
+                                                   double* __restrict__ x, double* __restrict__ R, double* __restrict__ RP,
+                                                   double* __restrict__ P, double* __restrict__ V)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { const double r = dinv[i] * b[i]; x[i] = 0.0; R[i] = r; RP[i] = r; P[i] = 0.0; V[i] = 0.0; }
+}
+__global__ void __launch_bounds__(256) k_mul_inplace(size_t n, const double* __restrict__ d, double* __restrict__ y)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) y[i] *= d[i];
+}
+// p = r + beta (p - omega v)
+__global__ void __launch_bounds__(256) k_bcgs_p(size_t n, double beta, double omega, const double* __restrict__ R,
+                                                const double* __restrict__ V, double* __restrict__ P)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) P[i] = R[i] + beta * (P[i] - omega * V[i]);
+}
+// w = y + a x
+__global__ void __launch_bounds__(256) k_waxpy(size_t n, double a, const double* __restrict__ x, const double* __restrict__ y,
+                                               double* __restrict__ w)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) w[i] = y[i] + a * x[i];
+}
+// x += alpha p + omega s ; r = s - omega t
+__global__ void __launch_bounds__(256) k_bcgs_xr(size_t n, double alpha, double omega, const double* __restrict__ P,
+                                                 const double* __restrict__ S, const double* __restrict__ T,
+                                                 double* __restrict__ x, double* __restrict__ R)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) { x[i] += alpha * P[i] + omega * S[i]; R[i] = S[i] - omega * T[i]; }
+}
+
 }  // namespace fem
 
 struct fem_ksp_s {
@@ -282,6 +323,8 @@ struct fem_ksp_s {
     DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
     std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
     std::unique_ptr<fem::BandCholesky> direct;   // -ksp_type preonly -pc_type lu|cholesky
+    std::unique_ptr<fem::BandLU> direct_lu;      // the same on a Mat flagged unsymmetric (Newton Jacobian)
+    DBuf<double> bcgs_work;                      // -ksp_type bcgs: r, r', v, t, s, p, A*in scratch
     bool mg_additive = false;
     double mg_box = 4.0;                     // level-1 box edge in mean node spacings
     int mg_slice_min = 32768;
@@ -313,7 +356,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
     while (is >> key) {
         if (key == "-ksp_type") {
             is >> val;
-            FEM_CHECK(val == "cg" || val == "preonly", 6, "unsupported -ksp_type " + val + " (cg|preonly)");
+            FEM_CHECK(val == "cg" || val == "preonly" || val == "bcgs", 6, "unsupported -ksp_type " + val + " (cg|preonly|bcgs)");
             k->type = val;
         }
         else if (key == "-pc_type") {
@@ -364,14 +407,22 @@ void ksp_set_up_impl(fem_ksp k)
     const bool direct = k->pc == "lu";
     FEM_CHECK((k->type == "preonly") == direct, 6,
               "fem_ksp_set_up: -ksp_type " + k->type + " with -pc_type " + k->pc +
-                  " is not supported (cg with jacobi|none|mg, preonly with lu|cholesky)");
+                  " is not supported (cg with jacobi|none|mg, bcgs with jacobi|none, preonly with lu|cholesky)");
     k->direct.reset();
+    k->direct_lu.reset();
     if (direct) {
         k->mg.reset();
-        k->direct.reset(new fem::BandCholesky);
-        k->direct->setup(A);
+        if (A->unsymmetric) { k->direct_lu.reset(new fem::BandLU); k->direct_lu->setup(A); }
+        else { k->direct.reset(new fem::BandCholesky); k->direct->setup(A); }
         k->setup_done = true;
         return;
+    }
+    FEM_CHECK(!(A->unsymmetric && k->type == "cg"), 6,
+              "fem_ksp_set_up: the operator carries cohesive tangents and is not symmetric: -ksp_type bcgs or preonly/lu");
+    if (k->type == "bcgs") {
+        FEM_CHECK(k->pc == "jacobi" || k->pc == "none", 6, "fem_ksp_set_up: -ksp_type bcgs pairs with -pc_type jacobi|none");
+        FEM_CHECK(!(A->mesh->halo && A->mesh->halo->comm->size > 1), 9, "fem_ksp_set_up: -ksp_type bcgs is single-domain");
+        k->bcgs_work.alloc(6 * n);
     }
     k->dinv.alloc(n); k->r.alloc(n); k->p.alloc(n); k->w.alloc(n);
     k->pzz.alloc(VGRID); k->pzr.alloc(VGRID);
@@ -406,6 +457,77 @@ void ksp_set_up_impl(fem_ksp k)
     k->setup_done = true;
 }
 
+// KSPSolve_BCGS (PETSc 3.5 src/ksp/ksp/impls/bcgs/bcgs.c) with left PCJACOBI, preconditioned residual norm, zero
+// initial guess, KSPConvergedDefault.  Host-driven: every scalar is reduced on the device and read back (the
+// systems this serves -- the reference's cohesive decks and their tilings -- are small).
+static void ksp_bcgs_solve(fem_ksp k, fem_vec b, fem_vec x)
+{
+    fem_ctx ctx = k->ctx;
+    hipStream_t s = ctx->stream;
+    fem_mat A = k->A;
+    const size_t n = (size_t)k->n;
+    const unsigned g = vgrid(n);
+    double *R = k->bcgs_work.p, *RP = R + n, *V = RP + n, *T = V + n, *S = T + n, *P = S + n;
+    DBuf<double> part(g + 1);
+    auto dot = [&](const double* a, const double* c) {
+        hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(256), 0, s, a, c, n, 1, (const unsigned char*)nullptr, part.p);
+        hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, part.p, (const double*)nullptr, (int)g, part.p + g,
+                           (const int*)nullptr);
+        double out = 0.0;
+        FEM_HIP(hipMemcpyAsync(&out, part.p + g, sizeof(double), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        return out;
+    };
+    auto mult = [&](const double* in, double* out) {   // out = M^-1 A in
+        mat_mult_raw(A, in, out, nullptr, nullptr);
+        hipLaunchKernelGGL(k_mul_inplace, dim3(g), dim3(256), 0, s, n, k->dinv.p, out);
+    };
+    hipLaunchKernelGGL(k_bcgs_init, dim3(g), dim3(256), 0, s, n, b->d.p, k->dinv.p, x->d.p, R, RP, P, V);
+    double dp = std::sqrt(dot(R, R));
+    const double rnorm0 = dp, ttol = std::fmax(k->rtol * dp, k->abstol);
+    std::vector<double> hist{dp};
+    int reason = 0, it = 0;
+    double rhoold = 1.0, alpha = 1.0, omegaold = 1.0;
+    if (std::isnan(dp) || std::isinf(dp)) reason = FEM_KSP_DIVERGED_NANORINF;
+    else if (dp <= ttol) reason = (dp < k->abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
+    while (!reason) {
+        if (it >= k->maxit) { reason = FEM_KSP_DIVERGED_ITS; break; }
+        const double rho = dot(R, RP);
+        if (rho == 0.0) { reason = -5; break; }   // KSP_DIVERGED_BREAKDOWN
+        const double beta = (rho / rhoold) * (alpha / omegaold);
+        hipLaunchKernelGGL(k_bcgs_p, dim3(g), dim3(256), 0, s, n, beta, omegaold, R, V, P);
+        mult(P, V);
+        const double d1 = dot(V, RP);
+        if (d1 == 0.0) { reason = -5; break; }
+        alpha = rho / d1;
+        hipLaunchKernelGGL(k_waxpy, dim3(g), dim3(256), 0, s, n, -alpha, V, R, S);
+        mult(S, T);
+        const double st_ = dot(S, T), tt = dot(T, T);
+        it++;
+        if (tt == 0.0) {   // t = 0: s is the residual of x + alpha p
+            hipLaunchKernelGGL(k_axpy, dim3(g), dim3(256), 0, s, x->d.p, alpha, P, n);
+            dp = std::sqrt(dot(S, S));
+            hist.push_back(dp);
+            reason = FEM_KSP_CONVERGED_RTOL;
+            break;
+        }
+        const double omega = st_ / tt;
+        hipLaunchKernelGGL(k_bcgs_xr, dim3(g), dim3(256), 0, s, n, alpha, omega, P, S, T, x->d.p, R);
+        dp = std::sqrt(dot(R, R));
+        hist.push_back(dp);
+        rhoold = rho; omegaold = omega;
+        if (std::isnan(dp) || std::isinf(dp)) reason = FEM_KSP_DIVERGED_NANORINF;
+        else if (dp <= ttol) reason = (dp < k->abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
+        else if (dp >= k->dtol * rnorm0) reason = FEM_KSP_DIVERGED_DTOL;
+    }
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));
+    k->its = it; k->reason = reason; k->rnorm = dp;
+    const size_t nh = std::min(hist.size(), (size_t)k->hist_len);
+    if (nh) FEM_HIP(hipMemcpy(k->hist.p, hist.data(), sizeof(double) * nh, hipMemcpyHostToDevice));
+    k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
+}
+
 void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
 {
     if (!k->setup_done) ksp_set_up_impl(k);
@@ -413,6 +535,14 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     fem_ctx ctx = k->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
+    if (k->direct_lu) {
+        k->direct_lu->solve(b->d.p, x->d.p);
+        FEM_HIP(hipStreamSynchronize(s));
+        k->its = 1; k->rnorm = 0.0; k->reason = 4;
+        k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
+        return;
+    }
+    if (k->type == "bcgs") { ksp_bcgs_solve(k, b, x); return; }
     if (k->direct) {
         // KSPSolve_PREONLY: x = PC(b), one "iteration", KSP_CONVERGED_ITS; a failed factorisation
         // reports KSP_DIVERGED_PC_FAILED (PETSc raises "zero pivot" there)
@@ -569,6 +699,20 @@ void vec_axpy(fem_vec y, double a, fem_vec x)
     hipLaunchKernelGGL(k_axpy, dim3(vgrid((size_t)y->n)), dim3(256), 0, y->ctx->stream, y->d.p, a, x->d.p, (size_t)y->n);
     FEM_HIP(hipGetLastError());
 }
+void vec_scale(fem_vec v, double a)
+{
+    v->ctx->bind();
+    // y = a*y + 0: k_waxpy with x = y
+    hipLaunchKernelGGL(k_waxpy, dim3(vgrid((size_t)v->n)), dim3(256), 0, v->ctx->stream, (size_t)v->n, a - 1.0, v->d.p, v->d.p, v->d.p);
+    FEM_HIP(hipGetLastError());
+}
+// w = y + a x (w may alias y or x)
+void vec_waxpy(fem_vec w, double a, fem_vec x, fem_vec y)
+{
+    w->ctx->bind();
+    hipLaunchKernelGGL(k_waxpy, dim3(vgrid((size_t)w->n)), dim3(256), 0, w->ctx->stream, (size_t)w->n, a, x->d.p, y->d.p, w->d.p);
+    FEM_HIP(hipGetLastError());
+}
 double vec_dot(fem_vec x, fem_vec y)
 {
     fem_ctx ctx = x->ctx;
@@ -597,7 +741,7 @@ void ksp_delete(fem_ksp k)
 void ksp_set_operators(fem_ksp k, fem_mat A) { k->A = A; k->setup_done = false; }
 void ksp_set_type(fem_ksp k, const char* t)
 {
-    FEM_CHECK(t && (std::string(t) == "cg" || std::string(t) == "preonly"), 6,
+    FEM_CHECK(t && (std::string(t) == "cg" || std::string(t) == "preonly" || std::string(t) == "bcgs"), 6,
               std::string("fem_ksp_set_type: unsupported type ") + (t ? t : "(null)"));
     k->type = t; k->setup_done = false;
 }

@@ -87,31 +87,34 @@ template <bool FILL>
 __global__ void __launch_bounds__(256) k_node_neighbours(int nn, int nrows_padded, const int* __restrict__ n2e_ptr,
                                                          const unsigned* __restrict__ n2e, GroupViews gvs,
                                                          int* __restrict__ rowlen, const int* __restrict__ boff,
-                                                         int* __restrict__ bcol, int* __restrict__ err)
+                                                         int* __restrict__ bcol, int* __restrict__ err,
+                                                         const int* __restrict__ xptr, const int* __restrict__ xadj)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nrows_padded) return;
     int list[MAXNB];
     int len = 0;
+    auto insert = [&](int u) {
+        int lo = 0, hi = len;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (list[mid] < u) lo = mid + 1; else hi = mid;
+        }
+        if (lo < len && list[lo] == u) return;
+        if (len == MAXNB) { atomicExch(err, 1); return; }
+        for (int q = len; q > lo; q--) list[q] = list[q - 1];
+        list[lo] = u;
+        len++;
+    };
     if (v < nn) {
         for (int k = n2e_ptr[v]; k < n2e_ptr[v + 1]; k++) {
             const unsigned code = n2e[k];
             const GroupView gv = gvs.g[code >> 30];
             const int* c = gv.conn + (size_t)((code & 0x3fffffffu) >> 3) * gv.npe;
-            for (int a = 0; a < gv.npe; a++) {
-                const int u = c[a];
-                int lo = 0, hi = len;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (list[mid] < u) lo = mid + 1; else hi = mid;
-                }
-                if (lo < len && list[lo] == u) continue;
-                if (len == MAXNB) { atomicExch(err, 1); continue; }
-                for (int q = len; q > lo; q--) list[q] = list[q - 1];
-                list[lo] = u;
-                len++;
-            }
+            for (int a = 0; a < gv.npe; a++) insert(c[a]);
         }
+        if (xptr)   // node pairs of the cohesive elements (they are not in the incidence lists)
+            for (int k = xptr[v]; k < xptr[v + 1]; k++) insert(xadj[k]);
         if (len == 0) { list[0] = v; len = 1; }  // isolated node: keep a diagonal block
     }
     if (!FILL) {
@@ -349,6 +352,22 @@ static std::shared_ptr<MatPattern> build_pattern(fem_mesh mesh)
         hipLaunchKernelGGL(k_fill_n2e, dim3(std::min<unsigned>(cdiv(nent, 256), 8192)), dim3(256), 0, s, gvs.g[g], g,
                            n2e_ptr.p, cursor.p, n2e.p);
     }
+    // node pairs coupled by cohesive elements only (CSR over nodes; absent on decks without them)
+    DBuf<int> xptr, xadj;
+    if (mesh->ncoh > 0) {
+        std::vector<int> hp((size_t)nn + 1, 0), ha;
+        for (int e = 0; e < mesh->ncoh; e++)
+            for (int a = 0; a < 4; a++) hp[(size_t)mesh->h_coh_conn[4 * e + a] + 1] += 4;
+        for (int v = 0; v < nn; v++) hp[v + 1] += hp[v];
+        ha.resize((size_t)hp[nn]);
+        std::vector<int> fill(hp.begin(), hp.end() - 1);
+        for (int e = 0; e < mesh->ncoh; e++)
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) ha[(size_t)fill[mesh->h_coh_conn[4 * e + a]]++] = mesh->h_coh_conn[4 * e + b];
+        xptr.alloc(hp.size()); xptr.upload(hp.data(), hp.size(), s);
+        xadj.alloc(std::max<size_t>(ha.size(), 1)); xadj.upload(ha.data(), ha.size(), s);
+        FEM_HIP(hipStreamSynchronize(s));
+    }
     // row lengths (and the sort of the incidence lists, the serialisation flags of the row-owner
     // assembly, the largest valence), slice widths, slice offsets
     P->rowlen.alloc(nn);
@@ -359,7 +378,7 @@ static std::shared_ptr<MatPattern> build_pattern(fem_mesh mesh)
     hipLaunchKernelGGL(k_sort_and_flag, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, n2e_ptr.p, n2e.p, gvs,
                        mesh->pdim == 3 ? 8 : 4, P->slice_serial.p, err.p + 1);
     hipLaunchKernelGGL(k_node_neighbours<false>, dim3(cdiv(nrp, 256)), dim3(256), 0, s, nn, nrp, n2e_ptr.p, n2e.p, gvs,
-                       P->rowlen.p, (const int*)nullptr, (int*)nullptr, err.p);
+                       P->rowlen.p, (const int*)nullptr, (int*)nullptr, err.p, (const int*)xptr.p, (const int*)xadj.p);
     hipLaunchKernelGGL(k_slice_width, dim3(cdiv(P->nslices, 256)), dim3(256), 0, s, nn, P->nslices, P->rowlen.p,
                        width.p);
     P->boff.alloc((size_t)P->nslices + 1);
@@ -383,7 +402,7 @@ static std::shared_ptr<MatPattern> build_pattern(fem_mesh mesh)
     P->maxw = maxw;
     P->bcol.alloc((size_t)P->padded_blocks);
     hipLaunchKernelGGL(k_node_neighbours<true>, dim3(cdiv(nrp, 256)), dim3(256), 0, s, nn, nrp, n2e_ptr.p, n2e.p, gvs,
-                       P->rowlen.p, P->boff.p, P->bcol.p, err.p);
+                       P->rowlen.p, P->boff.p, P->bcol.p, err.p, (const int*)xptr.p, (const int*)xadj.p);
     // per-element slot maps (consumed by the assembly kernels)
     for (auto& g : mesh->groups) {
         const size_t tot_s = (size_t)g.nel * g.npe * g.npe;

@@ -49,6 +49,13 @@ struct fem_mesh_s {
     std::vector<int> h_eltype, h_eptr, h_conn;
     std::vector<int> elem_group, elem_pos;  // element -> (group index, position in group)
     std::unique_ptr<fem::Halo> halo;
+    // cohesive elements (type 5, el%nlMat >= 1): kept apart from the solid groups -- they add nothing to Mat_K, only
+    // the tangent / traction of the Newton callbacks (src/m_global.F90:127-147,186-205) and their node pairs to the
+    // sparsity.  Set by fem_mesh_set_cohesive before the first Mat is created.
+    int ncoh = 0;
+    fem::DBuf<int> coh_conn;        // [ncoh*4]
+    fem::DBuf<double> coh_props;    // [ncoh*6] the element's cohMats(nlMat) row
+    std::vector<int> h_coh_conn;
     std::shared_ptr<fem::MatPattern> pattern;   // symbolic phase result, built by the first fem_mat_create_aij
 };
 
@@ -111,6 +118,7 @@ struct fem_mat_s {
     // zeroed matrix that is assembled next never pays for the memset; every other reader goes through
     // values(), which materialises the zeros first.
     bool lazy_zero = false;
+    bool unsymmetric = false;     // cohesive tangents were added (src/m_global.F90:830-831 scales only one of two terms)
     double* values() {
         if (lazy_zero) { val.zero(ctx->stream); lazy_zero = false; }
         return val.p;

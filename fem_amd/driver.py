@@ -68,6 +68,90 @@ class Problem:
         self.dmesh.destroy()
 
 
+class NonlinearProblem(Problem):
+    """The reference's state for a deck with cohesive elements: Mat_K, its duplicate Jacobian, Residual, the SNES with
+    its two callbacks (src/main.F90:197-206) and the running total aggregate_u the callbacks add to the iterate."""
+
+    def __init__(self, ctx: capi.Context, mesh: Mesh, options: str = "", rels_mode: int = 0, rels_nodes=None):
+        super().__init__(ctx, mesh, "")
+        self.rels_mode, self.rels_nodes = rels_mode, rels_nodes
+        self.dmesh.set_cohesive()                          # before MatCreateAIJ: the sparsity holds the cohesive pairs
+        self.create_matrix()
+        self.assemble()                                    # Mat_K with ApplyKBC (src/main.F90:157-171)
+        self.J = self.K.duplicate()                        # MatDuplicate(Mat_K, MAT_COPY_VALUES, Jacobian) :197
+        self.R = capi.Vec(ctx, mesh.ndof)                  # VecDuplicate(Vec_U, Residual) :198
+        self.agg = capi.Vec(ctx, mesh.ndof)                # aggregate_u (device copy for the callbacks)
+        self.utot = capi.Vec(ctx, mesh.ndof)
+        self.snes = capi.SNES(ctx)                         # SNESCreate :200
+        self.snes_ksp = self.snes.get_ksp()                # SNESGetKSP + SetupKSPSolver :201-202
+        self.snes_ksp.set_type("preonly"); self.snes_ksp.set_pc_type("lu")          # KSPPREONLY + PCLU (MUMPS), :355-358
+        self.snes_ksp.set_tolerances(rtol=capi.REFERENCE_RTOL)                       # :349-351
+        self.snes.set_function(self.R, self.calc_residual)                           # :204
+        self.snes.set_jacobian(self.J, self.calc_jacobian)                           # :205
+        if options:
+            self.snes.set_from_options(options)                                      # SNESSetFromOptions :206
+
+    def calc_jacobian(self, du: capi.Vec, J: capi.Mat):
+        """CalcJacobian, src/m_global.F90:98-158."""
+        self.K.copy_to(J)                                  # MatCopy(Mat_K, Jacobian) :123
+        du.copy_to(self.utot); self.utot.axpy(1.0, self.agg)          # uu = uu + aggregate_u :127
+        J.add_cohesive(self.utot, self.mesh.dt, self.rels_mode, self.rels_nodes)    # applyStiff_1 + MatSetValue(ADD) :129-147
+        J.apply_kbc()                                      # ApplyKBC(Jacobian) :153
+
+    def calc_residual(self, du: capi.Vec, R: capi.Vec):
+        """CalcResidual, src/m_global.F90:161-235: Residual = Jacobian*du - (Vec_F + cohesive tractions, BC rows)."""
+        du.copy_to(self.utot); self.utot.axpy(1.0, self.agg)          # current_u = current_u + aggregate_u :182
+        self.F.copy_to(R)                                  # VecCopy(Vec_F, Residual) :184
+        self.dmesh.add_cohesive_traction(self.utot, self.mesh.dt, R, self.rels_mode, self.rels_nodes)   # :186-205
+        self.dmesh.enforce_bc_force(R, self.mesh.dt)       # EnforceBCForce :210 (and again :215)
+        R.scale(-1.0)                                      # VecScale(Residual, MINUS) :223
+        self.J.mult_add(du, R, R)                          # MatMultAdd(Jacobian, du, Residual, Residual) :224
+
+    def destroy(self):
+        self.snes.destroy()
+        for o in (self.R, self.agg, self.utot, self.J):
+            o.destroy()
+        super().destroy()
+
+
+def run_nonlinear(mesh: Mesh, options: str = "", ctx: capi.Context | None = None, rels_mode: int = 0, rels_nodes=None,
+                  recover_stress: bool = True) -> RunResult:
+    """The increment loop of src/main.F90:216-296 on a deck with cohesive elements (the `ncohmats /= 0` branch)."""
+    own = ctx is None
+    ctx = ctx or capi.Context(0)
+    prob = NonlinearProblem(ctx, mesh, options, rels_mode, rels_nodes)
+    res = RunResult(np.zeros(mesh.ndof), np.zeros((mesh.nnds, mesh.cpdim)))
+    res.snes_its, res.snes_reasons, res.fnorms, res.U_hist = [], [], [], []
+    step = 0
+    while True:
+        t_init = mesh.dt * step
+        if t_init >= mesh.t:
+            break
+        ta = time.perf_counter()
+        prob.dmesh.form_rhs(prob.F, t_init, mesh.dt)       # FormRHS :236
+        prob.calc_jacobian(prob.U, prob.J)                 # CalcJacobian(.., Vec_U, Jacobian, Jacobian) :241
+        prob.snes.solve(prob.U)                            # SNESSolve :242 (Vec_U keeps the previous increment)
+        ctx.synchronize()
+        res.t_solve += time.perf_counter() - ta
+        res.snes_its.append(prob.snes.get_iteration_number())          # :243
+        res.snes_reasons.append(prob.snes.get_converged_reason())
+        res.fnorms.append(prob.snes.get_function_norm())
+        res.its.append(prob.snes.get_linear_solve_iterations())
+        u = prob.U.get_array()
+        res.U_hist.append(u)
+        res.aggregate_u += u                               # aggregate_u = aggregate_u + uu :250
+        prob.agg.set_array(res.aggregate_u)
+        if recover_stress:
+            res.aggregate_stress += prob.dmesh.recover_nodal_stress(prob.U)
+        step += 1
+        if res.snes_reasons[-1] < 0:
+            break
+    prob.destroy()
+    if own:
+        ctx.destroy()
+    return res
+
+
 def run(mesh: Mesh, options: str = "", ctx: capi.Context | None = None, recover_stress: bool = True) -> RunResult:
     own = ctx is None
     ctx = ctx or capi.Context(0)

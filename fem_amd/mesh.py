@@ -206,3 +206,25 @@ def quad_to_mixed(m: Mesh) -> Mesh:
                 eltype.append(TRI); conn += list(tri); eptr.append(len(conn)); mat.append(m.mat_id[e])
     return Mesh(pdim=2, eltype=eltype, eptr=eptr, conn=conn, mat_id=mat, coords=m.coords, mats=m.mats,
                 bcnode=m.bcnode, bcval=m.bcval, fnode=m.fnode, fval=m.fval, t=m.t, dt=m.dt)
+
+
+def tile_deck(m: Mesh, copies: int, shift=None) -> Mesh:
+    """`copies` disjoint copies of a deck side by side (BASELINE config 5: examples/cohesive_test_2.inp "scaled x1000"):
+    every copy keeps its own nodes, elements, constraints and loads, shifted by `shift` (default: the deck's extent
+    in x plus one), node and element numbers offset copy by copy."""
+    ext = m.coords.max(axis=0) - m.coords.min(axis=0)
+    sh = np.zeros(m.pdim) if shift is None else np.asarray(shift, dtype=np.float64)
+    if shift is None:
+        sh[0] = ext[0] + 1.0
+    nn = m.nnds
+    coords = np.concatenate([m.coords + c * sh for c in range(copies)])
+    conn = np.concatenate([m.conn + c * nn for c in range(copies)])
+    eptr = np.concatenate([[0]] + [m.eptr[1:] + c * m.eptr[-1] for c in range(copies)])
+    bcnode = np.concatenate([m.bcnode + np.array([c * nn] + [0] * m.pdim) for c in range(copies)]) if len(m.bcnode) else m.bcnode
+    telsd = np.concatenate([m.telsd + np.array([c * m.nels, 0]) for c in range(copies)]) if len(m.telsd) else m.telsd
+    return Mesh(pdim=m.pdim, eltype=np.tile(m.eltype, copies), eptr=eptr, conn=conn, mat_id=np.tile(m.mat_id, copies),
+                coords=coords, mats=m.mats, bcnode=bcnode, bcval=np.tile(m.bcval, (copies, 1)),
+                fnode=np.concatenate([m.fnode + c * nn for c in range(copies)]) if len(m.fnode) else m.fnode,
+                fval=np.tile(m.fval, (copies, 1)), telsd=telsd, tval=np.tile(m.tval, (copies, 1)), t=m.t, dt=m.dt,
+                stype=m.stype, nodal_bw=m.nodal_bw, nlmat=None if m.nlmat is None else np.tile(m.nlmat, copies),
+                cohmats=m.cohmats)

@@ -436,6 +436,134 @@ module fem_amd_capi
       type(c_ptr), value :: mesh, U, S
       integer(c_int) :: ierr
     end function
+    ! ---- cohesive elements + Newton (SNES): src/main.F90:197-206,240-245, src/m_global.F90:98-235 ----
+    function fem_mesh_set_cohesive(mesh, nlmat, ncohmats, props) bind(C, name="fem_mesh_set_cohesive") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mesh
+      integer(c_int), intent(in) :: nlmat(*)
+      integer(c_int), value :: ncohmats
+      real(c_double), intent(in) :: props(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_duplicate(A, B) bind(C, name="fem_mat_duplicate") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: A
+      type(c_ptr), intent(out) :: B
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_copy(src, dst) bind(C, name="fem_mat_copy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: src, dst
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_add_cohesive(J, u_total, dt, rels_mode, rels_nodes) bind(C, name="fem_mat_add_cohesive") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: J, u_total
+      real(c_double), value :: dt
+      integer(c_int), value :: rels_mode
+      integer(c_int), intent(in) :: rels_nodes(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_add_cohesive_traction(mesh, u_total, dt, rels_mode, rels_nodes, R) &
+        bind(C, name="fem_vec_add_cohesive_traction") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mesh, u_total, R
+      real(c_double), value :: dt
+      integer(c_int), value :: rels_mode
+      integer(c_int), intent(in) :: rels_nodes(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_enforce_bc_force(mesh, nbcs, bcnode, bcval, dt, t_total, R) bind(C, name="fem_enforce_bc_force") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mesh, R
+      integer(c_int), value :: nbcs
+      integer(c_int), intent(in) :: bcnode(*)
+      real(c_double), intent(in) :: bcval(*)
+      real(c_double), value :: dt, t_total
+      integer(c_int) :: ierr
+    end function
+    function fem_mat_mult_add(A, x, y, z) bind(C, name="fem_mat_mult_add") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: A, x, y, z
+      integer(c_int) :: ierr
+    end function
+    function fem_vec_scale(v, alpha) bind(C, name="fem_vec_scale") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: v
+      real(c_double), value :: alpha
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_create(ctx, snes) bind(C, name="fem_snes_create") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ctx
+      type(c_ptr), intent(out) :: snes
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_destroy(snes) bind(C, name="fem_snes_destroy") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_get_ksp(snes, ksp) bind(C, name="fem_snes_get_ksp") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes
+      type(c_ptr), intent(out) :: ksp
+      integer(c_int) :: ierr
+    end function
+    ! the callbacks are bind(C) functions of the host: integer(c_int) function f(snes, x, f, ctx) / j(snes, x, J, P, ctx)
+    function fem_snes_set_function(snes, r, f, ctx) bind(C, name="fem_snes_set_function") result(ierr)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: snes, r, ctx
+      type(c_funptr), value :: f
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_set_jacobian(snes, J, P, jf, ctx) bind(C, name="fem_snes_set_jacobian") result(ierr)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: snes, J, P, ctx
+      type(c_funptr), value :: jf
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_set_from_options(snes, options) bind(C, name="fem_snes_set_from_options") result(ierr)
+      import :: c_int, c_ptr, c_char
+      type(c_ptr), value :: snes
+      character(kind=c_char), intent(in) :: options(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_solve(snes, x) bind(C, name="fem_snes_solve") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes, x
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_get_iteration_number(snes, its) bind(C, name="fem_snes_get_iteration_number") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes
+      integer(c_int), intent(out) :: its
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_get_converged_reason(snes, reason) bind(C, name="fem_snes_get_converged_reason") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes
+      integer(c_int), intent(out) :: reason
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_get_function_norm(snes, fnorm) bind(C, name="fem_snes_get_function_norm") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: snes
+      real(c_double), intent(out) :: fnorm
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_get_linear_solve_iterations(snes, lits) bind(C, name="fem_snes_get_linear_solve_iterations") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes
+      integer(c_int), intent(out) :: lits
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_get_number_function_evals(snes, nfuncs) bind(C, name="fem_snes_get_number_function_evals") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: snes
+      integer(c_int), intent(out) :: nfuncs
+      integer(c_int) :: ierr
+    end function
   end interface
 
 contains

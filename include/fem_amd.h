@@ -38,6 +38,7 @@ typedef struct fem_mesh_s *fem_mesh; /* device-resident SoA mesh of one domain  
 typedef struct fem_mat_s *fem_mat;   /* Mat_K       (src/m_global.F90:26)        */
 typedef struct fem_vec_s *fem_vec;   /* Vec_F/Vec_U (src/m_global.F90:24)        */
 typedef struct fem_ksp_s *fem_ksp;   /* Krylov      (src/m_global.F90:27)        */
+typedef struct fem_snes_s *fem_snes; /* Solver      (src/m_global.F90:28)        */
 
 #define FEM_TRI 1
 #define FEM_QUA 2
@@ -54,6 +55,20 @@ typedef struct fem_ksp_s *fem_ksp;   /* Krylov      (src/m_global.F90:27)       
 #define FEM_KSP_DIVERGED_INDEFINITE_PC (-8)
 #define FEM_KSP_DIVERGED_NANORINF (-9)
 #define FEM_KSP_DIVERGED_INDEFINITE_MAT (-10)
+
+#define FEM_KSP_CONVERGED_ITS 4
+#define FEM_KSP_DIVERGED_BREAKDOWN (-5)
+#define FEM_KSP_DIVERGED_PC_FAILED (-11)
+
+/* SNESConvergedReason values (PETSc). */
+#define FEM_SNES_CONVERGED_FNORM_ABS 2
+#define FEM_SNES_CONVERGED_FNORM_RELATIVE 3
+#define FEM_SNES_CONVERGED_SNORM_RELATIVE 4
+#define FEM_SNES_DIVERGED_FUNCTION_COUNT (-2)
+#define FEM_SNES_DIVERGED_LINEAR_SOLVE (-3)
+#define FEM_SNES_DIVERGED_FNORM_NAN (-4)
+#define FEM_SNES_DIVERGED_MAX_IT (-5)
+#define FEM_SNES_DIVERGED_LINE_SEARCH (-6)
 
 /* PETSC_DEFAULT for fem_ksp_set_tolerances arguments. */
 #define FEM_DEFAULT_REAL (-2.0)
@@ -184,17 +199,19 @@ int fem_form_rhs(fem_mesh mesh, int nbcs, const int *bcnode, const double *bcval
 int fem_ksp_create(fem_ctx ctx, fem_ksp *ksp);
 int fem_ksp_destroy(fem_ksp ksp);
 int fem_ksp_set_operators(fem_ksp ksp, fem_mat A);          /* KSPSetOperators :348 */
-/* KSPSetType / PCSetType.  "cg" pairs with "jacobi" | "none" | "mg" ("gamg"); "preonly" pairs with
+/* KSPSetType / PCSetType.  "cg" pairs with "jacobi" | "none" | "mg" ("gamg"); "bcgs" (BiCGStab, for the unsymmetric
+ * Newton Jacobian) with "jacobi" | "none"; "preonly" pairs with
  * "lu" | "cholesky" -- the reference's own production pairing KSPPREONLY + PCLU (MUMPS),
  * src/main.F90:354-358 -- served here by a banded Cholesky factorisation on the device (single
  * domain, decks whose band fits the HBM; its = 1, reason KSP_CONVERGED_ITS = 4, or
- * KSP_DIVERGED_PC_FAILED = -11 when a pivot is not positive). */
+ * KSP_DIVERGED_PC_FAILED = -11 when a pivot is not positive); on a Mat that carries cohesive tangents (not symmetric)
+ * by a band LU with partial pivoting and MUMPS-style null-pivot fixing (src/main.F90:368-371). */
 int fem_ksp_set_type(fem_ksp ksp, const char *type);
 int fem_ksp_set_pc_type(fem_ksp ksp, const char *type);
 /* KSPSetTolerances :350; FEM_DEFAULT_* keeps the PETSc default
  * (rtol 1e-5, abstol 1e-50, dtol 1e5, maxits 10000). */
 int fem_ksp_set_tolerances(fem_ksp ksp, double rtol, double abstol, double dtol, int maxits);
-/* KSPSetFromOptions :377: parses "-ksp_type cg|preonly -pc_type jacobi|none|mg|gamg|lu|cholesky
+/* KSPSetFromOptions :377: parses "-ksp_type cg|bcgs|preonly -pc_type jacobi|none|mg|gamg|lu|cholesky
  * -ksp_rtol 1e-12 -ksp_atol .. -ksp_divtol .. -ksp_max_it .. -pc_mg_type multiplicative|additive
  * -pc_mg_alpha .. -pc_mg_omega .. -pc_mg_box .. -pc_mg_slice_min .. -mat_mult_type assembled|ebe" */
 int fem_ksp_set_from_options(fem_ksp ksp, const char *options);
@@ -210,6 +227,54 @@ int fem_ksp_get_residual_history(fem_ksp ksp, double *hist, int len, int *n);
  * their summed duration, total solve duration. */
 int fem_ksp_set_profiling(fem_ksp ksp, int on);
 int fem_ksp_get_profile(fem_ksp ksp, int *n_spmv, double *spmv_ms, double *solve_ms);
+
+/* ---- cohesive elements and the Newton increment: SURVEY 8 f1, BASELINE config 5 ------------------------------
+ * The reference solves a deck with cohesive elements through SNES (src/main.F90:200-206,240-245) with the two
+ * callbacks CalcJacobian (src/m_global.F90:98-158) and CalcResidual (:161-235).  The callbacks stay host code here
+ * too (fem_amd/driver.py, fortran/): they are written with the device primitives below, one per PETSc call or loop
+ * of the reference's callbacks.
+ *
+ * fem_mesh_set_cohesive: nlmat[nels] = el%nlMat of every element of the list the mesh was created from (0 = linear,
+ * m >= 1 = cohesive with material cohMats(m), src/m_io.F90:94,308-314); props[ncohmats*6] rows sigma_max delta_n
+ * delta_t q r zeta (src/m_seplaw.F90:19-24).  Call it before the first fem_mat_create_aij: the sparsity then holds
+ * the node pairs of the cohesive elements.  Cohesive elements add nothing to Mat_K (the reference sends them through
+ * FormElKE with an unhandled type, i.e. integrates an uninitialised dN: undefined behaviour that is not reproduced)
+ * and are left out of the stress recovery. */
+int fem_mesh_set_cohesive(fem_mesh mesh, const int *nlmat, int ncohmats, const double *props);
+/* MatDuplicate(Mat_K, MAT_COPY_VALUES, Jacobian) src/main.F90:197; MatCopy(Mat_K, Jacobian, SAME_NONZERO_PATTERN)
+ * src/m_global.F90:123 (both matrices from the same mesh). */
+int fem_mat_duplicate(fem_mat A, fem_mat *B);
+int fem_mat_copy(fem_mat src, fem_mat dst);
+/* The element loop of CalcJacobian (src/m_global.F90:127-147): applyStiff_1 for every cohesive element at the total
+ * displacement u_total and 64 MatSetValue(ADD_VALUES) each.  getCohRels reads four fixed local nodes of the rank
+ * instead of the element's (src/m_elems.F90:697-704): rels_mode 0 repeats that with rels_nodes[4] (NULL = the first
+ * four nodes, as on one rank), rels_mode 1 uses the element's own nodes.  ApplyKBC must follow, as in the reference. */
+int fem_mat_add_cohesive(fem_mat J, fem_vec u_total, double dt, int rels_mode, const int *rels_nodes);
+/* The element loop of CalcResidual (:186-205): R(node) += applyTract_1 for every cohesive element. */
+int fem_vec_add_cohesive_traction(fem_mesh mesh, fem_vec u_total, double dt, int rels_mode, const int *rels_nodes, fem_vec R);
+/* EnforceBCForce (src/m_global.F90:439-455) on any vector: INSERT PENALTY*val*dt/t_total on the constrained dofs. */
+int fem_enforce_bc_force(fem_mesh mesh, int nbcs, const int *bcnode, const double *bcval, double dt, double t_total, fem_vec R);
+/* MatMultAdd (src/m_global.F90:224): z = y + A x (z may be y). */
+int fem_mat_mult_add(fem_mat A, fem_vec x, fem_vec y, fem_vec z);
+int fem_vec_scale(fem_vec v, double alpha);              /* VecScale :223 */
+
+/* SNES: Newton with PETSc's default `bt` line search (SNESNEWTONLS), PETSc's defaults and convergence tests. */
+typedef int (*fem_snes_function_cb)(fem_snes snes, fem_vec x, fem_vec f, void *ctx);            /* CalcResidual */
+typedef int (*fem_snes_jacobian_cb)(fem_snes snes, fem_vec x, fem_mat J, fem_mat P, void *ctx); /* CalcJacobian */
+int fem_snes_create(fem_ctx ctx, fem_snes *snes);                                   /* SNESCreate :200 */
+int fem_snes_destroy(fem_snes snes);
+int fem_snes_get_ksp(fem_snes snes, fem_ksp *ksp);                                  /* SNESGetKSP :201 (owned by snes) */
+int fem_snes_set_function(fem_snes snes, fem_vec r, fem_snes_function_cb f, void *ctx);             /* :204 */
+int fem_snes_set_jacobian(fem_snes snes, fem_mat J, fem_mat P, fem_snes_jacobian_cb j, void *ctx);  /* :205 */
+/* SNESSetFromOptions :206: -snes_rtol -snes_atol -snes_stol -snes_max_it -snes_max_funcs -snes_linesearch_type bt|basic
+ * -snes_linesearch_alpha|maxstep|minlambda|max_it; any other option goes to the KSP (KSPSetFromOptions). */
+int fem_snes_set_from_options(fem_snes snes, const char *options);
+int fem_snes_solve(fem_snes snes, fem_vec x);                                       /* SNESSolve :242 (x = initial guess) */
+int fem_snes_get_iteration_number(fem_snes snes, int *its);                         /* :243 */
+int fem_snes_get_converged_reason(fem_snes snes, int *reason);
+int fem_snes_get_function_norm(fem_snes snes, double *fnorm);
+int fem_snes_get_linear_solve_iterations(fem_snes snes, int *lits);
+int fem_snes_get_number_function_evals(fem_snes snes, int *nfuncs);
 
 /* Reverse Cuthill-McKee numbering used by the direct solve (host only): CSR adjacency of an
  * undirected graph with n nodes -> perm[old] = new. */

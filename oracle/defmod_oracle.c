@@ -779,8 +779,9 @@ void dm_recover_nodal_stress(const dm_problem *p, const double *uu, double *stre
             for (c = 0; c < cp; c++) stress_node[(size_t)nd[a] + (size_t)c * nn] += sn[a + c * n];
         }
     }
-    for (a = 0; a < nn; a++)
-        for (c = 0; c < cp; c++) stress_node[(size_t)a + (size_t)c * nn] /= (double)cnt[a];
+    for (a = 0; a < nn; a++)   /* a node that only cohesive elements touch has no solid contribution: its stress stays 0 */
+        for (c = 0; c < cp; c++)
+            if (cnt[a]) stress_node[(size_t)a + (size_t)c * nn] /= (double)cnt[a];
     if (!count_node) free(cnt);
 }
 

@@ -267,6 +267,44 @@ class Oracle:
             raise RuntimeError(f"oracle solve failed: {nsteps}")
         return u, s.reshape(p.nnds, cp, order="F"), its[:nsteps]
 
+    # ---- nonlinear increment around the cohesive element (oracle/snes_oracle.c) ----
+    class Cohesive(C.Structure):
+        _fields_ = [("nlmat", _ip), ("ncohmats", C.c_int), ("props", _dp), ("rels_mode", C.c_int),
+                    ("rels_nodes", C.c_int * 4), ("bc_legacy", C.c_int)]
+
+    def _cohesive(self, m, rels_mode=0, rels_nodes=(0, 1, 2, 3), bc_legacy=False):
+        nlmat = np.ascontiguousarray(m.nlmat if m.nlmat is not None else np.zeros(m.nels), dtype=np.int32)
+        props = np.ascontiguousarray([pr for _, pr in m.cohmats], dtype=np.float64).reshape(-1, 6)
+        c = self.Cohesive(_i(nlmat), props.shape[0], _d(props), int(rels_mode), (C.c_int * 4)(*[int(v) for v in rels_nodes]),
+                          int(bool(bc_legacy)))
+        return c, [nlmat, props]
+
+    def snes_run(self, m, rels_mode=0, rels_nodes=(0, 1, 2, 3), bc_legacy=False, inner="lu", ksp_rtol=1e-12, ksp_abstol=1e-50,
+                 maxsteps=1000):
+        """main.F90:216-296 on a deck with cohesive elements.  Returns dict(u, stress, U_hist, its, reasons, fnorms)."""
+        p, keep = make_problem(m)
+        c, keep2 = self._cohesive(m, rels_mode, rels_nodes, bc_legacy)
+        N = p.nnds * p.pdim
+        nst = min(int(m.nsteps), maxsteps)
+        u = np.zeros(N); s = np.zeros(p.nnds * 3); hist = np.zeros((nst, N))
+        its = np.zeros(nst, dtype=np.int32); reasons = np.zeros(nst, dtype=np.int32); fn = np.zeros(nst)
+        self.L.dm_snes_run.restype = C.c_int
+        n = self.L.dm_snes_run(C.byref(p), C.byref(c), 0 if inner == "lu" else 1, C.c_double(ksp_rtol), C.c_double(ksp_abstol), _d(u), _d(s),
+                               _d(hist),
+                               _i(its), _i(reasons), _d(fn), nst)
+        if n < 0:
+            raise RuntimeError(f"dm_snes_run failed: {n}")
+        return {"u": u, "stress": s.reshape(p.nnds, 3, order="F"), "U_hist": hist[:n], "its": its[:n], "reasons": reasons[:n],
+                "fnorms": fn[:n]}
+
+    def snes_callbacks(self, m, rowptr, colind, Kbc, F, aggregate_u, du, rels_mode=0, rels_nodes=(0, 1, 2, 3), bc_legacy=False):
+        p, keep = make_problem(m)
+        c, keep2 = self._cohesive(m, rels_mode, rels_nodes, bc_legacy)
+        J = np.zeros(len(colind)); R = np.zeros(p.nnds * p.pdim)
+        a = [np.ascontiguousarray(x, dtype=np.float64) for x in (Kbc, F, aggregate_u, du)]
+        self.L.dm_snes_callbacks(C.byref(p), C.byref(c), _i(rowptr), _i(colind), _d(a[0]), _d(a[1]), _d(a[2]), _d(a[3]), _d(J), _d(R))
+        return J, R
+
     # ---- bench.py's cpu_baseline leg (oracle/cpu_baseline.c) ----
     def cpu_baseline(self, m, nthreads, ncg, rtol=DEFAULT_RTOL, nprod=0, want_arrays=False):
         """Timed all-core run of the path; returns a dict of timings (and the matrix / iterate when asked)."""

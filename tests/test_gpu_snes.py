@@ -1,0 +1,105 @@
+"""GPU: the Newton increment around the cohesive element (BASELINE config 5): the device primitives of
+the two SNES callbacks against the oracle's CalcJacobian / CalcResidual, the Newton line-search solver against the
+oracle's restatement of SNESNEWTONLS, on examples/cohesive_test_2.inp and on its tiling."""
+import os
+
+import numpy as np
+import pytest
+
+from fem_amd import capi, driver
+from fem_amd.inp import read_inp
+from fem_amd.mesh import tile_deck
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+DECK = os.path.join(HERE, "golden", "decks", "cohesive_test_2.inp")
+LEGACY = os.path.join(HERE, "golden", "decks", "cohesive_test_legacy.inp")
+
+
+@pytest.mark.parametrize("rels", [(0, None), (0, (1, 2, 4, 5)), (1, None)])
+def test_callbacks_match_oracle(gpu_ctx, oracle, rels):
+    """CalcJacobian (MatCopy + applyStiff_1 + 64 MatSetValue(ADD) + ApplyKBC) and CalcResidual (VecCopy + applyTract_1 +
+    EnforceBCForce + VecScale + MatMultAdd) on a non-trivial state, both readings of getCohRels' node list."""
+    mode, nodes = rels
+    m = read_inp(DECK)
+    prob = driver.NonlinearProblem(gpu_ctx, m, "", rels_mode=mode, rels_nodes=nodes)
+    rng = np.random.default_rng(4)
+    agg = 1e-3 * rng.standard_normal(m.ndof)
+    du = 1e-3 * rng.standard_normal(m.ndof)
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.agg.set_array(agg)
+    X = capi.Vec(gpu_ctx, m.ndof); X.set_array(du)
+    prob.calc_jacobian(X, prob.J)
+    prob.calc_residual(X, prob.R)
+    rp, ci = oracle.csr_pattern(m)
+    Kbc = oracle.assemble(m, rp, ci, apply_bc=True)
+    F = oracle.form_rhs(m, 0.0, m.dt)
+    Jr, Rr = oracle.snes_callbacks(m, rp, ci, Kbc, F, agg, du, rels_mode=mode, rels_nodes=nodes or (0, 1, 2, 3))
+    grp, gci, gv = prob.J.get_csr()
+    assert np.array_equal(grp, rp) and np.array_equal(gci, ci)      # sparsity incl. the cohesive node pairs
+    pen = Jr > 1e29
+    assert np.array_equal(gv[pen], Jr[pen])
+    assert np.abs(gv[~pen] - Jr[~pen]).max() <= 1e-13 * np.abs(Jr[~pen]).max()
+    R = prob.R.get_array()
+    big = np.abs(Rr) > 1e20                                          # penalty rows: 1e30 * (du - prescribed)
+    assert np.abs(R[big] - Rr[big]).max() <= 1e-13 * np.abs(Rr[big]).max()
+    assert np.abs(R[~big] - Rr[~big]).max() <= 1e-12 * np.abs(Rr[~big]).max()
+    X.destroy(); prob.destroy()
+
+
+def test_first_increment_reproduces_the_reference_log(gpu_ctx):
+    """examples/SNES_test/cohesive_test/tmp:20-37 through the HIP path (see tests/test_oracle_golden.py for the deck):
+    the old revision scaled the penalty force by dt, i.e. the prescribed values of this deck are t = 0.05 times the
+    log's -- Vec_U of the first increment scales with them."""
+    m = read_inp(LEGACY)
+    res = driver.run_nonlinear(m, "", ctx=gpu_ctx, rels_mode=0, rels_nodes=(1, 2, 4, 5), recover_stress=False)
+    log = np.array([2.59576e-32, 5e-05, 2.59576e-32, 2.52785e-05, -2.59576e-32, -6.05676e-32, -2.59576e-32, 5e-05,
+                    -2.59576e-32, 2.52785e-05, 2.59576e-32, -6.05676e-32, -2.59576e-32, -2.47215e-05, 2.59576e-32, -2.47215e-05])
+    u1 = res.U_hist[0] * m.t          # dt/t -> dt
+    big = np.abs(log) > 1e-10
+    assert res.snes_its[0] == 1 and res.snes_reasons[0] == 3
+    assert np.abs(u1[big] / log[big] - 1.0).max() < 5e-6
+
+
+@pytest.mark.parametrize("inner,tol", [("-ksp_type preonly -pc_type lu", 1e-9),
+                                       ("-ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-12 -ksp_atol 1e-16", 1e-5)])
+def test_newton_on_the_reference_deck_matches_oracle(gpu_ctx, oracle, inner, tol):
+    """Both inner solvers against the oracle's loop with its dense LU (the MUMPS stand-in).  With BiCGStab the first
+    increment agrees to the linear tolerance; the second starts from a state that already solves it, and what the
+    iterative solve then does with a right-hand side made of 1e30-weighted round-off is not comparable digit by digit."""
+    m = read_inp(DECK)
+    res = driver.run_nonlinear(m, inner, ctx=gpu_ctx)
+    ref = oracle.snes_run(m, inner="lu")
+    assert len(res.snes_its) == len(ref["its"]) == 2
+    assert res.snes_reasons[0] == ref["reasons"][0] == 3 and res.snes_its[0] == ref["its"][0]
+    assert min(res.snes_reasons) > 0
+    assert np.abs(res.U_hist[0] - ref["U_hist"][0]).max() <= 1e-9 * np.abs(ref["U_hist"][0]).max()
+    assert np.abs(res.aggregate_u - ref["u"]).max() <= tol * np.abs(ref["u"]).max()
+    assert np.abs(res.aggregate_stress - ref["stress"]).max() <= 10 * tol * np.abs(ref["stress"]).max()
+
+
+def test_newton_with_the_elements_own_nodes(gpu_ctx, oracle):
+    """rels_mode 1 (the element's own nodes in getCohRels): a deck on which the increments differ from each other."""
+    m = read_inp(LEGACY)
+    res = driver.run_nonlinear(m, "", ctx=gpu_ctx, rels_mode=1)
+    ref = oracle.snes_run(m, rels_mode=1)
+    n = len(ref["its"])
+    assert list(res.snes_its[:n]) == list(ref["its"]) and list(res.snes_reasons[:n]) == list(ref["reasons"])
+    assert np.abs(res.aggregate_u - ref["u"]).max() <= 1e-8 * np.abs(ref["u"]).max()
+
+
+def test_config5_tiling(gpu_ctx, oracle):
+    """Config 5: cohesive_test_2.inp x1000 (disjoint copies, 16,000 dofs).  Every copy must reproduce the single deck
+    when getCohRels reads the element's own nodes; as written (the first four nodes of the rank) the copies see copy 0's
+    displacements, which the oracle restates too (compared on 40 copies, where its dense LU is still cheap)."""
+    m1 = read_inp(DECK)
+    one = driver.run_nonlinear(m1, "", ctx=gpu_ctx, rels_mode=1, recover_stress=False)
+    big = driver.run_nonlinear(tile_deck(m1, 1000), "", ctx=gpu_ctx, rels_mode=1, recover_stress=False)
+    assert min(big.snes_reasons) > 0 and list(big.snes_its) == list(one.snes_its)
+    U = big.aggregate_u.reshape(1000, -1)
+    assert np.abs(U - one.aggregate_u[None]).max() <= 1e-10 * np.abs(one.aggregate_u).max()
+    m40 = tile_deck(m1, 40)
+    a = driver.run_nonlinear(m40, "", ctx=gpu_ctx, rels_mode=0, recover_stress=False)
+    b = oracle.snes_run(m40, rels_mode=0)
+    assert list(a.snes_its) == list(b["its"]) and min(a.snes_reasons) > 0
+    assert np.abs(a.aggregate_u - b["u"]).max() <= 1e-9 * np.abs(b["u"]).max()

@@ -240,3 +240,34 @@ def test_cpu_baseline_leg_computes_what_the_oracle_computes(oracle):
         y = oracle.cpu_ebe_mult(m, xx, nthreads=3)
         yr = oracle.spmv(rp, ci, v0, xx)
         assert np.abs(y - yr).max() <= 1e-12 * np.abs(yr).max()
+
+
+def test_newton_cohesive_first_increment_reproduces_the_reference_log(oracle):
+    """examples/SNES_test/cohesive_test/tmp:20-37 -- the reference's own two-rank run of the cohesive deck (re-typed for
+    the current reader as tests/golden/decks/cohesive_test_legacy.inp; that older revision scaled the penalty force by
+    dt, `bc_legacy`; rank 0 held global nodes 2,3,5,6,7,8, so getCohRels read nodes 2,3,5,6: 0_output_000000.vtk).
+    Increment 1: SNES iteration count 1 and Vec_U to the six printed digits, the 1e-32 round-off entries included."""
+    m = read_inp(os.path.join(HERE, "golden", "decks", "cohesive_test_legacy.inp"))
+    r = oracle.snes_run(m, rels_mode=0, rels_nodes=(1, 2, 4, 5), bc_legacy=True, maxsteps=1)
+    log = np.array([2.59576e-32, 5e-05, 2.59576e-32, 2.52785e-05, -2.59576e-32, -6.05676e-32, -2.59576e-32, 5e-05,
+                    -2.59576e-32, 2.52785e-05, 2.59576e-32, -6.05676e-32, -2.59576e-32, -2.47215e-05, 2.59576e-32, -2.47215e-05])
+    assert r["its"][0] == 1 and r["reasons"][0] == 3          # SNES_CONVERGED_FNORM_RELATIVE after one iteration
+    assert np.abs(r["U_hist"][0] - log).max() <= 6e-6 * np.abs(log).max()
+    big = np.abs(log) > 1e-10
+    assert np.abs(r["U_hist"][0][big] / log[big] - 1.0).max() < 5e-6
+    small = ~big                                                # the round-off entries: same sign, same six digits
+    assert np.abs(r["U_hist"][0][small] / log[small] - 1.0).max() < 5e-6
+
+
+def test_newton_cohesive_current_deck_runs_and_inner_solvers_agree(oracle):
+    """examples/cohesive_test_2.inp (config 5's deck) through the restated SNES loop: both inner solvers (dense LU
+    stand-in for MUMPS, BiCGStab + Jacobi as in the HIP library) give the same increments."""
+    m = read_inp(os.path.join(HERE, "golden", "decks", "cohesive_test_2.inp"))
+    a = oracle.snes_run(m, inner="lu")
+    b = oracle.snes_run(m, inner="bcgs", ksp_rtol=1e-12, ksp_abstol=1e-16)
+    assert len(a["its"]) == 2 and (a["reasons"] > 0).all() and (b["reasons"] > 0).all()
+    assert a["its"][0] == b["its"][0] == 1
+    assert np.abs(a["U_hist"][0] - b["U_hist"][0]).max() <= 1e-9 * np.abs(a["U_hist"][0]).max()
+    # the second increment starts from a state that solves it: the direct solve confirms it (an empty Newton step), the
+    # iterative one, whose first increment carries its own 1e-12 of error into 1e30-weighted rows, moves a little
+    assert np.abs(a["u"] - b["u"]).max() <= 1e-5 * np.abs(a["u"]).max()

@@ -48,6 +48,11 @@ _SIGS = {
     "fem_form_el_ke": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp],
     "fem_calc_el_stress": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp, _dp],
     "fem_form_el_indx": [C.c_int, C.c_int, _ip, _ip],
+    "fem_shape_func": [C.c_int, C.c_int, _dp],
+    "fem_shape_funcd": [_h, C.c_int, C.c_int, _dp, _dp],
+    "fem_form_dn_detj": [_h, C.c_int, C.c_int, _dp, _dp, _dp, _dp],
+    "fem_bmat": [_h, C.c_int, C.c_int, C.c_int, _dp, _dp],
+    "fem_dmat": [_h, C.c_int, C.c_int, _dp, _dp, _dp],
     "fem_coh_apply_1": [_h, C.c_int, _dp, _dp, _dp, C.c_double, _dp, _dp, _dp],
     "fem_rcm_order": [C.c_int, _ip, _ip, _ip],
     "fem_mesh_create": [_h, C.c_int, C.c_int, C.c_int, _ip, _ip, _ip, _ip, _dp, C.c_int, _dp, C.POINTER(_h)],

@@ -53,6 +53,10 @@ void comm_get_unique_id_impl(char*);
 fem_comm comm_create_rccl_impl(fem_ctx, int, int, const char*);
 void comm_create_local_group_impl(int, const fem_ctx*, fem_comm*);
 
+void shape_funcd_impl(fem_ctx, int, int, const double*, double*);
+void form_dn_detj_impl(fem_ctx, int, int, const double*, const double*, double*, double*);
+void bmat_impl(fem_ctx, int, int, int, const double*, double*);
+void dmat_impl(fem_ctx, int, int, const double*, const double*, double*);
 void mesh_set_cohesive_impl(fem_mesh, const int*, int, const double*);
 void mat_add_cohesive_impl(fem_mat, const double*, double, int, const int*);
 void vec_add_cohesive_traction_impl(fem_mesh, const double*, double, int, const int*, double*);
@@ -218,6 +222,48 @@ int fem_form_el_indx(int pdim, int n, const int* enodes, int* indx)
     FEM_CHECK(pdim == 2 || pdim == 3, 2, "fem_form_el_indx: pdim must be 2 or 3");
     for (int j = 0; j < n; j++)
         for (int d = 0; d < pdim; d++) indx[pdim * j + d] = pdim * enodes[j] + d;
+    FEM_CATCH
+}
+
+int fem_shape_func(int t, int gp, double* N)
+{
+    FEM_TRY
+    FEM_CHECK(t >= FEM_TRI && t <= FEM_COH, 3, "fem_shape_func: unknown element type");
+    const ElemTable& tb = host_elem_tables()[t];
+    FEM_CHECK(gp >= 0 && gp < tb.nip && N, 2, "fem_shape_func: integration point out of range");
+    for (int a = 0; a < tb.npe; a++) N[a] = tb.N[gp][a];
+    FEM_CATCH
+}
+
+int fem_shape_funcd(fem_ctx ctx, int t, int npts, const double* coord, double* dN)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    shape_funcd_impl(ctx, t, npts, coord, dN);
+    FEM_CATCH
+}
+
+int fem_form_dn_detj(fem_ctx ctx, int t, int nel, const double* ipcoord, const double* ecoords, double* dN, double* detj)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    form_dn_detj_impl(ctx, t, nel, ipcoord, ecoords, dN, detj);
+    FEM_CATCH
+}
+
+int fem_bmat(fem_ctx ctx, int pdim, int nodecount, int nel, const double* dN, double* B)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    bmat_impl(ctx, pdim, nodecount, nel, dN, B);
+    FEM_CATCH
+}
+
+int fem_dmat(fem_ctx ctx, int pdim, int nmat, const double* E, const double* nu, double* D)
+{
+    FEM_TRY
+    FEM_CHECK(ctx, 1, "null context");
+    dmat_impl(ctx, pdim, nmat, E, nu, D);
     FEM_CATCH
 }
 

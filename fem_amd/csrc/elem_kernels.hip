@@ -1062,6 +1062,136 @@ void mat_get_profile_impl(fem_mat A, int max_products, int* n, double* element_m
     if (penalty_ms) *penalty_ms = t[2];
 }
 
+// ---- the small routines of module `local` / `elems`, batched (element-level API) -----------------
+// ShapeFuncd (src/m_elems.F90:177-185): dN(pdim,n) column-major at npts arbitrary points
+__global__ void __launch_bounds__(128) k_shape_funcd(int type, int npts, int pd, int n, const double* __restrict__ coord,
+                                                     double* __restrict__ dN)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npts) return;
+    double x[3] = {0, 0, 0}, d[3][8];
+    for (int i = 0; i < pd; i++) x[i] = coord[(size_t)p * pd + i];
+    elem_shape_d(type, x, d);
+    for (int a = 0; a < n; a++)
+        for (int i = 0; i < pd; i++) dN[(size_t)p * pd * n + i + (size_t)a * pd] = d[i][a];
+}
+// FormdNdetJ (src/m_local.F90:175-189): every element at its own point; dN(pdim,n) column-major, signed detj
+template <int PD, int NPE>
+__global__ void __launch_bounds__(128) k_form_dn_detj(int type, int nel, const double* __restrict__ ipcoord,
+                                                      const double* __restrict__ ecoords, double* __restrict__ dN,
+                                                      double* __restrict__ detj)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    double x[3] = {0, 0, 0}, d[3][8], X[NPE][PD], g[NPE][PD], dj;
+    for (int i = 0; i < PD; i++) x[i] = ipcoord[(size_t)e * PD + i];
+    elem_shape_d(type, x, d);
+    DenseSrc<PD, NPE>{ecoords}.coordsOf((size_t)e, X);
+    dndx_at_gp<PD, NPE>(d, X, g, dj);
+    for (int a = 0; a < NPE; a++)
+        for (int i = 0; i < PD; i++) dN[(size_t)e * PD * NPE + i + (size_t)a * PD] = g[a][i];
+    detj[e] = dj;
+}
+// BMat (src/m_local.F90:148-171): B(cpdim, n*pdim) column-major from dN(pdim, n)
+__global__ void __launch_bounds__(128) k_bmat(int nel, int pd, int n, const double* __restrict__ dN, double* __restrict__ B)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nel) return;
+    const int cp = (pd == 2) ? 3 : 6;
+    const double* d = dN + (size_t)e * pd * n;
+    double* b = B + (size_t)e * cp * n * pd;
+    for (int k = 0; k < cp * n * pd; k++) b[k] = 0.0;
+    for (int j = 0; j < n; j++) {
+        const double dx = d[0 + j * pd], dy = d[1 + j * pd];
+        if (pd == 2) {
+            b[0 + (2 * j) * cp] = dx; b[1 + (2 * j + 1) * cp] = dy;
+            b[2 + (2 * j) * cp] = dy; b[2 + (2 * j + 1) * cp] = dx;
+        } else {
+            const double dz = d[2 + j * pd];
+            b[0 + (3 * j) * cp] = dx; b[1 + (3 * j + 1) * cp] = dy; b[2 + (3 * j + 2) * cp] = dz;
+            b[3 + (3 * j) * cp] = dy; b[3 + (3 * j + 1) * cp] = dx;
+            b[4 + (3 * j + 1) * cp] = dz; b[4 + (3 * j + 2) * cp] = dy;
+            b[5 + (3 * j) * cp] = dz; b[5 + (3 * j + 2) * cp] = dx;
+        }
+    }
+}
+// DMat / DMat2d / DMat3d (src/m_local.F90:204-228)
+__global__ void __launch_bounds__(128) k_dmat(int nmat, int pd, const double* __restrict__ E, const double* __restrict__ nu,
+                                              double* __restrict__ D)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nmat) return;
+    const int cp = (pd == 2) ? 3 : 6, nn = (pd == 2) ? 2 : 3;
+    const DCoef c = dmat_coef(E[m], nu[m]);
+    double* d = D + (size_t)m * cp * cp;
+    for (int k = 0; k < cp * cp; k++) d[k] = 0.0;
+    for (int i = 0; i < nn; i++)
+        for (int j = 0; j < nn; j++) d[i + j * cp] = (i == j) ? c.d11 : c.d12;
+    for (int i = nn; i < cp; i++) d[i + i * cp] = c.d44;
+}
+
+void shape_funcd_impl(fem_ctx ctx, int type, int npts, const double* coord, double* dN)
+{
+    if (npts <= 0) return;
+    FEM_CHECK(type >= FEM_TRI && type <= FEM_COH, 3, "fem_shape_funcd: unknown element type");
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int pd = type_dim(type), n = type_npe(type);
+    DBuf<double> dC((size_t)npts * pd), dD((size_t)npts * pd * n);
+    dC.upload(coord, dC.n, s);
+    hipLaunchKernelGGL(k_shape_funcd, dim3(cdiv(npts, 128)), dim3(128), 0, s, type, npts, pd, n, dC.p, dD.p);
+    FEM_HIP(hipGetLastError());
+    dD.download(dN, dD.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
+void form_dn_detj_impl(fem_ctx ctx, int type, int nel, const double* ipcoord, const double* ecoords, double* dN, double* detj)
+{
+    if (nel <= 0) return;
+    FEM_CHECK(type >= FEM_TRI && type <= FEM_HEX, 3, "fem_form_dn_detj: unsupported element type");
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int pd = type_dim(type), n = type_npe(type);
+    DBuf<double> dP((size_t)nel * pd), dX((size_t)nel * n * pd), dD((size_t)nel * pd * n), dJ((size_t)nel);
+    dP.upload(ipcoord, dP.n, s); dX.upload(ecoords, dX.n, s);
+    dispatch_type(type, [&](auto PD, auto NPE, auto, auto) {
+        hipLaunchKernelGGL((k_form_dn_detj<PD(), NPE()>), dim3(cdiv(nel, 128)), dim3(128), 0, s, type, nel, dP.p, dX.p, dD.p, dJ.p);
+    });
+    FEM_HIP(hipGetLastError());
+    dD.download(dN, dD.n, s); dJ.download(detj, dJ.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
+void bmat_impl(fem_ctx ctx, int pd, int n, int nel, const double* dN, double* B)
+{
+    if (nel <= 0) return;
+    FEM_CHECK((pd == 2 || pd == 3) && n >= 1 && n <= 8, 2, "fem_bmat: bad pdim / nodecount");
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int cp = (pd == 2) ? 3 : 6;
+    DBuf<double> dD((size_t)nel * pd * n), dB((size_t)nel * cp * n * pd);
+    dD.upload(dN, dD.n, s);
+    hipLaunchKernelGGL(k_bmat, dim3(cdiv(nel, 128)), dim3(128), 0, s, nel, pd, n, dD.p, dB.p);
+    FEM_HIP(hipGetLastError());
+    dB.download(B, dB.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
+void dmat_impl(fem_ctx ctx, int pd, int nmat, const double* E, const double* nu, double* D)
+{
+    if (nmat <= 0) return;
+    FEM_CHECK(pd == 2 || pd == 3, 2, "fem_dmat: pdim must be 2 or 3");
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int cp = (pd == 2) ? 3 : 6;
+    DBuf<double> dE((size_t)nmat), dn((size_t)nmat), dD((size_t)nmat * cp * cp);
+    dE.upload(E, nmat, s); dn.upload(nu, nmat, s);
+    hipLaunchKernelGGL(k_dmat, dim3(cdiv(nmat, 128)), dim3(128), 0, s, nmat, pd, dE.p, dn.p, dD.p);
+    FEM_HIP(hipGetLastError());
+    dD.download(D, dD.n, s);
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
 // FormElKE for a batch of elements given by their coordinates (host in/out)
 void form_el_ke_impl(fem_ctx ctx, int type, int nel, const double* ecoords, const double* E, const double* nu, double* k)
 {

@@ -57,43 +57,7 @@ static void shape(int t, const double* x, double* N)
     }
 }
 
-static void shape_d(int t, const double* x, double (&d)[3][8])
-{
-    const double e = x[0], n = x[1], s = x[2];
-    std::memset(d, 0, sizeof(d));
-    switch (t) {
-    case FEM_TRI:
-        d[0][0] = -1; d[0][1] = 1; d[0][2] = 0;
-        d[1][0] = -1; d[1][1] = 0; d[1][2] = 1;
-        break;
-    case FEM_QUA: {
-        const double de[4] = {-(1.0 - n), (1.0 - n), (1.0 + n), -(1.0 + n)};
-        const double dn[4] = {-(1.0 - e), -(1.0 + e), (1.0 + e), (1.0 - e)};
-        for (int a = 0; a < 4; a++) { d[0][a] = 0.25 * de[a]; d[1][a] = 0.25 * dn[a]; }
-        break;
-    }
-    case FEM_TET:
-        d[0][0] = -1; d[0][1] = 1;
-        d[1][0] = -1; d[1][2] = 1;
-        d[2][0] = -1; d[2][3] = 1;
-        break;
-    case FEM_HEX: {
-        const double sg[8][3] = {{-1, -1, -1}, {1, -1, -1}, {1, 1, -1}, {-1, 1, -1},
-                                 {-1, -1, 1},  {1, -1, 1},  {1, 1, 1},  {-1, 1, 1}};
-        for (int a = 0; a < 8; a++) {
-            const double fe = 1.0 + sg[a][0] * e, fn = 1.0 + sg[a][1] * n, fs = 1.0 + sg[a][2] * s;
-            d[0][a] = 0.125 * (sg[a][0] * fn * fs);
-            d[1][a] = 0.125 * (sg[a][1] * fe * fs);
-            d[2][a] = 0.125 * (sg[a][2] * fe * fn);
-        }
-        break;
-    }
-    case FEM_COH: /* ShapeFuncdCoh, src/m_elems.F90:651-656 */
-        d[0][0] = -0.5; d[0][1] = 0.5; d[0][2] = 0.5; d[0][3] = -0.5;
-        for (int a = 0; a < 4; a++) d[1][a] = d[0][a];
-        break;
-    }
-}
+static void shape_d(int t, const double* x, double (&d)[3][8]) { elem_shape_d(t, x, d); }
 
 int build_elem_table(int type, ElemTable* t)
 {

@@ -436,6 +436,44 @@ module fem_amd_capi
       type(c_ptr), value :: mesh, U, S
       integer(c_int) :: ierr
     end function
+    function fem_shape_func(eltype, gp, N) bind(C, name="fem_shape_func") result(ierr)
+      import :: c_int, c_double
+      integer(c_int), value :: eltype, gp
+      real(c_double), intent(out) :: N(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_shape_funcd(ctx, eltype, npts, coord, dN) bind(C, name="fem_shape_funcd") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: eltype, npts
+      real(c_double), intent(in) :: coord(*)
+      real(c_double), intent(out) :: dN(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_form_dn_detj(ctx, eltype, nel, ipcoord, ecoords, dN, detj) bind(C, name="fem_form_dn_detj") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: eltype, nel
+      real(c_double), intent(in) :: ipcoord(*), ecoords(*)
+      real(c_double), intent(out) :: dN(*), detj(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_bmat(ctx, pdim, nodecount, nel, dN, B) bind(C, name="fem_bmat") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: pdim, nodecount, nel
+      real(c_double), intent(in) :: dN(*)
+      real(c_double), intent(out) :: B(*)
+      integer(c_int) :: ierr
+    end function
+    function fem_dmat(ctx, pdim, nmat, E, nu, D) bind(C, name="fem_dmat") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: ctx
+      integer(c_int), value :: pdim, nmat
+      real(c_double), intent(in) :: E(*), nu(*)
+      real(c_double), intent(out) :: D(*)
+      integer(c_int) :: ierr
+    end function
     ! ---- cohesive elements + Newton (SNES): src/main.F90:197-206,240-245, src/m_global.F90:98-235 ----
     function fem_mesh_set_cohesive(mesh, nlmat, ncohmats, props) bind(C, name="fem_mesh_set_cohesive") result(ierr)
       import :: c_int, c_ptr, c_double

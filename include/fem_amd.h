@@ -107,6 +107,19 @@ int fem_calc_el_stress(fem_ctx ctx, int eltype, int nel, const double *ecoords, 
                        const double *nu, double *estress);
 /* FormElIndx :70-78 (0-based). */
 int fem_form_el_indx(int pdim, int n, const int *enodes, int *indx);
+/* ShapeFunc src/m_elems.F90:136-141: N(1:nodecount) at integration point gp (0-based) of the type's rule. */
+int fem_shape_func(int eltype, int gp, double *N);
+/* ShapeFuncd src/m_elems.F90:177-185 at npts points: coord[npts][pdim] -> dN[npts][pdim*n], each dN(pdim,n)
+ * column-major (derivatives with respect to the reference coordinates). */
+int fem_shape_funcd(fem_ctx ctx, int eltype, int npts, const double *coord, double *dN);
+/* FormdNdetJ src/m_local.F90:175-189 for nel elements, each at its own point: ipcoord[nel][pdim],
+ * ecoords[nel][n*pdim] (column-major (n,pdim)) -> dN[nel][pdim*n] (dN/dx, column-major (pdim,n)), detj[nel]
+ * (signed, MatDet src/m_utils.F90:60-66; J^-1 in closed form where the reference calls LAPACK). */
+int fem_form_dn_detj(fem_ctx ctx, int eltype, int nel, const double *ipcoord, const double *ecoords, double *dN, double *detj);
+/* BMat src/m_local.F90:148-171: dN[nel][pdim*n] -> B[nel][cpdim*(n*pdim)], each B(cpdim, n*pdim) column-major. */
+int fem_bmat(fem_ctx ctx, int pdim, int nodecount, int nel, const double *dN, double *B);
+/* DMat src/m_local.F90:204-228: D[nmat][cpdim*cpdim] (plane strain in 2-D). */
+int fem_dmat(fem_ctx ctx, int pdim, int nmat, const double *E, const double *nu, double *D);
 
 /* ---- cohesive element, element level ----------------------------------------------
  * Batched getCohValues / getCohRels / getCohGaps (src/m_elems.F90:658-720), Seplaw_1_Tract / Seplaw_1_Stiff

@@ -147,6 +147,14 @@ class Oracle:
         self.L.dm_form_dn_detj(t, _d(x), _d(ec), _d(dN), C.byref(dj))
         return dN.reshape(dim, n, order="F"), dj.value
 
+    def bmat(self, pdim, n, dN):
+        """BMat: dN(pdim, n) -> B(cpdim, n*pdim)."""
+        cp = 3 if pdim == 2 else 6
+        d = np.asfortranarray(np.asarray(dN, dtype=np.float64).reshape(pdim, n))
+        B = np.zeros((cp, n * pdim), order="F")
+        self.L.dm_bmat(int(pdim), int(n), d.ctypes.data_as(_dp), B.ctypes.data_as(_dp))
+        return np.array(B)
+
     def dmat(self, pdim, E, nu):
         cp = 3 if pdim == 2 else 6
         D = np.zeros(cp * cp)

@@ -18,16 +18,50 @@ def _need(path):
         pytest.skip(f"{path} not built (no flang at build time)")
 
 
-def test_fortran_element_api_known_answers():
+def test_fortran_element_api_matches_reference_goldens(oracle):
+    """The element-level Fortran API with the reference's own names and signatures (Initialize(ipoints, weights),
+    FormElKE, CalcElStress, FormdNdetJ, BMat, DMat, ShapeFunc, ShapeFuncd, FormElIndx, get*) over the 28 golden cases
+    the reference's compiled modules produced (tests/golden/element_golden.json): 1e-13 of the largest entry."""
+    import json
     _need(TEL)
-    p = subprocess.run([TEL], capture_output=True, text=True, timeout=120)
-    assert p.returncode == 0, p.stdout + p.stderr
-    lines = {ln.split()[0]: [float(x) for x in ln.split()[1:]] for ln in p.stdout.splitlines() if ln.strip()}
-    assert np.allclose(lines["KQ1"], [2100, 875, -1400, 175, -1050, -875, 350, -175], atol=1e-3)   # examples/tmp.txt:23
-    assert lines["INDX"] == [7, 8, 17, 18, 3, 4, 13, 14]                                          # FormElIndx, 1-based
-    assert np.allclose(lines["SQ1"], [105.0, 245.0, 0.0], atol=1e-6)                              # elastic golden stress
-    assert lines["CNT"] == [8, 8, 3, 4, 12]
-    assert np.allclose(lines["KH1"], [855.5556, 291.6667, 291.6667, -388.8889, 58.3333, 58.3333], atol=1e-3)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "element_golden.json")))["types"]
+    p = subprocess.run([TEL, os.path.join(ROOT, "tests", "golden", "element_cases.txt")], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    cases, cur = [], None
+    for ln in p.stdout.splitlines():
+        t = ln.split()
+        if not t:
+            continue
+        if t[0] == "CASE":
+            cur = {"type": t[1], "n": int(t[2]), "pd": int(t[3]), "nip": int(t[4]), "cp": int(t[5])}
+            cases.append(cur)
+        elif t[0] in ("INDX", "CNT"):
+            cur[t[0]] = [int(x) for x in t[1:]]
+        else:
+            cur[t[0]] = np.array([float(x) for x in t[1:]])
+    assert len(cases) == 28
+    close = lambda a, b, tol=1e-13: np.abs(np.asarray(a) - np.asarray(b)).max() <= tol * max(np.abs(np.asarray(b)).max(), 1e-300)  # noqa: E731
+    seen = {}
+    for c in cases:
+        g = gold[c["type"]]
+        k = seen.get(c["type"], 0)
+        seen[c["type"]] = k + 1
+        ref = g["cases"][k]
+        n, pd, nip, cp = c["n"], c["pd"], c["nip"], c["cp"]
+        assert close(c["K"].reshape(n * pd, n * pd, order="F"), np.array(ref["k"]))
+        assert close(c["S"].reshape(nip, cp, order="F"), np.array(ref["estress"]))
+        dN = c["DN"].reshape(pd, n, order="F")
+        assert close(dN, np.array(ref["dN"])) and abs(c["DETJ"][0] - ref["detj"]) <= 1e-13 * abs(ref["detj"])
+        assert close(c["D"].reshape(cp, cp, order="F"), np.array(ref["dmat"]))
+        assert close(c["B"].reshape(cp, n * pd, order="F"), oracle.bmat(pd, n, np.array(ref["dN"])), 1e-13)
+        assert close(c["N1"], np.array(g["shape"])[0])
+        assert close(c["IP"].reshape(nip, pd, order="F"), np.array(g["ipoints"])) and close(c["W"], g["weights"])
+        # ShapeFuncd at xi, then J = dNxi X must reproduce the golden detJ
+        dnxi = c["DNXI"].reshape(pd, n, order="F")
+        assert abs(np.linalg.det(dnxi @ np.array(ref["ecoords"])) - ref["detj"]) <= 1e-12 * abs(ref["detj"])
+        assert c["INDX"] == [int(v) for v in ref["indx"]]
+        assert c["CNT"] == [g["nodecount"], g["nip"], g["dim"], g["nps"], g["vtkid"]]
 
 
 def test_fortran_driver_reproduces_elastic_golden(tmp_path, oracle):

@@ -247,3 +247,40 @@ def test_fortran_interface_module_covers_the_whole_c_abi():
     assert len(declared) > 60
     assert declared - bound == set(), sorted(declared - bound)
     assert bound - declared == set(), sorted(bound - declared)
+
+
+def test_element_module_builds_under_the_reference_module_name(tmp_path):
+    """fortran/m_local_amd.F90 compiled with -DFEM_AMD_AS_LOCAL is a module called `local`: a reference-side file
+    that says `use local` and calls the element routines with the reference's signatures compiles against it
+    unchanged (compile only: running needs the GPU)."""
+    import shutil
+    import subprocess
+    flang = "/opt/rocm/lib/llvm/bin/flang"
+    if not os.path.exists(flang):
+        pytest.skip("no flang in this image")
+    src = tmp_path / "caller.F90"
+    src.write_text("""subroutine caller(k, estress, B, D, detj)
+  use local
+  implicit none
+  real(8) :: k(8, 8), estress(4, 3), B(3, 8), D(3, 3), detj, ec(4, 2), dN(2, 4), u(8)
+  real(8), pointer :: N(:)
+  integer :: indx(8)
+  pdim = 2
+  call Initialize(ipoints, weights)
+  ec = reshape((/0.d0, 1.d0, 1.d0, 0.d0, 0.d0, 0.d0, 1.d0, 1.d0/), (/4, 2/)); u = 0.d0
+  call FormElKE("qua", ec, 3640.d0, 0.3d0, 1.d0, k)
+  call CalcElStress("qua", ec, u, 3640.d0, 0.3d0, estress)
+  call FormdNdetJ("qua", ipoints(getElTypeNo("qua"))%array(1, :), ec, dN, detj)
+  call BMat(4, dN, B)
+  call DMat(D, 3640.d0, 0.3d0)
+  call ShapeFunc("qua", 1, N)
+  call ShapeFuncd("qua", dN, (/0.d0, 0.d0/))
+  call FormElIndx((/1, 2, 3, 4/), indx)
+end subroutine caller
+""")
+    fdir = os.path.join(ROOT, "fortran")
+    for f in ("fem_amd_capi.F90", "m_local_amd.F90"):
+        subprocess.check_call([flang, "-c", "-DFEM_AMD_AS_LOCAL", "-module-dir", str(tmp_path), "-I", str(tmp_path),
+                               os.path.join(fdir, f), "-o", str(tmp_path / (f + ".o"))])
+    subprocess.check_call([flang, "-c", "-module-dir", str(tmp_path), "-I", str(tmp_path), str(src), "-o", str(tmp_path / "caller.o")])
+    assert (tmp_path / "local.mod").exists()

@@ -12,10 +12,10 @@ echo "== bench"; timeout -k 10 600 python3 bench.py --steps 5 --warmup 2 > $O/be
 cat $O/bench.json
 echo "== bench config 2"; timeout -k 10 300 python3 bench.py --config 2 --steps 3 --warmup 1 --no-mg > $O/bench_c2.json 2> $O/bench_c2.err
 cat $O/bench_c2.json
-echo "== rocprofv3 stats"; (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-mg > $GRAFT_REPO_ROOT/$O/bench_profiled.json 2> $GRAFT_REPO_ROOT/$O/bench_profiled.err)
+echo "== rocprofv3 stats"; (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu --no-mg > $GRAFT_REPO_ROOT/$O/bench_profiled.json 2> $GRAFT_REPO_ROOT/$O/bench_profiled.err)
 find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
-echo "== pmc"; for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $c -d $GRAFT_REPO_ROOT/$O/pmc_$c -o ebe -- python3 $GRAFT_REPO_ROOT/tools/ebe_products.py 149 10 > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1); done
-python3 tools/pmc_to_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "k_ebe_apply<3, 8, 8>" $O/ebe_traffic.json 149 3 "k_ebe_gather<3>" "k_form_ke<3, 8, 8" > /dev/null
+echo "== pmc"; for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$c -o ebe -- python3 $GRAFT_REPO_ROOT/tools/ebe_products.py 149 10 > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1); done
+python3 tools/pmc_to_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "k_ebe_apply<3, 8, 8>" $O/ebe_traffic.json 149 3 "k_ebe_gather<3>" "k_assemble_rows<3, 8, 32>" > /dev/null
 python3 tools/pmc_summary.py $O/pmc_FETCH_SIZE FETCH_SIZE > $O/pmc_summary.txt; python3 tools/pmc_summary.py $O/pmc_WRITE_SIZE WRITE_SIZE >> $O/pmc_summary.txt
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/prof_stats
 echo "== done"

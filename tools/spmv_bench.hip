@@ -3,9 +3,12 @@
 // operator (n^3 nodes, 27-point node stencil, 3x3 fp64 blocks) so that the
 // product format is chosen from measurements on gfx950.
 //
-//   hipcc -O3 --offload-arch=gfx950 tools/spmv_bench.hip -o tools/spmv_bench
+//   hipcc -O3 --offload-arch=gfx950 tools/spmv_bench.hip -o tools/spmv_bench -lrocsparse
+// The rocSPARSE rows (rocsparse_spmv on scalar CSR, adaptive and row-split algorithms; rocsparse_dbsrmv on 3x3 BSR)
+// are the library reference point north_star names; the product uses its own sliced block-ELL kernel.
 //   tools/spmv_bench [nodes_per_edge=150] [reps=20]
 #include <hip/hip_runtime.h>
+#include <rocsparse/rocsparse.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -13,6 +16,7 @@
 #include <vector>
 #include <algorithm>
 
+#define RS(x) do { rocsparse_status s_ = (x); if (s_ != rocsparse_status_success) { printf("rocSPARSE error %d at %s:%d\n", (int)s_, __FILE__, __LINE__); exit(1);} } while (0)
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
 
 static inline double hash01(uint64_t k) {
@@ -301,6 +305,17 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dbv, bval.data(), nnz * 8, hipMemcpyHostToDevice));
         double fmt_bytes = nb * 76.0 + ndof * 16.0;
         RUN("bsr3 wave/row", (k_bsr3_wave<<<(unsigned)((nn * 64 + 255) / 256), 256>>>((int)nn, dbp, dbc, dbv, dx, dy)));
+        {   // rocSPARSE BSR, block dimension 3, row-major blocks
+            rocsparse_handle h; rocsparse_mat_descr descr; rocsparse_mat_info info;
+            RS(rocsparse_create_handle(&h)); RS(rocsparse_create_mat_descr(&descr)); RS(rocsparse_create_mat_info(&info));
+            const double one = 1.0, zero = 0.0;
+            RS(rocsparse_dbsrmv_analysis(h, rocsparse_direction_row, rocsparse_operation_none, (rocsparse_int)nn, (rocsparse_int)nn,
+                                         (rocsparse_int)nb, descr, dbv, dbp, dbc, 3, info));
+            RUN("rocsparse_dbsrmv bs3", RS(rocsparse_dbsrmv(h, rocsparse_direction_row, rocsparse_operation_none, (rocsparse_int)nn,
+                                                            (rocsparse_int)nn, (rocsparse_int)nb, &one, descr, dbv, dbp, dbc, 3, info,
+                                                            dx, &zero, dy)));
+            RS(rocsparse_destroy_mat_info(info)); RS(rocsparse_destroy_mat_descr(descr)); RS(rocsparse_destroy_handle(h));
+        }
         CK(hipFree(dbp)); CK(hipFree(dbc)); CK(hipFree(dbv));
     }
     // ---- (C) scalar CSR ----
@@ -320,6 +335,30 @@ int main(int argc, char** argv) {
         RUN("csr 8 lanes/row", (k_csr<8><<<(unsigned)((ndof * 8 + 255) / 256), 256>>>((int)ndof, drp, dci, dcv, dx, dy)));
         RUN("csr 16 lanes/row", (k_csr<16><<<(unsigned)((ndof * 16 + 255) / 256), 256>>>((int)ndof, drp, dci, dcv, dx, dy)));
         RUN("csr 32 lanes/row", (k_csr<32><<<(unsigned)((ndof * 32 + 255) / 256), 256>>>((int)ndof, drp, dci, dcv, dx, dy)));
+        {   // rocSPARSE generic SpMV on the scalar CSR matrix (what "rocSPARSE CSR SpMV" in north_star means)
+            rocsparse_handle h; RS(rocsparse_create_handle(&h));
+            rocsparse_spmat_descr A; rocsparse_dnvec_descr vx, vy;
+            RS(rocsparse_create_csr_descr(&A, (int64_t)ndof, (int64_t)ndof, (int64_t)nnz, drp, dci, dcv, rocsparse_indextype_i32,
+                                          rocsparse_indextype_i32, rocsparse_index_base_zero, rocsparse_datatype_f64_r));
+            RS(rocsparse_create_dnvec_descr(&vx, (int64_t)ndof, dx, rocsparse_datatype_f64_r));
+            RS(rocsparse_create_dnvec_descr(&vy, (int64_t)ndof, dy, rocsparse_datatype_f64_r));
+            const double one = 1.0, zero = 0.0;
+            const rocsparse_spmv_alg algs[3] = {rocsparse_spmv_alg_csr_adaptive, rocsparse_spmv_alg_csr_rowsplit, rocsparse_spmv_alg_csr_lrb};
+            const char* names[3] = {"rocsparse_spmv csr adaptive", "rocsparse_spmv csr rowsplit", "rocsparse_spmv csr lrb"};
+            for (int a = 0; a < 3; a++) {
+                size_t bsz = 0; void* buf = nullptr;
+                RS(rocsparse_spmv(h, rocsparse_operation_none, &one, A, vx, &zero, vy, rocsparse_datatype_f64_r, algs[a],
+                                  rocsparse_spmv_stage_buffer_size, &bsz, nullptr));
+                CK(hipMalloc(&buf, bsz ? bsz : 8));
+                RS(rocsparse_spmv(h, rocsparse_operation_none, &one, A, vx, &zero, vy, rocsparse_datatype_f64_r, algs[a],
+                                  rocsparse_spmv_stage_preprocess, &bsz, buf));
+                RUN(names[a], RS(rocsparse_spmv(h, rocsparse_operation_none, &one, A, vx, &zero, vy, rocsparse_datatype_f64_r, algs[a],
+                                                rocsparse_spmv_stage_compute, &bsz, buf)));
+                CK(hipFree(buf));
+            }
+            RS(rocsparse_destroy_dnvec_descr(vx)); RS(rocsparse_destroy_dnvec_descr(vy)); RS(rocsparse_destroy_spmat_descr(A));
+            RS(rocsparse_destroy_handle(h));
+        }
         CK(hipFree(drp)); CK(hipFree(dci)); CK(hipFree(dcv));
     }
     return 0;

@@ -343,9 +343,9 @@ int main(int argc, char** argv) {
             RS(rocsparse_create_dnvec_descr(&vx, (int64_t)ndof, dx, rocsparse_datatype_f64_r));
             RS(rocsparse_create_dnvec_descr(&vy, (int64_t)ndof, dy, rocsparse_datatype_f64_r));
             const double one = 1.0, zero = 0.0;
-            const rocsparse_spmv_alg algs[3] = {rocsparse_spmv_alg_csr_adaptive, rocsparse_spmv_alg_csr_rowsplit, rocsparse_spmv_alg_csr_lrb};
-            const char* names[3] = {"rocsparse_spmv csr adaptive", "rocsparse_spmv csr rowsplit", "rocsparse_spmv csr lrb"};
-            for (int a = 0; a < 3; a++) {
+            const rocsparse_spmv_alg algs[2] = {rocsparse_spmv_alg_csr_adaptive, rocsparse_spmv_alg_csr_rowsplit};   // (csr_lrb returns at once without computing on this build: left out)
+            const char* names[2] = {"rocsparse_spmv csr adaptive", "rocsparse_spmv csr rowsplit"};
+            for (int a = 0; a < 2; a++) {
                 size_t bsz = 0; void* buf = nullptr;
                 RS(rocsparse_spmv(h, rocsparse_operation_none, &one, A, vx, &zero, vy, rocsparse_datatype_f64_r, algs[a],
                                   rocsparse_spmv_stage_buffer_size, &bsz, nullptr));

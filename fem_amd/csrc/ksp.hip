@@ -633,9 +633,10 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // status record is examined, so the GPU never idles on a poll.  The chunk
     // length shrinks as the (log-linear) residual history approaches the target,
     // which keeps the number of no-op launches after convergence to a handful.
-    // Multi-domain runs use a fixed schedule: every domain must enqueue the same
-    // collectives in the same order.
-    int chunk = comm ? 16 : 8;
+    // Multi-domain runs take the same decisions on every domain: the record they are taken from (iteration count,
+    // all-reduced residual norm, target) is bitwise the same everywhere, and every domain examines chunk c at the same
+    // point of its enqueue sequence -- so all of them enqueue the same collectives in the same order.
+    int chunk = 8;
     int slot = 0, prev_it = -1;
     double prev_dp = 0.0;
     bool have_pending = false, finished = false;
@@ -652,7 +653,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
             FEM_HIP(hipEventSynchronize(k->poll_ev[ps]));
             const KspState& hs = k->h_state[ps];
             if (hs.done) { finished = true; break; }
-            if (!comm && prev_it >= 0 && hs.it > prev_it && hs.dp > 0 && prev_dp > hs.dp && hs.ttol > 0) {
+            if (prev_it >= 0 && hs.it > prev_it && hs.dp > 0 && prev_dp > hs.dp && hs.ttol > 0) {
                 const double rate = std::log(prev_dp / hs.dp) / (hs.it - prev_it);   // decades per iteration (ln)
                 const double remaining = std::log(hs.dp / hs.ttol) / rate - chunk;   // beyond what is already queued
                 chunk = (int)std::fmin(32.0, std::fmax(1.0, 0.4 * remaining));

@@ -685,8 +685,235 @@ void mat_assemble_elements_impl(fem_mat A)
 // un-assembled identity the partitioned product uses.
 // Traffic at config 3: 0.11 GB connectivity + 1.27 GB element buffer (write + read) + gathers from
 // L2, i.e. 1.5 GB instead of 7.4 GB; the element kernel is bound by the fp64 FMA pipe.
-template <int PD, int NPE, int NIP>
-__global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int* __restrict__ conn,
+// hex8: the same product in the monomial basis of the trilinear element (sum factorisation written out).
+//   v(xi) = c0 + cx xi + cy eta + cz zeta + cxy xi eta + cxz xi zeta + cyz eta zeta + cxyz xi eta zeta
+// Eight nodal values become seven coefficients by a three-stage butterfly (c0 never enters a gradient); at the Gauss
+// point (s1 g, s2 g, s3 g) of the 2x2x2 rule the reference gradient of a field is three signed sums of coefficients
+// that carry their powers of g, shared between points with equal signs, instead of 24 multiply-adds against dN/dxi;
+// the element forces are accumulated as the seven moments of T against the gradients of the monomials and go back to
+// nodal values by the transposed butterfly.  ~1,550 fp64 instructions per element instead of ~2,750.
+//   H' = adj(J) G and T = (w/det) D eps(H') adj(J): the inverse Jacobian itself is never formed.
+template <int S>
+__device__ __forceinline__ double sadd(double a, double b) { return S > 0 ? a + b : a - b; }
+template <int S>
+__device__ __forceinline__ double sg(double a) { return S > 0 ? a : -a; }
+
+
+struct Mono { double x, y, z, xy, xz, yz, xyz; };
+
+__device__ __forceinline__ Mono hex_mono(const double (&v)[8], double g8, double gg8)
+{
+    // stage xi
+    const double s00 = v[1] + v[0], d00 = v[1] - v[0];   // (eta-, zeta-)
+    const double s10 = v[2] + v[3], d10 = v[2] - v[3];   // (eta+, zeta-)
+    const double s01 = v[5] + v[4], d01 = v[5] - v[4];   // (eta-, zeta+)
+    const double s11 = v[6] + v[7], d11 = v[6] - v[7];   // (eta+, zeta+)
+    // stage eta
+    const double ss0 = s10 + s00, sd0 = s10 - s00, ds0 = d10 + d00, dd0 = d10 - d00;
+    const double ss1 = s11 + s01, sd1 = s11 - s01, ds1 = d11 + d01, dd1 = d11 - d01;
+    // stage zeta, with 1/8 and the powers of g the gradients at the Gauss points need
+    Mono c;
+    c.x = 0.125 * (ds1 + ds0);
+    c.y = 0.125 * (sd1 + sd0);
+    c.z = 0.125 * (ss1 - ss0);
+    c.xy = g8 * (dd1 + dd0);
+    c.xz = g8 * (ds1 - ds0);
+    c.yz = g8 * (sd1 - sd0);
+    c.xyz = gg8 * (dd1 - dd0);
+    return c;
+}
+
+template <int S1, int S2, int S3>
+__device__ __forceinline__ void hex_point(const Mono (&cX)[3], const Mono (&cU)[3], double w, double lam, double mu,
+                                          Mono (&F)[3])
+{
+    double J[3][3], G[3][3];   // J[i][j] = d x_j / d xi_i, G[i][l] = d u_l / d xi_i
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const double a2 = sadd<S1>(cX[j].yz, cX[j].xyz);
+        J[0][j] = sadd<S3>(sadd<S2>(cX[j].x, cX[j].xy), sadd<S2>(cX[j].xz, cX[j].xyz));
+        J[1][j] = sadd<S3>(sadd<S1>(cX[j].y, cX[j].xy), a2);
+        J[2][j] = sadd<S2>(sadd<S1>(cX[j].z, cX[j].xz), a2);
+        const double b2 = sadd<S1>(cU[j].yz, cU[j].xyz);
+        G[0][j] = sadd<S3>(sadd<S2>(cU[j].x, cU[j].xy), sadd<S2>(cU[j].xz, cU[j].xyz));
+        G[1][j] = sadd<S3>(sadd<S1>(cU[j].y, cU[j].xy), b2);
+        G[2][j] = sadd<S2>(sadd<S1>(cU[j].z, cU[j].xz), b2);
+    }
+    // adj[i][j] = det * d xi_j / d x_i
+    double adj[3][3];
+    adj[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    adj[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    adj[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    adj[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    adj[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    adj[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    adj[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    adj[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    adj[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double det = J[0][0] * adj[0][0] + J[0][1] * adj[1][0] + J[0][2] * adj[2][0];
+    double rd = __builtin_amdgcn_rcp(det);      // two Newton steps: full double precision
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    double H[3][3];                             // H[l][i] = det * d u_l / d x_i
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) H[l][i] = adj[i][0] * G[0][l] + adj[i][1] * G[1][l] + adj[i][2] * G[2][l];
+    // S = (w det) D eps(grad u) / det^2 ... = (w / det) D eps(H); DMat (src/m_local.F90:204) as lambda, mu
+    const double wr = w * rd;
+    const double lw = lam * wr, mw = mu * wr, m2 = mw + mw;
+    const double lt = lw * ((H[0][0] + H[1][1]) + H[2][2]);
+    double S[3][3];
+    S[0][0] = fma(m2, H[0][0], lt);
+    S[1][1] = fma(m2, H[1][1], lt);
+    S[2][2] = fma(m2, H[2][2], lt);
+    S[0][1] = S[1][0] = mw * (H[0][1] + H[1][0]);
+    S[1][2] = S[2][1] = mw * (H[1][2] + H[2][1]);
+    S[0][2] = S[2][0] = mw * (H[2][0] + H[0][2]);
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        // T[j] = sum_i S[l][i] adj[i][j]:  f_a[l] += sum_j T[j] dN_a/dxi_j
+        const double T0 = S[l][0] * adj[0][0] + S[l][1] * adj[1][0] + S[l][2] * adj[2][0];
+        const double T1 = S[l][0] * adj[0][1] + S[l][1] * adj[1][1] + S[l][2] * adj[2][1];
+        const double T2 = S[l][0] * adj[0][2] + S[l][1] * adj[1][2] + S[l][2] * adj[2][2];
+        F[l].x += T0;
+        F[l].y += T1;
+        F[l].z += T2;
+        F[l].xy += sg<S2>(T0) + sg<S1>(T1);
+        F[l].xz += sg<S3>(T0) + sg<S1>(T2);
+        F[l].yz += sg<S3>(T1) + sg<S2>(T2);
+        F[l].xyz += (sg<S2 * S3>(T0) + sg<S1 * S3>(T1)) + sg<S1 * S2>(T2);
+    }
+}
+
+
+// T[l][j] = (w / det J) * sum_i (D eps(adj(J) G))[l][i] adj(J)[i][j] at one Gauss point: the nodal forces are
+// f_a[l] += sum_j T[l][j] dN_a/dxi_j
+__device__ __forceinline__ void hex_point_T(const double (&J)[3][3], const double (&G)[3][3], double w, double lam, double mu,
+                                            double (&T)[3][3])
+{
+    double adj[3][3];   // adj[i][j] = det * d xi_j / d x_i
+    adj[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    adj[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    adj[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    adj[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    adj[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    adj[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    adj[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    adj[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    adj[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double det = J[0][0] * adj[0][0] + J[0][1] * adj[1][0] + J[0][2] * adj[2][0];
+    double rd = __builtin_amdgcn_rcp(det);      // two Newton steps: full double precision
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    double H[3][3];                             // H[l][i] = det * d u_l / d x_i
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) H[l][i] = adj[i][0] * G[0][l] + adj[i][1] * G[1][l] + adj[i][2] * G[2][l];
+    // DMat (src/m_local.F90:204) as lambda, mu; one factor 1/det from H, one from adj, w det from the quadrature
+    const double wr = w * rd;
+    const double lw = lam * wr, mw = mu * wr, m2 = mw + mw;
+    const double lt = lw * ((H[0][0] + H[1][1]) + H[2][2]);
+    double S[3][3];
+    S[0][0] = fma(m2, H[0][0], lt);
+    S[1][1] = fma(m2, H[1][1], lt);
+    S[2][2] = fma(m2, H[2][2], lt);
+    S[0][1] = S[1][0] = mw * (H[0][1] + H[1][0]);
+    S[1][2] = S[2][1] = mw * (H[1][2] + H[2][1]);
+    S[0][2] = S[2][0] = mw * (H[2][0] + H[0][2]);
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[l][j] = S[l][0] * adj[0][j] + S[l][1] * adj[1][j] + S[l][2] * adj[2][j];
+}
+
+// the two Gauss points (s1 g, s2 g, -+g): signs s1, s2 are run-time wave-uniform values of a rolled loop (the live set
+// stays at coefficients + moments + one pair's temporaries), the zeta sign is written out so that the pair shares the
+// partial sums of its gradients and of its moments
+__device__ __forceinline__ void hex_pair(double s1, double s2, const Mono (&cX)[3], const Mono (&cU)[3], double w, double lam,
+                                         double mu, Mono (&F)[3])
+{
+    double Jm[3][3], Jp[3][3], Gm[3][3], Gp[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        {
+            const Mono& c = cX[j];
+            const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+            const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+            Jm[0][j] = B1 - B2; Jp[0][j] = B1 + B2;
+            Jm[1][j] = A1 - A2; Jp[1][j] = A1 + A2;
+            Jm[2][j] = Jp[2][j] = fma(s2, A2, A3);
+        }
+        {
+            const Mono& c = cU[j];
+            const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+            const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+            Gm[0][j] = B1 - B2; Gp[0][j] = B1 + B2;
+            Gm[1][j] = A1 - A2; Gp[1][j] = A1 + A2;
+            Gm[2][j] = Gp[2][j] = fma(s2, A2, A3);
+        }
+    }
+    double Tm[3][3], Tp[3][3];
+    hex_point_T(Jm, Gm, w, lam, mu, Tm);
+    hex_point_T(Jp, Gp, w, lam, mu, Tp);
+    const double s12 = s1 * s2;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const double U0 = Tp[l][0] + Tm[l][0], U1 = Tp[l][1] + Tm[l][1], U2 = Tp[l][2] + Tm[l][2];
+        const double V0 = Tp[l][0] - Tm[l][0], V1 = Tp[l][1] - Tm[l][1];
+        F[l].x += U0;
+        F[l].y += U1;
+        F[l].z += U2;
+        F[l].xy = fma(s1, U1, fma(s2, U0, F[l].xy));
+        F[l].xz = fma(s1, U2, F[l].xz + V0);
+        F[l].yz = fma(s2, U2, F[l].yz + V1);
+        F[l].xyz = fma(s12, U2, fma(s1, V1, fma(s2, V0, F[l].xyz)));
+    }
+}
+
+// nodal forces fe and x_e . f_e of one hex8 from nodal coordinates X and values u (2x2x2 Gauss rule: points +-g, weight w)
+__device__ __forceinline__ void hex_forces(const double (&X)[8][3], const double (&u)[8][3], double g, double w, double lam,
+                                           double mu, double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cX[3], cU[3], F[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8];
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = X[a][j];
+        cX[j] = hex_mono(v, g8, gg8);
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8);
+        F[j] = Mono{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    }
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < 4; q++) hex_pair((q & 1) ? 1.0 : -1.0, (q & 2) ? 1.0 : -1.0, cX, cU, w, lam, mu, F);
+    double d = 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        // x_e . f_e in the monomial basis: the butterflies are orthogonal up to the factor 8 the scalings carry
+        d += cU[l].x * F[l].x + cU[l].y * F[l].y + cU[l].z * F[l].z + cU[l].xy * F[l].xy + cU[l].xz * F[l].xz +
+             cU[l].yz * F[l].yz + cU[l].xyz * F[l].xyz;
+        // moments -> nodal forces: f_a = 1/8 sum_m (sign pattern of monomial m at node a) * moment_m
+        const double P = 0.125 * F[l].x, Q = 0.125 * F[l].y, R = 0.125 * F[l].z;
+        const double PQ = g8 * F[l].xy, PR = g8 * F[l].xz, QR = g8 * F[l].yz, PQR = gg8 * F[l].xyz;
+        // zeta, then eta, then xi
+        const double a10m = P - PR, a10p = P + PR, a01m = Q - QR, a01p = Q + QR, a11m = PQ - PQR, a11p = PQ + PQR;
+        const double b0mm = -R - a01m, b0pm = -R + a01m, b0mp = R - a01p, b0pp = R + a01p;      // [eta][zeta]
+        const double b1mm = a10m - a11m, b1pm = a10m + a11m, b1mp = a10p - a11p, b1pp = a10p + a11p;
+        fe[0][l] = b0mm - b1mm; fe[1][l] = b0mm + b1mm;   // (xi-+, eta-, zeta-)
+        fe[3][l] = b0pm - b1pm; fe[2][l] = b0pm + b1pm;   // eta+, zeta-
+        fe[4][l] = b0mp - b1mp; fe[5][l] = b0mp + b1mp;   // eta-, zeta+
+        fe[7][l] = b0pp - b1pp; fe[6][l] = b0pp + b1pp;   // eta+, zeta+
+    }
+    dot = d;
+}
+
+template <int PD, int NPE, int NIP, bool MONO = true>
+__global__ void __launch_bounds__(256, 2) k_ebe_apply(int type, int nel, const int* __restrict__ conn,
                                                    const double* __restrict__ coords, const double* __restrict__ Ev,
                                                    const double* __restrict__ nuv, const double* __restrict__ x,
                                                    const unsigned char* __restrict__ donate, double* __restrict__ f,
@@ -712,6 +939,9 @@ __global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int*
             for (int d = 0; d < PD; d++) { X[a][d] = coords[v * PD + d]; u[a][d] = x[v * PD + d]; }
         }
         const DCoef D = dmat_coef(Ev[e], nuv[e]);
+        if constexpr (MONO && PD == 3 && NPE == 8 && NIP == 8) {
+            hex_forces(X, u, fabs(tab.xi[0][0]), tab.w[0], D.d12, D.d44, fe, dot);
+        } else {
 #pragma unroll
         for (int q = 0; q < NIP; q++) {
             // Everything in reference coordinates, so that dN/dx (npe*pdim values per point) is never formed:
@@ -797,6 +1027,7 @@ __global__ void __launch_bounds__(256) k_ebe_apply(int type, int nel, const int*
         for (int a = 0; a < NPE; a++)
 #pragma unroll
             for (int d = 0; d < PD; d++) dot += u[a][d] * fe[a][d];
+        }
     }
     // hand-over along the wavefront (every lane takes part in the cross-lane moves): the +x face forces
     // of lane l-1 are added to the -x face nodes of lane l (same global nodes, checked at set-up), and
@@ -1016,8 +1247,13 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
         ev.f[gi] = A->ebe_f[gi].p; ev.nel[gi] = g.nel;
         const unsigned nb = cdiv((size_t)g.nel, 256);
         dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto) {
-            hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP()>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
-                               m->coords.p, g.E.p, g.nu.p, x, A->pat->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
+            static const bool mono = !(std::getenv("FEM_AMD_EBE_MONO") && std::atoi(std::getenv("FEM_AMD_EBE_MONO")) == 0);
+            if (mono)
+                hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP(), true>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
+                                   m->coords.p, g.E.p, g.nu.p, x, A->pat->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
+            else
+                hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP(), false>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
+                                   m->coords.p, g.E.p, g.nu.p, x, A->pat->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
         });
         off += (int)nb;
     }

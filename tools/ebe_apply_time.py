@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""tools/ebe_apply_time.py [n] [reps] -- per-kernel time of the element-by-element product (event pairs around
+k_ebe_apply and k_ebe_gather) on the n^3 hex8 cube."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fem_amd import capi, driver  # noqa: E402
+from fem_amd.mesh import structured_hex  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 149
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+ctx = capi.Context(0)
+m = structured_hex(n)
+prob = driver.Problem(ctx, m, "-mat_mult_type ebe")
+prob.assemble(); prob.ksp.set_up()
+X, Y = capi.Vec(ctx, m.ndof), capi.Vec(ctx, m.ndof)
+X.set_array(np.sin(0.001 * np.arange(m.ndof)))
+for _ in range(5):
+    prob.K.mult(X, Y)
+prob.K.set_profiling(1)
+for _ in range(reps):
+    prob.K.mult(X, Y)
+ctx.synchronize()
+k, el, ga, pe = prob.K.get_profile(reps)
+print(f"tag={os.environ.get('TAG', '')} products={k} apply_ms={el / k:.4f} gather_ms={ga / k:.4f}", flush=True)
+prob.destroy(); ctx.destroy()

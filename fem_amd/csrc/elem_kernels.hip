@@ -76,12 +76,10 @@ struct DenseSink {  // k(nd,nd) column-major per element (FormElKE's out-argumen
 };
 
 // local nodes on the +x face (quad4: 1,2; hex8: 1,2,5,6): the hand-over of the element-by-element product
-template <int NPE, int PD>
-__device__ __forceinline__ bool is_plus_x(int a)
+template <int NPE>
+__host__ __device__ constexpr bool plus_face_x(int a)
 {
-    if constexpr (NPE == 8) return a == 1 || a == 2 || a == 5 || a == 6;
-    else if constexpr (NPE == 4 && PD == 2) return a == 1 || a == 2;
-    else return false;
+    return NPE == 8 ? (a == 1 || a == 2 || a == 5 || a == 6) : (a == 1 || a == 2);
 }
 
 // ---- element stiffness ----------------------------------------------------------------------
@@ -693,15 +691,9 @@ void mat_assemble_elements_impl(fem_mat A)
 // the element forces are accumulated as the seven moments of T against the gradients of the monomials and go back to
 // nodal values by the transposed butterfly.  ~1,550 fp64 instructions per element instead of ~2,750.
 //   H' = adj(J) G and T = (w/det) D eps(H') adj(J): the inverse Jacobian itself is never formed.
-template <int S>
-__device__ __forceinline__ double sadd(double a, double b) { return S > 0 ? a + b : a - b; }
-template <int S>
-__device__ __forceinline__ double sg(double a) { return S > 0 ? a : -a; }
-
-
 struct Mono { double x, y, z, xy, xz, yz, xyz; };
 
-__device__ __forceinline__ Mono hex_mono(const double (&v)[8], double g8, double gg8)
+__device__ __forceinline__ Mono hex_mono(const double (&v)[8], double g8, double gg8, double& c0)
 {
     // stage xi
     const double s00 = v[1] + v[0], d00 = v[1] - v[0];   // (eta-, zeta-)
@@ -720,72 +712,9 @@ __device__ __forceinline__ Mono hex_mono(const double (&v)[8], double g8, double
     c.xz = g8 * (ds1 - ds0);
     c.yz = g8 * (sd1 - sd0);
     c.xyz = gg8 * (dd1 - dd0);
+    c0 = 0.125 * (ss1 + ss0);
     return c;
 }
-
-template <int S1, int S2, int S3>
-__device__ __forceinline__ void hex_point(const Mono (&cX)[3], const Mono (&cU)[3], double w, double lam, double mu,
-                                          Mono (&F)[3])
-{
-    double J[3][3], G[3][3];   // J[i][j] = d x_j / d xi_i, G[i][l] = d u_l / d xi_i
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-        const double a2 = sadd<S1>(cX[j].yz, cX[j].xyz);
-        J[0][j] = sadd<S3>(sadd<S2>(cX[j].x, cX[j].xy), sadd<S2>(cX[j].xz, cX[j].xyz));
-        J[1][j] = sadd<S3>(sadd<S1>(cX[j].y, cX[j].xy), a2);
-        J[2][j] = sadd<S2>(sadd<S1>(cX[j].z, cX[j].xz), a2);
-        const double b2 = sadd<S1>(cU[j].yz, cU[j].xyz);
-        G[0][j] = sadd<S3>(sadd<S2>(cU[j].x, cU[j].xy), sadd<S2>(cU[j].xz, cU[j].xyz));
-        G[1][j] = sadd<S3>(sadd<S1>(cU[j].y, cU[j].xy), b2);
-        G[2][j] = sadd<S2>(sadd<S1>(cU[j].z, cU[j].xz), b2);
-    }
-    // adj[i][j] = det * d xi_j / d x_i
-    double adj[3][3];
-    adj[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-    adj[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-    adj[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-    adj[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
-    adj[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
-    adj[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
-    adj[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
-    adj[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
-    adj[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-    const double det = J[0][0] * adj[0][0] + J[0][1] * adj[1][0] + J[0][2] * adj[2][0];
-    double rd = __builtin_amdgcn_rcp(det);      // two Newton steps: full double precision
-    rd = fma(fma(-det, rd, 1.0), rd, rd);
-    rd = fma(fma(-det, rd, 1.0), rd, rd);
-    double H[3][3];                             // H[l][i] = det * d u_l / d x_i
-#pragma unroll
-    for (int l = 0; l < 3; l++)
-#pragma unroll
-        for (int i = 0; i < 3; i++) H[l][i] = adj[i][0] * G[0][l] + adj[i][1] * G[1][l] + adj[i][2] * G[2][l];
-    // S = (w det) D eps(grad u) / det^2 ... = (w / det) D eps(H); DMat (src/m_local.F90:204) as lambda, mu
-    const double wr = w * rd;
-    const double lw = lam * wr, mw = mu * wr, m2 = mw + mw;
-    const double lt = lw * ((H[0][0] + H[1][1]) + H[2][2]);
-    double S[3][3];
-    S[0][0] = fma(m2, H[0][0], lt);
-    S[1][1] = fma(m2, H[1][1], lt);
-    S[2][2] = fma(m2, H[2][2], lt);
-    S[0][1] = S[1][0] = mw * (H[0][1] + H[1][0]);
-    S[1][2] = S[2][1] = mw * (H[1][2] + H[2][1]);
-    S[0][2] = S[2][0] = mw * (H[2][0] + H[0][2]);
-#pragma unroll
-    for (int l = 0; l < 3; l++) {
-        // T[j] = sum_i S[l][i] adj[i][j]:  f_a[l] += sum_j T[j] dN_a/dxi_j
-        const double T0 = S[l][0] * adj[0][0] + S[l][1] * adj[1][0] + S[l][2] * adj[2][0];
-        const double T1 = S[l][0] * adj[0][1] + S[l][1] * adj[1][1] + S[l][2] * adj[2][1];
-        const double T2 = S[l][0] * adj[0][2] + S[l][1] * adj[1][2] + S[l][2] * adj[2][2];
-        F[l].x += T0;
-        F[l].y += T1;
-        F[l].z += T2;
-        F[l].xy += sg<S2>(T0) + sg<S1>(T1);
-        F[l].xz += sg<S3>(T0) + sg<S1>(T2);
-        F[l].yz += sg<S3>(T1) + sg<S2>(T2);
-        F[l].xyz += (sg<S2 * S3>(T0) + sg<S1 * S3>(T1)) + sg<S1 * S2>(T2);
-    }
-}
-
 
 // T[l][j] = (w / det J) * sum_i (D eps(adj(J) G))[l][i] adj(J)[i][j] at one Gauss point: the nodal forces are
 // f_a[l] += sum_j T[l][j] dN_a/dxi_j
@@ -872,25 +801,105 @@ __device__ __forceinline__ void hex_pair(double s1, double s2, const Mono (&cX)[
     }
 }
 
-// nodal forces fe and x_e . f_e of one hex8 from nodal coordinates X and values u (2x2x2 Gauss rule: points +-g, weight w)
-__device__ __forceinline__ void hex_forces(const double (&X)[8][3], const double (&u)[8][3], double g, double w, double lam,
-                                           double mu, double (&fe)[8][3], double& dot)
+// Parallelepipeds (constant Jacobian -- the "affine cell" class of matrix-free finite-element codes): adj(J), det J and so the
+// map L: G -> T are the same at the eight Gauss points, T(q) = sum_p p(q) L(G_p) over the seven sign patterns p of the
+// gradient of a trilinear field, and the sum over the points keeps, for every moment, the pattern(s) of that monomial's own
+// gradient (the sign patterns are orthogonal over the 2x2x2 rule: sum_q p(q) p'(q) = 8 [p = p']).  Seven sparse
+// applications of L instead of eight full ones.
+//   RM: rows of G that are not zero, CM: columns of T that are wanted (bit i = row / column i)
+template <int RM, int CM>
+__device__ __forceinline__ void affine_T(const double (&A)[3][3], const double (&G)[3][3], double lw, double mw, double m2,
+                                         double (&T)[3][3])
 {
-    const double g8 = 0.125 * g, gg8 = g8 * g;
-    Mono cX[3], cU[3], F[3];
+    double H[3][3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
-        double v[8];
+    for (int l = 0; l < 3; l++)
 #pragma unroll
-        for (int a = 0; a < 8; a++) v[a] = X[a][j];
-        cX[j] = hex_mono(v, g8, gg8);
+        for (int i = 0; i < 3; i++) {
+            double h = 0.0;
+            bool first = true;
 #pragma unroll
-        for (int a = 0; a < 8; a++) v[a] = u[a][j];
-        cU[j] = hex_mono(v, g8, gg8);
-        F[j] = Mono{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    }
-#pragma clang loop unroll(disable)
-    for (int q = 0; q < 4; q++) hex_pair((q & 1) ? 1.0 : -1.0, (q & 2) ? 1.0 : -1.0, cX, cU, w, lam, mu, F);
+            for (int j = 0; j < 3; j++)
+                if ((RM >> j) & 1) { h = first ? A[i][j] * G[j][l] : fma(A[i][j], G[j][l], h); first = false; }
+            H[l][i] = h;
+        }
+    const double lt = lw * ((H[0][0] + H[1][1]) + H[2][2]);
+    double S[3][3];
+    S[0][0] = fma(m2, H[0][0], lt);
+    S[1][1] = fma(m2, H[1][1], lt);
+    S[2][2] = fma(m2, H[2][2], lt);
+    S[0][1] = S[1][0] = mw * (H[0][1] + H[1][0]);
+    S[1][2] = S[2][1] = mw * (H[1][2] + H[2][1]);
+    S[0][2] = S[2][0] = mw * (H[2][0] + H[0][2]);
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if ((CM >> j) & 1) T[l][j] = S[l][0] * A[0][j] + S[l][1] * A[1][j] + S[l][2] * A[2][j];
+}
+
+__device__ __forceinline__ void hex_affine(const double (&J)[3][3], const Mono (&cU)[3], double w, double lam, double mu,
+                                           Mono (&F)[3])
+{
+    double A[3][3];
+    A[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    A[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    A[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    A[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    A[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    A[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    A[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    A[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    A[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double det = J[0][0] * A[0][0] + J[0][1] * A[1][0] + J[0][2] * A[2][0];
+    double rd = __builtin_amdgcn_rcp(det);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    const double wr = 8.0 * w * rd;   // eight points of equal weight
+    const double lw = lam * wr, mw = mu * wr, m2 = mw + mw;
+    double G[3][3], T[3][3];
+    // pattern 1: G = (c.x, c.y, c.z) -> moments x, y, z
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].x; G[1][l] = cU[l].y; G[2][l] = cU[l].z; }
+    affine_T<7, 7>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].x = T[l][0]; F[l].y = T[l][1]; F[l].z = T[l][2]; }
+    // pattern s1 (sign of xi): G = (0, c.xy, c.xz) -> second terms of xy and xz
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[1][l] = cU[l].xy; G[2][l] = cU[l].xz; }
+    affine_T<6, 6>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xy = T[l][1]; F[l].xz = T[l][2]; }
+    // pattern s2: G = (c.xy, 0, c.yz) -> first term of xy, second of yz
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].xy; G[2][l] = cU[l].yz; }
+    affine_T<5, 5>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xy += T[l][0]; F[l].yz = T[l][2]; }
+    // pattern s3: G = (c.xz, c.yz, 0) -> first terms of xz and yz
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].xz; G[1][l] = cU[l].yz; }
+    affine_T<3, 3>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xz += T[l][0]; F[l].yz += T[l][1]; }
+    // patterns s2 s3, s1 s3, s1 s2: the xyz coefficient in one row -> the three terms of xyz
+#pragma unroll
+    for (int l = 0; l < 3; l++) G[0][l] = G[1][l] = G[2][l] = cU[l].xyz;
+    affine_T<1, 1>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz = T[l][0];
+    affine_T<2, 2>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz += T[l][1];
+    affine_T<4, 4>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz += T[l][2];
+}
+
+// moments -> nodal forces (the transposed butterfly) and x_e . f_e
+__device__ __forceinline__ void hex_finish(const Mono (&cU)[3], const Mono (&F)[3], double g8, double gg8, double (&fe)[8][3],
+                                           double& dot)
+{
     double d = 0.0;
 #pragma unroll
     for (int l = 0; l < 3; l++) {
@@ -912,35 +921,111 @@ __device__ __forceinline__ void hex_forces(const double (&X)[8][3], const double
     dot = d;
 }
 
-template <int PD, int NPE, int NIP, bool MONO = true>
-__global__ void __launch_bounds__(256, 2) k_ebe_apply(int type, int nel, const int* __restrict__ conn,
-                                                   const double* __restrict__ coords, const double* __restrict__ Ev,
-                                                   const double* __restrict__ nuv, const double* __restrict__ x,
-                                                   const unsigned char* __restrict__ donate, double* __restrict__ f,
-                                                   double* __restrict__ partial, const int* __restrict__ done)
+// a parallelepiped known as such from the set-up (same test as in hex_forces, once per mesh): the Jacobian is read off
+// three edges of one corner
+__device__ __forceinline__ void hex_forces_affine(const double (&X)[8][3], const double (&u)[8][3], double g, double w,
+                                                  double lam, double mu, double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cU[3], F[3];
+    double J[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+        J[0][j] = 0.5 * (X[1][j] - X[0][j]);
+        J[1][j] = 0.5 * (X[3][j] - X[0][j]);
+        J[2][j] = 0.5 * (X[4][j] - X[0][j]);
+    }
+    hex_affine(J, cU, w, lam, mu, F);
+    hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
+// nodal forces fe and x_e . f_e of one hex8 from nodal coordinates X and values u (2x2x2 Gauss rule: points +-g, weight w)
+template <bool AFFINE_PATH>
+__device__ __forceinline__ void hex_forces(const double (&X)[8][3], const double (&u)[8][3], double g, double w, double lam,
+                                           double mu, double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cX[3], cU[3], F[3];
+    bool affine = true;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = X[a][j];
+        cX[j] = hex_mono(v, g8, gg8, c0);
+        // mixed terms below the rounding noise of the coordinates themselves (2^-50 of their magnitude): a parallelepiped
+        const double tol = 0x1p-50 * (fabs(c0) + fabs(cX[j].x) + fabs(cX[j].y) + fabs(cX[j].z));
+        affine = affine && fabs(cX[j].xy) <= tol && fabs(cX[j].xz) <= tol && fabs(cX[j].yz) <= tol && fabs(cX[j].xyz) <= tol;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+    }
+    if (AFFINE_PATH && __all(affine)) {
+        double J[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { J[0][j] = cX[j].x; J[1][j] = cX[j].y; J[2][j] = cX[j].z; }
+        hex_affine(J, cU, w, lam, mu, F);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) F[j] = Mono{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < 4; q++) hex_pair((q & 1) ? 1.0 : -1.0, (q & 2) ? 1.0 : -1.0, cX, cU, w, lam, mu, F);
+    }
+    hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
+//   VAR 0: Gauss loop against dN/dxi (tri3, quad4, tet4; hex8 only for measurement)   1: hex8 in the monomial basis, with the
+//   wave-level short cut for parallelepipeds   2: the same without the short cut (measurement)   3: hex8 workgroups the set-up
+//   found to hold parallelepipeds only (128 registers, four waves per SIMD)
+template <int PD, int NPE, int NIP, int VAR = 0>
+__global__ void __launch_bounds__(256, VAR == 3 ? 4 : 2) k_ebe_apply(int type, int nel, int nblk, const int* __restrict__ blocks,
+                                                      const int* __restrict__ conn, const double* __restrict__ coords,
+                                                      const double* __restrict__ Ev, const double* __restrict__ nuv,
+                                                      const double* __restrict__ x, const unsigned char* __restrict__ donate,
+                                                      double* __restrict__ f, double* __restrict__ partial,
+                                                      const int* __restrict__ done)
 {
     if (done && *done) return;
     constexpr bool PAIR = (NPE == 8 || (NPE == 4 && PD == 2));
+    constexpr int NP = NPE / 2;
+    constexpr int plus8[4] = {1, 2, 5, 6}, minus8[4] = {0, 3, 4, 7};   // quad4 uses the first two pairs: (1,0) (2,3)
     __shared__ double sh[4];
     const ElemTable& tab = c_tab[type];
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // Workgroups b and b + 8 share an XCD (and its L2): every XCD takes a contiguous eighth of the workgroup list, so that
+    // elements that share nodes across rows and layers of the mesh meet in one L2 (the grid is a multiple of 8)
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+    if (lb >= (unsigned)nblk) return;
+    const unsigned blk = blocks ? (unsigned)blocks[lb] : lb;
+    const size_t e = (size_t)blk * blockDim.x + threadIdx.x;
+    const bool active = e < (size_t)nel;
+    const bool don = PAIR && active && donate[e] != 0;   // the +x face forces go to the next lane (set-up)
     double dot = 0.0;
     double fe[NPE][PD];
 #pragma unroll
     for (int a = 0; a < NPE; a++)
 #pragma unroll
         for (int d = 0; d < PD; d++) fe[a][d] = 0.0;
-    if (e < (size_t)nel) {
+    if (active) {
         double X[NPE][PD], u[NPE][PD];
 #pragma unroll
         for (int a = 0; a < NPE; a++) {
             const size_t v = (size_t)conn[e * NPE + a];
 #pragma unroll
-            for (int d = 0; d < PD; d++) { X[a][d] = coords[v * PD + d]; u[a][d] = x[v * PD + d]; }
+            for (int d = 0; d < PD; d++) {
+                // the affine-only kernel reads the coordinates of one corner and its three neighbours
+                if (VAR != 3 || a == 0 || a == 1 || a == 3 || a == 4) X[a][d] = coords[v * PD + d];
+                u[a][d] = x[v * PD + d];
+            }
         }
         const DCoef D = dmat_coef(Ev[e], nuv[e]);
-        if constexpr (MONO && PD == 3 && NPE == 8 && NIP == 8) {
-            hex_forces(X, u, fabs(tab.xi[0][0]), tab.w[0], D.d12, D.d44, fe, dot);
+        if constexpr (VAR == 3 && PD == 3 && NPE == 8 && NIP == 8) {
+            hex_forces_affine(X, u, fabs(tab.xi[0][0]), tab.w[0], D.d12, D.d44, fe, dot);
+        } else if constexpr (VAR != 0 && PD == 3 && NPE == 8 && NIP == 8) {
+            hex_forces<VAR == 1>(X, u, fabs(tab.xi[0][0]), tab.w[0], D.d12, D.d44, fe, dot);
         } else {
 #pragma unroll
         for (int q = 0; q < NIP; q++) {
@@ -1032,15 +1117,11 @@ __global__ void __launch_bounds__(256, 2) k_ebe_apply(int type, int nel, const i
     // hand-over along the wavefront (every lane takes part in the cross-lane moves): the +x face forces
     // of lane l-1 are added to the -x face nodes of lane l (same global nodes, checked at set-up), and
     // lane l-1 does not store them
-    bool don = false;
     if constexpr (PAIR) {
-        don = (e < (size_t)nel) && donate[e] != 0;
         const bool recv = (__shfl_up((int)don, 1) != 0) && ((threadIdx.x & 63) != 0);
-        constexpr int NP = NPE / 2;
-        constexpr int plus8[4] = {1, 2, 5, 6}, minus8[4] = {0, 3, 4, 7};
 #pragma unroll
         for (int k = 0; k < NP; k++) {
-            const int pa = plus8[k], ma = minus8[k];   // quad4 uses the first two pairs: (1,0) (2,3)
+            const int pa = plus8[k], ma = minus8[k];
 #pragma unroll
             for (int d = 0; d < PD; d++) {
                 const double v = __shfl_up(fe[pa][d], 1);
@@ -1048,10 +1129,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_apply(int type, int nel, const i
             }
         }
     }
-    if (e < (size_t)nel) {
+    if (active) {
 #pragma unroll
         for (int a = 0; a < NPE; a++) {
-            if (PAIR && don && is_plus_x<NPE, PD>(a)) continue;
+            if (PAIR && don && plus_face_x<NPE>(a)) continue;
 #pragma unroll
             for (int d = 0; d < PD; d++) f[(size_t)(a * PD + d) * nel + e] = fe[a][d];   // component-major: coalesced
         }
@@ -1059,7 +1140,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_apply(int type, int nel, const i
     for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (threadIdx.x == 0) partial[blk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // donate[e] = 1 when element e+1 sits in the next lane of the same wavefront and its -x face is e's +x face
@@ -1077,9 +1158,28 @@ __global__ void __launch_bounds__(256) k_ebe_mark_donors(int nel, const int* __r
             ok = ok && conn[(size_t)e * NPE + plus8[k]] == conn[(size_t)(e + 1) * NPE + minus8[k]];
     donate[e] = ok ? 1 : 0;
 }
+// hex8 workgroups (256 elements) whose elements are all parallelepipeds: the test of hex_forces, once per mesh
+__global__ void __launch_bounds__(256) k_ebe_classify_hex8(int nel, const int* __restrict__ conn, const double* __restrict__ coords,
+                                                           double g, unsigned char* __restrict__ blk_affine)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool affine = true;
+    if (e < nel) {
+        const double g8 = 0.125 * g, gg8 = g8 * g;
+        for (int j = 0; j < 3; j++) {
+            double v[8], c0;
+            for (int a = 0; a < 8; a++) v[a] = coords[(size_t)conn[(size_t)e * 8 + a] * 3 + j];
+            const Mono c = hex_mono(v, g8, gg8, c0);
+            const double tol = 0x1p-50 * (fabs(c0) + fabs(c.x) + fabs(c.y) + fabs(c.z));
+            affine = affine && fabs(c.xy) <= tol && fabs(c.xz) <= tol && fabs(c.yz) <= tol && fabs(c.xyz) <= tol;
+        }
+    }
+    const int all = __syncthreads_and(affine ? 1 : 0);
+    if (threadIdx.x == 0) blk_affine[blockIdx.x] = all ? 1 : 0;
+}
 struct DonateViews {
     const unsigned char* d[4];
-    int npe[4], pdim;
+    int npe[4];
 };
 __device__ __forceinline__ bool ebe_entry_kept(const DonateViews& dv, unsigned code)
 {
@@ -1088,7 +1188,7 @@ __device__ __forceinline__ bool ebe_entry_kept(const DonateViews& dv, unsigned c
     if (!d) return true;
     const size_t e = (code & 0x3fffffffu) >> 3;
     const int a = code & 7u;
-    const bool plus = (dv.npe[g] == 8) ? (a == 1 || a == 2 || a == 5 || a == 6) : (a == 1 || a == 2);
+    const bool plus = (dv.npe[g] == 8) ? plus_face_x<8>(a) : plus_face_x<4>(a);
     return !(plus && d[e]);
 }
 // gather lists without the handed-over entries: count, (scan), fill -- order of the sorted lists kept
@@ -1176,23 +1276,39 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
     const bool ebe = (t == "ebe");
     fem_mesh m = A->mesh;
     MatPattern& P = *A->pat;
-    if (ebe && !P.ebe_ready) {   // connectivity-only part: hand-over flags and gather lists, once per mesh
+    if (ebe && !P.ebe_ready) {   // once per mesh: hand-over flags, workgroup classes, gather lists
         FEM_CHECK(A->n2e_ptr.p && A->n2e.p, 5, "fem_mat_set_mult_type: matrix was not created from a mesh");
-        P.ebe_donate.resize(m->groups.size());
+        P.ebe_plan.clear();
+        P.ebe_plan.resize(m->groups.size());
         DonateViews dv{};
-        dv.pdim = m->pdim;
         for (size_t g = 0; g < m->groups.size(); g++) {
             auto& grp = m->groups[g];
+            auto& pl = P.ebe_plan[g];
+            const unsigned nb = cdiv((size_t)grp.nel, 256);
             dv.npe[g] = grp.npe; dv.d[g] = nullptr;
             if (grp.type == FEM_HEX || grp.type == FEM_QUA) {
-                P.ebe_donate[g].alloc((size_t)grp.nel);
+                pl.donate.alloc((size_t)grp.nel);
                 if (grp.type == FEM_HEX)
-                    hipLaunchKernelGGL(k_ebe_mark_donors<8>, dim3(cdiv((size_t)grp.nel, 256)), dim3(256), 0, s, grp.nel,
-                                       grp.conn.p, P.ebe_donate[g].p);
+                    hipLaunchKernelGGL(k_ebe_mark_donors<8>, dim3(nb), dim3(256), 0, s, grp.nel, grp.conn.p, pl.donate.p);
                 else
-                    hipLaunchKernelGGL(k_ebe_mark_donors<4>, dim3(cdiv((size_t)grp.nel, 256)), dim3(256), 0, s, grp.nel,
-                                       grp.conn.p, P.ebe_donate[g].p);
-                dv.d[g] = P.ebe_donate[g].p;
+                    hipLaunchKernelGGL(k_ebe_mark_donors<4>, dim3(nb), dim3(256), 0, s, grp.nel, grp.conn.p, pl.donate.p);
+                dv.d[g] = pl.donate.p;
+            }
+            if (grp.type == FEM_HEX) {   // workgroups of parallelepipeds go to the affine kernel
+                DBuf<unsigned char> cls((size_t)nb);
+                const ElemTable& tab = host_elem_tables()[FEM_HEX];
+                hipLaunchKernelGGL(k_ebe_classify_hex8, dim3(nb), dim3(256), 0, s, grp.nel, grp.conn.p, m->coords.p,
+                                   std::fabs(tab.xi[0][0]), cls.p);
+                std::vector<unsigned char> h_cls((size_t)nb);
+                FEM_HIP(hipMemcpyAsync(h_cls.data(), cls.p, (size_t)nb, hipMemcpyDeviceToHost, s));
+                FEM_HIP(hipStreamSynchronize(s));
+                std::vector<int> ba, bg;
+                for (unsigned b = 0; b < nb; b++) (h_cls[b] ? ba : bg).push_back((int)b);
+                pl.n_affine = (int)ba.size(); pl.n_general = (int)bg.size();
+                pl.blk_affine.alloc(std::max<size_t>(ba.size(), 1)); pl.blk_general.alloc(std::max<size_t>(bg.size(), 1));
+                if (!ba.empty()) FEM_HIP(hipMemcpyAsync(pl.blk_affine.p, ba.data(), ba.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                if (!bg.empty()) FEM_HIP(hipMemcpyAsync(pl.blk_general.p, bg.data(), bg.size() * sizeof(int), hipMemcpyHostToDevice, s));
+                FEM_HIP(hipStreamSynchronize(s));
             }
         }
         {
@@ -1228,36 +1344,62 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
     A->spmv_partial.alloc((size_t)A->spmv_grid);
 }
 
+// profiling: one event before the element kernels and one after each stage of a sampled product
+static void ebe_mark(fem_mat A)
+{
+    if (!A->sampling) return;
+    if (A->pev_used == A->pev.size()) { hipEvent_t e; FEM_HIP(hipEventCreate(&e)); A->pev.push_back(e); }
+    FEM_HIP(hipEventRecord(A->pev[A->pev_used++], A->ctx->stream));
+}
+static EbeViews ebe_views(fem_mat A)
+{
+    EbeViews ev{};
+    for (size_t gi = 0; gi < A->mesh->groups.size(); gi++) { ev.f[gi] = A->ebe_f[gi].p; ev.nel[gi] = A->mesh->groups[gi].nel; }
+    return ev;
+}
+// the element kernels of one product: nodal forces of every element into the buffers, x_e.f_e partials into part[0 .. return)
+int ebe_apply_elements(fem_mat A, const double* x, double* part, const int* done)
+{
+    fem_mesh m = A->mesh;
+    hipStream_t s = A->ctx->stream;
+    A->sampling = A->profiling > 0 && (A->prod_count++ % (size_t)A->profiling) == 0;
+    ebe_mark(A);
+    int off = 0;
+    // FEM_AMD_EBE_VAR (measurement): 0 = Gauss loop against dN/dxi for hex8 too (round 1), 2 = monomial-basis general path for
+    // every hex8 workgroup (no affine kernel, no affine shortcut)
+    static const int var = std::getenv("FEM_AMD_EBE_VAR") ? std::atoi(std::getenv("FEM_AMD_EBE_VAR")) : 1;
+    for (size_t gi = 0; gi < m->groups.size(); gi++) {
+        auto& g = m->groups[gi];
+        auto& pl = A->pat->ebe_plan[gi];
+        const unsigned nb = cdiv((size_t)g.nel, 256);
+        dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto) {
+            auto go = [&](auto kern, unsigned nblk, const int* blocks) {
+                if (!nblk) return;
+                hipLaunchKernelGGL(kern, dim3((nblk + 7) / 8 * 8), dim3(256), 0, s, g.type, g.nel, (int)nblk, blocks, g.conn.p,
+                                   m->coords.p, g.E.p, g.nu.p, x, pl.donate.p, A->ebe_f[gi].p, part + off, done);
+            };
+            if constexpr (NPE() == 8) {
+                if (var == 1) {
+                    go(k_ebe_apply<PD(), NPE(), NIP(), 3>, (unsigned)pl.n_affine, pl.blk_affine.p);
+                    go(k_ebe_apply<PD(), NPE(), NIP(), 1>, (unsigned)pl.n_general, pl.blk_general.p);
+                    return;
+                }
+                if (var == 2) { go(k_ebe_apply<PD(), NPE(), NIP(), 2>, nb, nullptr); return; }
+            }
+            go(k_ebe_apply<PD(), NPE(), NIP(), 0>, nb, nullptr);
+        });
+        off += (int)nb;
+    }
+    ebe_mark(A);
+    return off;
+}
 void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const int* done)
 {
     fem_mesh m = A->mesh;
     hipStream_t s = A->ctx->stream;
     double* part = partial ? partial : A->ebe_partial.p;
-    const bool sample = A->profiling > 0 && (A->prod_count++ % (size_t)A->profiling) == 0;
-    auto mark = [&] {   // profiling: one event before the element kernels and one after each stage
-        if (!sample) return;
-        if (A->pev_used == A->pev.size()) { hipEvent_t e; FEM_HIP(hipEventCreate(&e)); A->pev.push_back(e); }
-        FEM_HIP(hipEventRecord(A->pev[A->pev_used++], s));
-    };
-    mark();
-    EbeViews ev{};
-    int off = 0;
-    for (size_t gi = 0; gi < m->groups.size(); gi++) {
-        auto& g = m->groups[gi];
-        ev.f[gi] = A->ebe_f[gi].p; ev.nel[gi] = g.nel;
-        const unsigned nb = cdiv((size_t)g.nel, 256);
-        dispatch_type(g.type, [&](auto PD, auto NPE, auto NIP, auto) {
-            static const bool mono = !(std::getenv("FEM_AMD_EBE_MONO") && std::atoi(std::getenv("FEM_AMD_EBE_MONO")) == 0);
-            if (mono)
-                hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP(), true>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
-                                   m->coords.p, g.E.p, g.nu.p, x, A->pat->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
-            else
-                hipLaunchKernelGGL((k_ebe_apply<PD(), NPE(), NIP(), false>), dim3(nb), dim3(256), 0, s, g.type, g.nel, g.conn.p,
-                                   m->coords.p, g.E.p, g.nu.p, x, A->pat->ebe_donate[gi].p, A->ebe_f[gi].p, part + off, done);
-        });
-        off += (int)nb;
-    }
-    mark();
+    const int off = ebe_apply_elements(A, x, part, done);
+    const EbeViews ev = ebe_views(A);
     const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
     if (m->pdim == 3)
         hipLaunchKernelGGL(k_ebe_gather<3>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->pat->ebe_ptr.p,
@@ -1265,8 +1407,8 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
     else
         hipLaunchKernelGGL(k_ebe_gather<2>, dim3(cdiv((size_t)m->nnds, 256)), dim3(256), 0, s, m->nnds, A->pat->ebe_ptr.p,
                            A->pat->ebe_lst.p, ev, bcn, A->bc_dof.p, A->bc_shift.p, x, y, part + off, done);
-    mark();
-    mark();   // (the penalty rows used to be a stage of their own: the profile keeps its four marks per product)
+    ebe_mark(A);
+    ebe_mark(A);   // (the penalty rows used to be a stage of their own: the profile keeps its four marks per product)
 }
 
 void mat_set_profiling_impl(fem_mat A, int on)

@@ -89,9 +89,14 @@ struct MatPattern {
     // local column in the same pass (same node at the same local index of two incident elements)
     DBuf<unsigned char> slice_serial;   // [nslices]
     int max_valence = 0;
-    // MatMult by element-by-element recomputation: hand-over flags and gather lists
+    // MatMult by element-by-element recomputation: hand-over flags, workgroup classes, gather lists
     bool ebe_ready = false;
-    std::vector<DBuf<unsigned char>> ebe_donate;   // per group [nel]
+    struct EbePlan {
+        DBuf<unsigned char> donate;          // [nel] hex8 / quad4: the element hands its +x face to the next lane
+        DBuf<int> blk_affine, blk_general;   // hex8: workgroups whose elements are all parallelepipeds / the others
+        int n_affine = 0, n_general = 0;
+    };
+    std::vector<EbePlan> ebe_plan;     // per group
     DBuf<int> ebe_ptr;
     DBuf<unsigned> ebe_lst;
     int ebe_grid = 0;             // workgroups of all element groups + those of the node gather
@@ -130,6 +135,7 @@ struct fem_mat_s {
     std::vector<fem::DBuf<double>> ebe_f;   // per element group: nodal forces [npe*pdim][nel]
     fem::DBuf<double> ebe_partial;          // internal p.Kp partials when the caller wants none
     int ebe_grid = 0;
+    bool sampling = false;                  // the product in flight is one the profile samples
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
     fem::DBuf<int> bc_dof;
     fem::DBuf<double> bc_shift;

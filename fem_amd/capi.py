@@ -492,7 +492,8 @@ class Mat:
         return n.value, a.value, b.value, c.value
 
     def set_mult_type(self, kind: str):
-        """'assembled' (sliced block-ELL SpMV) or 'ebe' (element-by-element recomputation)."""
+        """'assembled' (sliced block-ELL SpMV), 'ebe' (element-by-element recomputation: one-pass tile kernel on a mesh of
+        hex8 elements alone, element buffer + node gather otherwise) or 'ebe_gather' (always the latter)."""
         _ck(_lib.fem_mat_set_mult_type(self.h, kind.encode()))
 
     def mult_timed(self, x: Vec, y: Vec, reps: int) -> float:

@@ -1,0 +1,442 @@
+// fem_amd/csrc/ebe_tile.hip -- MatMult by element-by-element recomputation, one pass: y = K x for a mesh of hex8
+// elements without the element-force buffer of the two-kernel product (elem_kernels.hip: k_ebe_apply + k_ebe_gather,
+// 1.3 GB of traffic per product at config 3, half of it that buffer written and read back).
+//
+// Tiles.  The nodes are binned into boxes (15 x 15 x 7 nodes of a regular grid; any mesh: boxes of the mean element
+// size); a tile OWNS the nodes of its box and computes every element that touches one of them -- the elements of a
+// one-element rim are computed by two (or more) tiles, 1.3x the arithmetic for 16 x 16 x 8 element tiles, and in
+// exchange every owned node receives all of its contributions inside one workgroup: nodal sums live in LDS, y is
+// written once, nothing is exchanged between tiles and nothing is atomic.
+// Order.  The elements of a tile are coloured at set-up (no two elements of a colour share a node; 8 colours on a
+// regular grid) and processed colour by colour with a barrier in between: inside a colour every LDS sum has one writer,
+// so the plain read-add-write is race-free and the order of the additions into a node is fixed -- bitwise reproducible.
+// p.Kp comes from the owned nodes: sum x_i y_i (penalty rows included), one partial per tile.
+// Traffic at config 3: tile lists 0.1 GB + x / coordinates through L2 + E, nu + y = about 0.5 GB.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <memory>
+
+#include "hex8_ebe.h"
+#include "objects.h"
+
+using namespace fem;
+
+namespace fem {
+
+constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
+constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB)
+
+struct EbeTilePlan {
+    int ntiles = 0, n_aff = 0, n_gen = 0, max_nnode = 0;
+    long long tile_elements = 0;         // elements computed per product (rim elements counted once per tile)
+    DBuf<int> hdr;                       // [ntiles*6] node_off, nown, nnode, elem_off, step_off, nsteps
+    DBuf<int2> steps;                    // rounds of <= 256 elements of one colour: {first (relative), count | barrier << 31}
+    DBuf<int> nodes;                     // global node ids of every tile, owned ones first
+    DBuf<int> elems;                     // global element ids of every tile, colour by colour
+    DBuf<uint4> conn16;                  // the same elements' eight tile-local node numbers (16 bit each)
+    DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others
+    DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
+    double t_setup_ms = 0.0;
+};
+
+// What a lane needs of its coming elements is fetched ahead of the arithmetic (two waves per SIMD is all the LDS image of a
+// tile allows, so the latencies have to be covered inside the lane): the index chain -- element id, local numbers, global
+// ids from LDS, E and nu -- two steps ahead, and, registers permitting (the affine kernel), the gathers of x and of the
+// coordinates one step ahead.
+struct TileIdx {
+    uint4 c16;               // eight tile-local node numbers
+    int v[8];                // their global ids
+    double E, nu;            // (general kernel)
+    bool valid;
+};
+struct TileData {
+    double u[8][3];
+    double geo[11];          // a parallelepiped's stored geometry: adj(J) row by row, then the two Lame factors (hex_affine_geom)
+};
+__device__ __forceinline__ int tile_loc(const uint4& c, int a)
+{
+    const unsigned w = a < 2 ? c.x : a < 4 ? c.y : a < 6 ? c.z : c.w;
+    return (a & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
+}
+template <bool AFFINE>
+__device__ __forceinline__ void tile_fetch_idx(TileIdx& in, bool valid, size_t k, const int* __restrict__ telems,
+                                               const uint4* __restrict__ tconn, const int* gl, const double* __restrict__ Ev,
+                                               const double* __restrict__ nuv)
+{
+    in.valid = valid;
+    if (!valid) return;
+    in.c16 = tconn[k];
+    if constexpr (!AFFINE) {
+        const size_t e = (size_t)telems[k];
+        in.E = Ev[e]; in.nu = nuv[e];
+    }
+#pragma unroll
+    for (int a = 0; a < 8; a++) in.v[a] = gl[tile_loc(in.c16, a)];
+}
+__device__ __forceinline__ void tile_fetch_data(TileData& dt, const TileIdx& in, size_t k, const double* __restrict__ geo,
+                                                size_t geo_stride, const double* __restrict__ x)
+{
+    if (!in.valid) return;
+#pragma unroll
+    for (int j = 0; j < 11; j++) dt.geo[j] = geo[(size_t)j * geo_stride + k];
+#pragma unroll
+    for (int a = 0; a < 8; a++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) dt.u[a][d] = x[(size_t)in.v[a] * 3 + d];
+}
+
+// geometry records of the elements of the affine tiles (set-up): geo[j * stride + k], k = position in the tile lists
+__global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __restrict__ telems, const unsigned char* __restrict__ taff,
+                                                   const int* __restrict__ conn, const double* __restrict__ coords,
+                                                   const double* __restrict__ Ev, const double* __restrict__ nuv, double w,
+                                                   double* __restrict__ geo)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntel || !taff[k]) return;
+    const size_t e = (size_t)telems[k];
+    double X[4][3];
+    constexpr int xa[4] = {0, 1, 3, 4};
+    for (int i = 0; i < 4; i++)
+        for (int d = 0; d < 3; d++) X[i][d] = coords[(size_t)conn[e * 8 + xa[i]] * 3 + d];
+    double J[3][3], A[3][3], lw, mw;
+    hex_affine_jac(X[0], X[1], X[2], X[3], J);
+    const DCoef D = dmat_coef(Ev[e], nuv[e]);
+    hex_affine_geom(J, w, D.d12, D.d44, A, lw, mw);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) geo[(size_t)(3 * i + j) * ntel + k] = A[i][j];
+    geo[(size_t)9 * ntel + k] = lw;
+    geo[(size_t)10 * ntel + k] = mw;
+}
+
+// one tile per workgroup.  LDS: acc[3 * nnode] nodal sums, then gl[nnode] global node ids.
+// steps[step_off .. step_off + nsteps): {first element (relative), count | barrier-after << 31}: rounds of 256 elements
+// of one colour, a barrier behind the last round of a colour
+template <bool AFFINE>
+__global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+                                                     const int2* __restrict__ steps, const int* __restrict__ tnodes,
+                                                     const int* __restrict__ telems, const uint4* __restrict__ tconn,
+                                                     const double* __restrict__ coords, const double* __restrict__ Ev,
+                                                     const double* __restrict__ nuv, const double* __restrict__ x,
+                                                     const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
+                                                     const double* __restrict__ bc_shift, const double* __restrict__ geo,
+                                                     size_t geo_stride, double g, double w, int max_nnode,
+                                                     double* __restrict__ y, double* __restrict__ partial,
+                                                     const int* __restrict__ done)
+{
+    if (done && *done) return;
+    extern __shared__ double lds[];
+    __shared__ double sh[4];
+    // workgroups b and b + 8 share an XCD (and its L2): neighbouring tiles, which read the same nodes, go to one XCD
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+    if (lb >= (unsigned)nlist) return;
+    const int t = list[lb];
+    const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
+    const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
+    double* acc = lds;
+    int* gl = reinterpret_cast<int*>(lds + 3 * (size_t)max_nnode);
+    for (int i = threadIdx.x; i < nnode; i += 256) {
+        gl[i] = tnodes[node_off + i];
+        acc[3 * i] = 0.0; acc[3 * i + 1] = 0.0; acc[3 * i + 2] = 0.0;
+    }
+    __syncthreads();
+    auto pos_of = [&](int s) { return (size_t)elem_off + steps[step_off + (s < nsteps ? s : 0)].x + threadIdx.x; };
+    auto idx_of = [&](TileIdx& in, int s) {
+        const bool have = s < nsteps;
+        const int2 st = steps[step_off + (have ? s : 0)];
+        tile_fetch_idx<AFFINE>(in, have && (int)threadIdx.x < (st.y & 0x7fffffff), (size_t)elem_off + st.x + threadIdx.x, telems,
+                               tconn, gl, Ev, nuv);
+    };
+    TileIdx i0, i1, i2;        // steps s, s + 1, s + 2
+    TileData d0, d1;           // steps s, s + 1 (affine kernel)
+    idx_of(i0, 0);
+    idx_of(i1, 1);
+    if constexpr (AFFINE) tile_fetch_data(d0, i0, pos_of(0), geo, geo_stride, x);
+    for (int s = 0; s < nsteps; s++) {
+        const bool bar = steps[step_off + s].y < 0;
+        if constexpr (AFFINE) {
+            idx_of(i2, s + 2);
+            tile_fetch_data(d1, i1, pos_of(s + 1), geo, geo_stride, x);
+        }
+        if (i0.valid) {
+            double fe[8][3], dot;
+            if constexpr (AFFINE) {
+                double A[3][3];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int j = 0; j < 3; j++) A[i][j] = d0.geo[3 * i + j];
+                hex_forces_geom(A, d0.geo[9], d0.geo[10], d0.u, g, fe, dot);
+            } else {
+                double X[8][3], u[8][3];
+#pragma unroll
+                for (int a = 0; a < 8; a++)
+#pragma unroll
+                    for (int d = 0; d < 3; d++) { X[a][d] = coords[(size_t)i0.v[a] * 3 + d]; u[a][d] = x[(size_t)i0.v[a] * 3 + d]; }
+                const DCoef D = dmat_coef(i0.E, i0.nu);
+                hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
+            }
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                const int la = tile_loc(i0.c16, a);
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc[3 * la + d] += fe[a][d];   // one writer per node and colour
+            }
+        }
+        if (bar) __syncthreads();
+        if constexpr (AFFINE) { i0 = i1; i1 = i2; d0 = d1; }
+        else { i0 = i1; idx_of(i1, s + 2); }
+    }
+    double dot = 0.0;
+    for (int i = threadIdx.x; i < nown; i += 256) {
+        const size_t v = (size_t)gl[i];
+        const int kb = bc_node ? bc_node[v] : -1;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double xi = x[v * 3 + d];
+            double s = acc[3 * i + d];
+            if (kb >= 0 && bc_dof[kb + d] >= 0) s += bc_shift[kb + d] * xi;   // ApplyKBC INSERTs on the diagonal only
+            y[v * 3 + d] = s;
+            dot += xi * s;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// the parallelepiped test of hex_forces on the host (same tolerance)
+static bool host_hex_affine(const double (&X)[8][3])
+{
+    for (int j = 0; j < 3; j++) {
+        double v[8];
+        for (int a = 0; a < 8; a++) v[a] = X[a][j];
+        const double s00 = v[1] + v[0], d00 = v[1] - v[0], s10 = v[2] + v[3], d10 = v[2] - v[3];
+        const double s01 = v[5] + v[4], d01 = v[5] - v[4], s11 = v[6] + v[7], d11 = v[6] - v[7];
+        const double ss0 = s10 + s00, sd0 = s10 - s00, ds0 = d10 + d00, dd0 = d10 - d00;
+        const double ss1 = s11 + s01, sd1 = s11 - s01, ds1 = d11 + d01, dd1 = d11 - d01;
+        const double c0 = 0.125 * (ss1 + ss0), cx = 0.125 * (ds1 + ds0), cy = 0.125 * (sd1 + sd0), cz = 0.125 * (ss1 - ss0);
+        // (the device test scales the mixed terms by g <= 1 first: this one is the stricter of the two)
+        const double cxy = 0.125 * (dd1 + dd0), cxz = 0.125 * (ds1 - ds0), cyz = 0.125 * (sd1 - sd0), cxyz = 0.125 * (dd1 - dd0);
+        const double tol = 0x1p-50 * (std::fabs(c0) + std::fabs(cx) + std::fabs(cy) + std::fabs(cz));
+        if (!(std::fabs(cxy) <= tol && std::fabs(cxz) <= tol && std::fabs(cyz) <= tol && std::fabs(cxyz) <= tol)) return false;
+    }
+    return true;
+}
+
+}  // namespace fem
+
+// Builds the plan (host; once per mesh).  Returns nullptr when the mesh is not one group of hex8 elements or a tile
+// would not fit (nodes, colours): the caller keeps the two-kernel product.
+std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
+{
+    if (m->groups.size() != 1 || m->groups[0].type != FEM_HEX || m->pdim != 3) return nullptr;
+    static const bool verbose = std::getenv("FEM_AMD_EBE_VERBOSE") != nullptr;
+    auto refuse = [&](const char* why, long long a = 0, long long b = 0) -> std::shared_ptr<EbeTilePlan> {
+        if (verbose) std::fprintf(stderr, "[fem_amd] ebe tiles: not used (%s %lld %lld)\n", why, a, b);
+        return nullptr;
+    };
+    auto& grp = m->groups[0];
+    const int nel = grp.nel, nn = m->nnds;
+    if (nel < 1) return nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<int> conn((size_t)nel * 8);
+    std::vector<double> xyz((size_t)nn * 3);
+    FEM_HIP(hipMemcpyAsync(conn.data(), grp.conn.p, conn.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    FEM_HIP(hipMemcpyAsync(xyz.data(), m->coords.p, xyz.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    FEM_HIP(hipStreamSynchronize(s));
+    // grid of the mean element size over the bounding box of the nodes; node -> box of NB nodes per direction
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
+    for (int v = 0; v < nn; v++)
+        for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], xyz[(size_t)v * 3 + d]); hi[d] = std::max(hi[d], xyz[(size_t)v * 3 + d]); }
+    std::vector<unsigned char> aff((size_t)nel);
+    for (int e = 0; e < nel; e++) {
+        double X[8][3], mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+        for (int a = 0; a < 8; a++)
+            for (int d = 0; d < 3; d++) {
+                X[a][d] = xyz[(size_t)conn[(size_t)e * 8 + a] * 3 + d];
+                mn[d] = std::min(mn[d], X[a][d]); mx[d] = std::max(mx[d], X[a][d]);
+            }
+        // spacing of the grid the nodes sit on: per direction the longest of the three mean edge vectors of the element
+        // (exact on a regular brick, unbiased under node jitter -- the bounding box of a jittered element is not)
+        for (int d = 0; d < 3; d++) {
+            const double ex = 0.25 * std::fabs((X[1][d] + X[2][d] + X[5][d] + X[6][d]) - (X[0][d] + X[3][d] + X[4][d] + X[7][d]));
+            const double ey = 0.25 * std::fabs((X[3][d] + X[2][d] + X[7][d] + X[6][d]) - (X[0][d] + X[1][d] + X[4][d] + X[5][d]));
+            const double ez = 0.25 * std::fabs((X[4][d] + X[5][d] + X[6][d] + X[7][d]) - (X[0][d] + X[1][d] + X[2][d] + X[3][d]));
+            hsum[d] += std::max(ex, std::max(ey, ez));
+        }
+        (void)mn; (void)mx;
+        aff[e] = host_hex_affine(X) ? 1 : 0;
+    }
+    static const int NB[3] = {15, 15, 7};
+    long long nbox[3];
+    double h[3];
+    for (int d = 0; d < 3; d++) {
+        h[d] = hsum[d] / nel;
+        if (!(h[d] > 0.0)) return refuse("flat mesh");
+        const long long npts = (long long)std::llround((hi[d] - lo[d]) / h[d]) + 1;
+        nbox[d] = (npts + NB[d] - 1) / NB[d];
+    }
+    if ((double)nbox[0] * nbox[1] * nbox[2] > 4.0 * nn + 1024.0) return refuse("grid does not describe the mesh");
+    auto box_of = [&](int v) {
+        long long b[3];
+        for (int d = 0; d < 3; d++) {
+            long long i = std::llround((xyz[(size_t)v * 3 + d] - lo[d]) / h[d]);
+            b[d] = std::min(std::max(i / NB[d], 0LL), nbox[d] - 1);
+        }
+        return b[0] + nbox[0] * (b[1] + nbox[1] * b[2]);
+    };
+    // nodes sorted by box (counting sort: ascending node id inside a box)
+    const long long nboxes = nbox[0] * nbox[1] * nbox[2];
+    std::vector<long long> nbx((size_t)nn);
+    std::vector<int> bstart((size_t)nboxes + 1, 0);
+    for (int v = 0; v < nn; v++) { nbx[v] = box_of(v); bstart[(size_t)nbx[v] + 1]++; }
+    for (long long b = 0; b < nboxes; b++) bstart[b + 1] += bstart[b];
+    std::vector<int> border((size_t)nn), bfill(bstart.begin(), bstart.end() - 1);
+    for (int v = 0; v < nn; v++) border[(size_t)bfill[nbx[v]]++] = v;
+    // node -> elements
+    std::vector<int> nptr((size_t)nn + 1, 0), nlst((size_t)nel * 8);
+    for (size_t k = 0; k < conn.size(); k++) nptr[(size_t)conn[k] + 1]++;
+    for (int v = 0; v < nn; v++) nptr[v + 1] += nptr[v];
+    {
+        std::vector<int> f(nptr.begin(), nptr.end() - 1);
+        for (int e = 0; e < nel; e++)
+            for (int a = 0; a < 8; a++) nlst[(size_t)f[conn[(size_t)e * 8 + a]]++] = e;
+    }
+    auto plan = std::make_shared<EbeTilePlan>();
+    std::vector<int> hdr, tnodes, telems;
+    std::vector<int2> steps;
+    int tnodes_off = 0;
+    std::vector<uint4> tconn;
+    std::vector<int> laff, lgen;
+    std::vector<int> estamp((size_t)nel, -1), nstamp((size_t)nn, -1), local((size_t)nn, 0);
+    std::vector<unsigned> cmask;
+    std::vector<int> el, nd, col, order;
+    int ntiles = 0, max_nnode = 0;
+    for (long long b = 0; b < nboxes; b++) {
+        const int o0 = bstart[b], o1 = bstart[b + 1];
+        if (o0 == o1) continue;
+        const int t = ntiles++;
+        el.clear(); nd.clear();
+        for (int k = o0; k < o1; k++) {   // owned nodes first (ascending ids), and the elements that touch them
+            const int v = border[k];
+            nstamp[v] = t; local[v] = (int)nd.size(); nd.push_back(v);
+            for (int q = nptr[v]; q < nptr[v + 1]; q++)
+                if (estamp[nlst[q]] != t) { estamp[nlst[q]] = t; el.push_back(nlst[q]); }
+        }
+        const int nown = (int)nd.size();
+        std::sort(el.begin(), el.end());
+        size_t rim0 = nd.size();
+        for (int e : el)
+            for (int a = 0; a < 8; a++) {
+                const int v = conn[(size_t)e * 8 + a];
+                if (nstamp[v] != t) { nstamp[v] = t; nd.push_back(v); }
+            }
+        std::sort(nd.begin() + rim0, nd.end());
+        for (size_t i = rim0; i < nd.size(); i++) local[nd[i]] = (int)i;
+        if ((int)nd.size() > TILE_MAX_NODES || nd.size() > 65535) return refuse("tile with too many nodes", (long long)nd.size(), nown);
+        // greedy colouring in element order
+        cmask.assign(nd.size(), 0u);
+        col.resize(el.size());
+        int ncol = 0;
+        bool all_aff = true;
+        for (size_t i = 0; i < el.size(); i++) {
+            unsigned used = 0;
+            for (int a = 0; a < 8; a++) used |= cmask[local[conn[(size_t)el[i] * 8 + a]]];
+            int c = 0;
+            while (c < TILE_MAXC && ((used >> c) & 1u)) c++;
+            if (c >= TILE_MAXC) return refuse("too many colours");
+            col[i] = c; ncol = std::max(ncol, c + 1);
+            for (int a = 0; a < 8; a++) cmask[local[conn[(size_t)el[i] * 8 + a]]] |= 1u << c;
+            all_aff = all_aff && aff[el[i]];
+        }
+        const int elem_off = (int)telems.size(), step_off = (int)steps.size();
+        tnodes_off = (int)tnodes.size();
+        tnodes.insert(tnodes.end(), nd.begin(), nd.end());
+        for (int c = 0; c < ncol; c++) {
+            const int first = (int)telems.size() - elem_off;
+            for (size_t i = 0; i < el.size(); i++)
+                if (col[i] == c) {
+                    telems.push_back(el[i]);
+                    unsigned l[8];
+                    for (int a = 0; a < 8; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * 8 + a]];
+                    tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
+                }
+            const int cnt = (int)telems.size() - elem_off - first;
+            for (int r = 0; r < cnt; r += 256) {
+                const int n = std::min(256, cnt - r);
+                steps.push_back(make_int2(first + r, (r + 256 >= cnt) ? (int)((unsigned)n | 0x80000000u) : n));
+            }
+        }
+        hdr.push_back(tnodes_off); hdr.push_back(nown); hdr.push_back((int)nd.size()); hdr.push_back(elem_off);
+        hdr.push_back(step_off); hdr.push_back((int)steps.size() - step_off);
+        max_nnode = std::max(max_nnode, (int)nd.size());
+        (all_aff ? laff : lgen).push_back(t);
+    }
+    plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->max_nnode = max_nnode;
+    plan->tile_elements = (long long)telems.size();
+    auto up = [&](auto& dbuf, const auto& vec) {
+        dbuf.alloc(std::max<size_t>(vec.size(), 1));
+        if (!vec.empty())
+            FEM_HIP(hipMemcpyAsync(dbuf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
+    };
+    up(plan->hdr, hdr); up(plan->steps, steps); up(plan->nodes, tnodes); up(plan->elems, telems); up(plan->conn16, tconn);
+    up(plan->list_aff, laff); up(plan->list_gen, lgen);
+    if (!laff.empty()) {   // geometry records of the affine tiles' elements
+        std::vector<unsigned char> taff(telems.size(), 0);
+        for (int t : laff) {
+            const int e0 = hdr[6 * (size_t)t + 3];
+            const int e1 = (t + 1 < ntiles) ? hdr[6 * (size_t)(t + 1) + 3] : (int)telems.size();
+            std::fill(taff.begin() + e0, taff.begin() + e1, 1);
+        }
+        DBuf<unsigned char> d_taff;
+        up(d_taff, taff);
+        plan->geo.alloc(telems.size() * 11);
+        const ElemTable& tab = host_elem_tables()[FEM_HEX];
+        hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((telems.size() + 255) / 256)), dim3(256), 0, s, telems.size(), plan->elems.p,
+                           d_taff.p, grp.conn.p, m->coords.p, grp.E.p, grp.nu.p, tab.w[0], plan->geo.p);
+        FEM_HIP(hipStreamSynchronize(s));
+    }
+    FEM_HIP(hipStreamSynchronize(s));
+    plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (verbose)
+        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine), <= %d nodes, %lld element visits for %d elements, %zu steps, set-up %.0f ms\n",
+                     ntiles, plan->n_aff, max_nnode, plan->tile_elements, nel, steps.size(), plan->t_setup_ms);
+    return plan;
+}
+
+int ebe_tile_partials(const EbeTilePlan& P) { return P.ntiles; }
+double ebe_tile_setup_ms(const EbeTilePlan& P) { return P.t_setup_ms; }
+long long ebe_tile_elements(const EbeTilePlan& P) { return P.tile_elements; }
+
+// y = K x, p.Kp partials into part[0 .. ntiles)
+void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done)
+{
+    fem_mesh m = A->mesh;
+    hipStream_t s = A->ctx->stream;
+    auto& grp = m->groups[0];
+    const ElemTable& tab = host_elem_tables()[FEM_HEX];
+    const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
+    const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
+    const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
+    static bool attr_set = false;
+    if (!attr_set) {
+        FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(TILE_MAX_NODES * 28)));
+        FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(TILE_MAX_NODES * 28)));
+        attr_set = true;
+    }
+    if (P.n_aff)
+        hipLaunchKernelGGL(k_ebe_tile<true>, dim3((P.n_aff + 7) / 8 * 8), dim3(256), shmem, s, P.n_aff, P.list_aff.p, P.hdr.p,
+                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
+                           A->bc_shift.p, P.geo.p, (size_t)P.tile_elements, g, w, P.max_nnode, y, part, done);
+    if (P.n_gen)
+        hipLaunchKernelGGL(k_ebe_tile<false>, dim3((P.n_gen + 7) / 8 * 8), dim3(256), shmem, s, P.n_gen, P.list_gen.p, P.hdr.p,
+                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
+                           A->bc_shift.p, P.geo.p, (size_t)P.tile_elements, g, w, P.max_nnode, y, part, done);
+}

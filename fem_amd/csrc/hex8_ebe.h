@@ -1,0 +1,346 @@
+// fem_amd/csrc/hex8_ebe.h -- K_e x_e of one hex8 element without K_e: the device functions shared by the
+// element-by-element MatMult kernels (elem_kernels.hip: element buffer + node gather; ebe_tile.hip: tiles with the nodal
+// sums in LDS).  Reference arithmetic: FormElKE (src/m_local.F90:21-67) applied to a vector, 2x2x2 Gauss rule.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace fem {
+
+// hex8: the same product in the monomial basis of the trilinear element (sum factorisation written out).
+//   v(xi) = c0 + cx xi + cy eta + cz zeta + cxy xi eta + cxz xi zeta + cyz eta zeta + cxyz xi eta zeta
+// Eight nodal values become seven coefficients by a three-stage butterfly (c0 never enters a gradient); at the Gauss
+// point (s1 g, s2 g, s3 g) of the 2x2x2 rule the reference gradient of a field is three signed sums of coefficients
+// that carry their powers of g, shared between points with equal signs, instead of 24 multiply-adds against dN/dxi;
+// the element forces are accumulated as the seven moments of T against the gradients of the monomials and go back to
+// nodal values by the transposed butterfly.  ~1,550 fp64 instructions per element instead of ~2,750.
+//   H' = adj(J) G and T = (w/det) D eps(H') adj(J): the inverse Jacobian itself is never formed.
+struct Mono { double x, y, z, xy, xz, yz, xyz; };
+
+__device__ __forceinline__ Mono hex_mono(const double (&v)[8], double g8, double gg8, double& c0)
+{
+    // stage xi
+    const double s00 = v[1] + v[0], d00 = v[1] - v[0];   // (eta-, zeta-)
+    const double s10 = v[2] + v[3], d10 = v[2] - v[3];   // (eta+, zeta-)
+    const double s01 = v[5] + v[4], d01 = v[5] - v[4];   // (eta-, zeta+)
+    const double s11 = v[6] + v[7], d11 = v[6] - v[7];   // (eta+, zeta+)
+    // stage eta
+    const double ss0 = s10 + s00, sd0 = s10 - s00, ds0 = d10 + d00, dd0 = d10 - d00;
+    const double ss1 = s11 + s01, sd1 = s11 - s01, ds1 = d11 + d01, dd1 = d11 - d01;
+    // stage zeta, with 1/8 and the powers of g the gradients at the Gauss points need
+    Mono c;
+    c.x = 0.125 * (ds1 + ds0);
+    c.y = 0.125 * (sd1 + sd0);
+    c.z = 0.125 * (ss1 - ss0);
+    c.xy = g8 * (dd1 + dd0);
+    c.xz = g8 * (ds1 - ds0);
+    c.yz = g8 * (sd1 - sd0);
+    c.xyz = gg8 * (dd1 - dd0);
+    c0 = 0.125 * (ss1 + ss0);
+    return c;
+}
+
+// T[l][j] = (w / det J) * sum_i (D eps(adj(J) G))[l][i] adj(J)[i][j] at one Gauss point: the nodal forces are
+// f_a[l] += sum_j T[l][j] dN_a/dxi_j
+__device__ __forceinline__ void hex_point_T(const double (&J)[3][3], const double (&G)[3][3], double w, double lam, double mu,
+                                            double (&T)[3][3])
+{
+    double adj[3][3];   // adj[i][j] = det * d xi_j / d x_i
+    adj[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    adj[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    adj[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    adj[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    adj[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    adj[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    adj[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    adj[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    adj[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double det = J[0][0] * adj[0][0] + J[0][1] * adj[1][0] + J[0][2] * adj[2][0];
+    double rd = __builtin_amdgcn_rcp(det);      // two Newton steps: full double precision
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    double H[3][3];                             // H[l][i] = det * d u_l / d x_i
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) H[l][i] = adj[i][0] * G[0][l] + adj[i][1] * G[1][l] + adj[i][2] * G[2][l];
+    // DMat (src/m_local.F90:204) as lambda, mu; one factor 1/det from H, one from adj, w det from the quadrature
+    const double wr = w * rd;
+    const double lw = lam * wr, mw = mu * wr, m2 = mw + mw;
+    const double lt = lw * ((H[0][0] + H[1][1]) + H[2][2]);
+    double S[3][3];
+    S[0][0] = fma(m2, H[0][0], lt);
+    S[1][1] = fma(m2, H[1][1], lt);
+    S[2][2] = fma(m2, H[2][2], lt);
+    S[0][1] = S[1][0] = mw * (H[0][1] + H[1][0]);
+    S[1][2] = S[2][1] = mw * (H[1][2] + H[2][1]);
+    S[0][2] = S[2][0] = mw * (H[2][0] + H[0][2]);
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[l][j] = S[l][0] * adj[0][j] + S[l][1] * adj[1][j] + S[l][2] * adj[2][j];
+}
+
+// the two Gauss points (s1 g, s2 g, -+g): signs s1, s2 are run-time wave-uniform values of a rolled loop (the live set
+// stays at coefficients + moments + one pair's temporaries), the zeta sign is written out so that the pair shares the
+// partial sums of its gradients and of its moments
+__device__ __forceinline__ void hex_pair(double s1, double s2, const Mono (&cX)[3], const Mono (&cU)[3], double w, double lam,
+                                         double mu, Mono (&F)[3])
+{
+    double Jm[3][3], Jp[3][3], Gm[3][3], Gp[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        {
+            const Mono& c = cX[j];
+            const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+            const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+            Jm[0][j] = B1 - B2; Jp[0][j] = B1 + B2;
+            Jm[1][j] = A1 - A2; Jp[1][j] = A1 + A2;
+            Jm[2][j] = Jp[2][j] = fma(s2, A2, A3);
+        }
+        {
+            const Mono& c = cU[j];
+            const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+            const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+            Gm[0][j] = B1 - B2; Gp[0][j] = B1 + B2;
+            Gm[1][j] = A1 - A2; Gp[1][j] = A1 + A2;
+            Gm[2][j] = Gp[2][j] = fma(s2, A2, A3);
+        }
+    }
+    double Tm[3][3], Tp[3][3];
+    hex_point_T(Jm, Gm, w, lam, mu, Tm);
+    hex_point_T(Jp, Gp, w, lam, mu, Tp);
+    const double s12 = s1 * s2;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        const double U0 = Tp[l][0] + Tm[l][0], U1 = Tp[l][1] + Tm[l][1], U2 = Tp[l][2] + Tm[l][2];
+        const double V0 = Tp[l][0] - Tm[l][0], V1 = Tp[l][1] - Tm[l][1];
+        F[l].x += U0;
+        F[l].y += U1;
+        F[l].z += U2;
+        F[l].xy = fma(s1, U1, fma(s2, U0, F[l].xy));
+        F[l].xz = fma(s1, U2, F[l].xz + V0);
+        F[l].yz = fma(s2, U2, F[l].yz + V1);
+        F[l].xyz = fma(s12, U2, fma(s1, V1, fma(s2, V0, F[l].xyz)));
+    }
+}
+
+// Parallelepipeds (constant Jacobian -- the "affine cell" class of matrix-free finite-element codes): adj(J), det J and so the
+// map L: G -> T are the same at the eight Gauss points, T(q) = sum_p p(q) L(G_p) over the seven sign patterns p of the
+// gradient of a trilinear field, and the sum over the points keeps, for every moment, the pattern(s) of that monomial's own
+// gradient (the sign patterns are orthogonal over the 2x2x2 rule: sum_q p(q) p'(q) = 8 [p = p']).  Seven sparse
+// applications of L instead of eight full ones.
+//   RM: rows of G that are not zero, CM: columns of T that are wanted (bit i = row / column i)
+template <int RM, int CM>
+__device__ __forceinline__ void affine_T(const double (&A)[3][3], const double (&G)[3][3], double lw, double mw, double m2,
+                                         double (&T)[3][3])
+{
+    double H[3][3];
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double h = 0.0;
+            bool first = true;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                if ((RM >> j) & 1) { h = first ? A[i][j] * G[j][l] : fma(A[i][j], G[j][l], h); first = false; }
+            H[l][i] = h;
+        }
+    const double lt = lw * ((H[0][0] + H[1][1]) + H[2][2]);
+    double S[3][3];
+    S[0][0] = fma(m2, H[0][0], lt);
+    S[1][1] = fma(m2, H[1][1], lt);
+    S[2][2] = fma(m2, H[2][2], lt);
+    S[0][1] = S[1][0] = mw * (H[0][1] + H[1][0]);
+    S[1][2] = S[2][1] = mw * (H[1][2] + H[2][1]);
+    S[0][2] = S[2][0] = mw * (H[2][0] + H[0][2]);
+#pragma unroll
+    for (int l = 0; l < 3; l++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            if ((CM >> j) & 1) T[l][j] = S[l][0] * A[0][j] + S[l][1] * A[1][j] + S[l][2] * A[2][j];
+}
+
+// geometry of a parallelepiped: A = adj(J) (A[i][j] = det * d xi_j / d x_i) and the two Lame factors with the quadrature
+// weight of all eight points and 1/det folded in
+__device__ __forceinline__ void hex_affine_geom(const double (&J)[3][3], double w, double lam, double mu, double (&A)[3][3],
+                                                double& lw, double& mw)
+{
+    A[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    A[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    A[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    A[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    A[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    A[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    A[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    A[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    A[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double det = J[0][0] * A[0][0] + J[0][1] * A[1][0] + J[0][2] * A[2][0];
+    double rd = __builtin_amdgcn_rcp(det);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    const double wr = 8.0 * w * rd;   // eight points of equal weight
+    lw = lam * wr; mw = mu * wr;
+}
+// Jacobian of a parallelepiped from one corner and its three neighbours (nodes 0, 1, 3, 4)
+__device__ __forceinline__ void hex_affine_jac(const double (&X0)[3], const double (&X1)[3], const double (&X3)[3],
+                                               const double (&X4)[3], double (&J)[3][3])
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        J[0][j] = 0.5 * (X1[j] - X0[j]);
+        J[1][j] = 0.5 * (X3[j] - X0[j]);
+        J[2][j] = 0.5 * (X4[j] - X0[j]);
+    }
+}
+
+__device__ __forceinline__ void hex_affine_apply(const double (&A)[3][3], double lw, double mw, const Mono (&cU)[3],
+                                                 Mono (&F)[3])
+{
+    const double m2 = mw + mw;
+    double G[3][3], T[3][3];
+    // pattern 1: G = (c.x, c.y, c.z) -> moments x, y, z
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].x; G[1][l] = cU[l].y; G[2][l] = cU[l].z; }
+    affine_T<7, 7>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].x = T[l][0]; F[l].y = T[l][1]; F[l].z = T[l][2]; }
+    // pattern s1 (sign of xi): G = (0, c.xy, c.xz) -> second terms of xy and xz
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[1][l] = cU[l].xy; G[2][l] = cU[l].xz; }
+    affine_T<6, 6>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xy = T[l][1]; F[l].xz = T[l][2]; }
+    // pattern s2: G = (c.xy, 0, c.yz) -> first term of xy, second of yz
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].xy; G[2][l] = cU[l].yz; }
+    affine_T<5, 5>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xy += T[l][0]; F[l].yz = T[l][2]; }
+    // pattern s3: G = (c.xz, c.yz, 0) -> first terms of xz and yz
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].xz; G[1][l] = cU[l].yz; }
+    affine_T<3, 3>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xz += T[l][0]; F[l].yz += T[l][1]; }
+    // patterns s2 s3, s1 s3, s1 s2: the xyz coefficient in one row -> the three terms of xyz
+#pragma unroll
+    for (int l = 0; l < 3; l++) G[0][l] = G[1][l] = G[2][l] = cU[l].xyz;
+    affine_T<1, 1>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz = T[l][0];
+    affine_T<2, 2>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz += T[l][1];
+    affine_T<4, 4>(A, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz += T[l][2];
+}
+
+__device__ __forceinline__ void hex_affine(const double (&J)[3][3], const Mono (&cU)[3], double w, double lam, double mu,
+                                           Mono (&F)[3])
+{
+    double A[3][3], lw, mw;
+    hex_affine_geom(J, w, lam, mu, A, lw, mw);
+    hex_affine_apply(A, lw, mw, cU, F);
+}
+
+
+// moments -> nodal forces (the transposed butterfly) and x_e . f_e
+__device__ __forceinline__ void hex_finish(const Mono (&cU)[3], const Mono (&F)[3], double g8, double gg8, double (&fe)[8][3],
+                                           double& dot)
+{
+    double d = 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        // x_e . f_e in the monomial basis: the butterflies are orthogonal up to the factor 8 the scalings carry
+        d += cU[l].x * F[l].x + cU[l].y * F[l].y + cU[l].z * F[l].z + cU[l].xy * F[l].xy + cU[l].xz * F[l].xz +
+             cU[l].yz * F[l].yz + cU[l].xyz * F[l].xyz;
+        // moments -> nodal forces: f_a = 1/8 sum_m (sign pattern of monomial m at node a) * moment_m
+        const double P = 0.125 * F[l].x, Q = 0.125 * F[l].y, R = 0.125 * F[l].z;
+        const double PQ = g8 * F[l].xy, PR = g8 * F[l].xz, QR = g8 * F[l].yz, PQR = gg8 * F[l].xyz;
+        // zeta, then eta, then xi
+        const double a10m = P - PR, a10p = P + PR, a01m = Q - QR, a01p = Q + QR, a11m = PQ - PQR, a11p = PQ + PQR;
+        const double b0mm = -R - a01m, b0pm = -R + a01m, b0mp = R - a01p, b0pp = R + a01p;      // [eta][zeta]
+        const double b1mm = a10m - a11m, b1pm = a10m + a11m, b1mp = a10p - a11p, b1pp = a10p + a11p;
+        fe[0][l] = b0mm - b1mm; fe[1][l] = b0mm + b1mm;   // (xi-+, eta-, zeta-)
+        fe[3][l] = b0pm - b1pm; fe[2][l] = b0pm + b1pm;   // eta+, zeta-
+        fe[4][l] = b0mp - b1mp; fe[5][l] = b0mp + b1mp;   // eta-, zeta+
+        fe[7][l] = b0pp - b1pp; fe[6][l] = b0pp + b1pp;   // eta+, zeta+
+    }
+    dot = d;
+}
+
+// a parallelepiped known as such from the set-up (same test as in hex_forces, once per mesh): the Jacobian is read off
+// three edges of one corner
+__device__ __forceinline__ void hex_forces_affine(const double (&X)[8][3], const double (&u)[8][3], double g, double w,
+                                                  double lam, double mu, double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cU[3], F[3];
+    double J[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+    }
+    hex_affine_jac(X[0], X[1], X[3], X[4], J);
+    hex_affine(J, cU, w, lam, mu, F);
+    hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
+// nodal forces of a parallelepiped from its stored geometry (hex_affine_geom) and the nodal values u
+__device__ __forceinline__ void hex_forces_geom(const double (&A)[3][3], double lw, double mw, const double (&u)[8][3], double g,
+                                                double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cU[3], F[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+    }
+    hex_affine_apply(A, lw, mw, cU, F);
+    hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
+// nodal forces fe and x_e . f_e of one hex8 from nodal coordinates X and values u (2x2x2 Gauss rule: points +-g, weight w)
+template <bool AFFINE_PATH>
+__device__ __forceinline__ void hex_forces(const double (&X)[8][3], const double (&u)[8][3], double g, double w, double lam,
+                                           double mu, double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cX[3], cU[3], F[3];
+    bool affine = true;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = X[a][j];
+        cX[j] = hex_mono(v, g8, gg8, c0);
+        // mixed terms below the rounding noise of the coordinates themselves (2^-50 of their magnitude): a parallelepiped
+        const double tol = 0x1p-50 * (fabs(c0) + fabs(cX[j].x) + fabs(cX[j].y) + fabs(cX[j].z));
+        affine = affine && fabs(cX[j].xy) <= tol && fabs(cX[j].xz) <= tol && fabs(cX[j].yz) <= tol && fabs(cX[j].xyz) <= tol;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+    }
+    if (AFFINE_PATH && __all(affine)) {
+        double J[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { J[0][j] = cX[j].x; J[1][j] = cX[j].y; J[2][j] = cX[j].z; }
+        hex_affine(J, cU, w, lam, mu, F);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) F[j] = Mono{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(disable)
+        for (int q = 0; q < 4; q++) hex_pair((q & 1) ? 1.0 : -1.0, (q & 2) ? 1.0 : -1.0, cX, cU, w, lam, mu, F);
+    }
+    hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
+}  // namespace fem

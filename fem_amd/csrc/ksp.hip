@@ -376,7 +376,8 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-pc_mg_slice_min") { is >> k->mg_slice_min; }   // partitioned meshes: see mg.h     // Jacobi damping of the smoother
         else if (key == "-mat_mult_type") {
             is >> val;
-            FEM_CHECK(val == "assembled" || val == "ebe", 6, "unsupported -mat_mult_type " + val + " (assembled|ebe)");
+            FEM_CHECK(val == "assembled" || val == "ebe" || val == "ebe_gather", 6,
+                      "unsupported -mat_mult_type " + val + " (assembled|ebe|ebe_gather)");
             k->mult_type = val;
         }
         else if (key == "-ksp_rtol") { is >> k->rtol; }

@@ -67,6 +67,8 @@ struct fem_vec_s {
 
 namespace fem {
 
+struct EbeTilePlan;   // ebe_tile.hip
+
 // Everything about Mat_K that depends on the connectivity alone (the product of MatCreateAIJ's
 // preallocation, src/main.F90:153-156, and of the implicit pattern growth of MatSetValues): built once
 // per mesh by the symbolic phase and shared by every Mat created from that mesh -- the reference, too,
@@ -97,6 +99,8 @@ struct MatPattern {
         int n_affine = 0, n_general = 0;
     };
     std::vector<EbePlan> ebe_plan;     // per group
+    std::shared_ptr<EbeTilePlan> ebe_tile;   // one-pass product by tiles (ebe_tile.hip); null: not built or not applicable
+    bool ebe_tile_tried = false;
     DBuf<int> ebe_ptr;
     DBuf<unsigned> ebe_lst;
     int ebe_grid = 0;             // workgroups of all element groups + those of the node gather
@@ -136,6 +140,7 @@ struct fem_mat_s {
     fem::DBuf<double> ebe_partial;          // internal p.Kp partials when the caller wants none
     int ebe_grid = 0;
     bool sampling = false;                  // the product in flight is one the profile samples
+    bool ebe_use_tile = false;              // `ebe`: one-pass tile product when the mesh allows it; `ebe_gather`: never
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
     fem::DBuf<int> bc_dof;
     fem::DBuf<double> bc_shift;

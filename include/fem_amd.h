@@ -172,7 +172,9 @@ int fem_mat_get_csr(fem_mat mat, int *rowptr, int *colind, double *val);
 /* How MatMult is carried out.  "assembled" (default): sliced block-ELL SpMV over the stored blocks.
  * "ebe": element-by-element recomputation from the mesh (PETSc's MATSHELL idea: same operator, no
  * matrix read; needs the usual assemble + ApplyKBC first, which also serve the preconditioners);
- * deterministic, about twice as fast as the SpMV on hex8 meshes.  Also `-mat_mult_type` of the KSP. */
+ * deterministic, about four times as fast as the SpMV on hex8 meshes.  On a mesh of hex8 elements alone the product is
+ * one pass over tiles of elements with the nodal sums in LDS; every other mesh -- and "ebe_gather" on any mesh -- writes
+ * element forces to a buffer and sums them node by node.  Also `-mat_mult_type` of the KSP. */
 int fem_mat_set_mult_type(fem_mat mat, const char *type);
 /* HIP-event profile of the element-by-element product on the product's own stream.  on = 0: off;
  * on = p > 0: every p-th product is bracketed by events (p = 1: all of them).  get_profile sums over
@@ -226,7 +228,7 @@ int fem_ksp_set_pc_type(fem_ksp ksp, const char *type);
 int fem_ksp_set_tolerances(fem_ksp ksp, double rtol, double abstol, double dtol, int maxits);
 /* KSPSetFromOptions :377: parses "-ksp_type cg|bcgs|preonly -pc_type jacobi|none|mg|gamg|lu|cholesky
  * -ksp_rtol 1e-12 -ksp_atol .. -ksp_divtol .. -ksp_max_it .. -pc_mg_type multiplicative|additive
- * -pc_mg_alpha .. -pc_mg_omega .. -pc_mg_box .. -pc_mg_slice_min .. -mat_mult_type assembled|ebe" */
+ * -pc_mg_alpha .. -pc_mg_omega .. -pc_mg_box .. -pc_mg_slice_min .. -mat_mult_type assembled|ebe|ebe_gather" */
 int fem_ksp_set_from_options(fem_ksp ksp, const char *options);
 int fem_ksp_set_up(fem_ksp ksp);                            /* KSPSetUp :378 */
 int fem_ksp_solve(fem_ksp ksp, fem_vec b, fem_vec x);       /* KSPSolve :247 (zero initial guess) */

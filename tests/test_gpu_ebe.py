@@ -37,6 +37,8 @@ def _meshes():
         "tet": hex_to_tets(structured_hex(4, 3, 3, jitter=0.15)),
         "mixed_tri_qua": quad_to_mixed(structured_quad(8, 5, jitter=0.1)),
         "hex300": structured_hex(7, 7, 6, jitter=0.1),            # more than one 256-element workgroup
+        "hex_tiles": structured_hex(33, 20, 17, jitter=0.12),      # several tiles of the one-pass product, ragged ones included
+        "hex_tiles_flat": structured_hex(40, 35, 3),               # tiles thinner than their box; parallelepipeds (stored geometry)
     }
 
 
@@ -63,6 +65,15 @@ def test_ebe_product_matches_assembled_product_and_oracle(gpu_ctx, oracle, name)
     row_scale = np.abs(oracle.spmv(rp, ci, np.abs(vr), np.abs(x)))
     assert (np.abs(ye - yr) <= 1e-13 * row_scale).all()
     assert (np.abs(ye - Ya.get_array()) <= 1e-13 * row_scale).all()
+    # the two forms of the product -- `ebe` takes the one-pass tile kernel on a mesh of hex8 alone and the element buffer
+    # + node gather everywhere else, `ebe_gather` always the latter -- agree, and each is reproducible
+    K.set_mult_type("ebe_gather")
+    K.mult(X, Ye)
+    yg = Ye.get_array()
+    K.mult(X, Ye)
+    assert np.array_equal(yg, Ye.get_array())
+    assert (np.abs(yg - yr) <= 1e-13 * row_scale).all()
+    assert (np.abs(yg - ye) <= 1e-13 * row_scale).all()
     K.set_mult_type("assembled")
     K.mult(X, Ye)
     assert np.array_equal(Ye.get_array(), Ya.get_array())

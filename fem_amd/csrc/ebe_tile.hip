@@ -28,55 +28,96 @@ using namespace fem;
 namespace fem {
 
 constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
-constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB)
+constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB); <= 12 * 256
 
 struct EbeTilePlan {
     int ntiles = 0, n_aff = 0, n_gen = 0, max_nnode = 0;
     long long tile_elements = 0;         // elements computed per product (rim elements counted once per tile)
+    long long slots = 0;                 // lanes of all steps (elements + the padding of 16-lane rows)
     DBuf<int> hdr;                       // [ntiles*6] node_off, nown, nnode, elem_off, step_off, nsteps
     DBuf<int2> steps;                    // rounds of <= 256 elements of one colour: {first (relative), count | barrier << 31}
     DBuf<int> nodes;                     // global node ids of every tile, owned ones first
-    DBuf<int> elems;                     // global element ids of every tile, colour by colour
+    DBuf<int> elems;                     // [slots] global element id of every lane slot, colour by colour; -1 = padding
     DBuf<uint4> conn16;                  // the same elements' eight tile-local node numbers (16 bit each)
+    DBuf<unsigned char> flags;           // [slots] bit 0: the element's +x face is the -x face of the next lane's element
     DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
     double t_setup_ms = 0.0;
 };
 
 // What a lane needs of its coming elements is fetched ahead of the arithmetic (two waves per SIMD is all the LDS image of a
-// tile allows, so the latencies have to be covered inside the lane): the index chain -- element id, local numbers, global
-// ids from LDS, E and nu -- two steps ahead, and, registers permitting (the affine kernel), the gathers of x and of the
-// coordinates one step ahead.
+// tile allows, so the latencies have to be covered inside the lane): the index chain -- local numbers, global ids from
+// LDS, E and nu -- two steps ahead, and, registers permitting (the affine kernel), the gathers of x and the stored geometry
+// one step ahead.
+// Chains.  The lanes of a 16-lane row hold runs of elements whose +x face is the next lane's -x face (set-up): such a lane
+// loads only its -x face nodes and takes the others from the next lane (DPP row shift), and hands its +x face forces to
+// the next lane instead of adding them to LDS itself -- half the gathers, half the LDS traffic, and consecutive lanes read
+// consecutive nodes.
 struct TileIdx {
     uint4 c16;               // eight tile-local node numbers
-    int v[8];                // their global ids
+    int v[8];                // their global ids (+x face: only where the chain ends)
     double E, nu;            // (general kernel)
+    unsigned fl;             // bit 0: linked to the next lane
     bool valid;
 };
 struct TileData {
     double u[8][3];
     double geo[11];          // a parallelepiped's stored geometry: adj(J) row by row, then the two Lame factors (hex_affine_geom)
 };
+__device__ constexpr int c_tplus[4] = {1, 2, 5, 6}, c_tminus[4] = {0, 3, 4, 7};
 __device__ __forceinline__ int tile_loc(const uint4& c, int a)
 {
     const unsigned w = a < 2 ? c.x : a < 4 ? c.y : a < 6 ? c.z : c.w;
     return (a & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
 }
-template <bool AFFINE>
-__device__ __forceinline__ void tile_fetch_idx(TileIdx& in, bool valid, size_t k, const int* __restrict__ telems,
-                                               const uint4* __restrict__ tconn, const int* gl, const double* __restrict__ Ev,
-                                               const double* __restrict__ nuv)
+// value of the next / the previous lane of the 16-lane row (DPP row_shl:1 / row_shr:1; lanes without a source keep 0)
+__device__ __forceinline__ double row_next(double x)
 {
-    in.valid = valid;
-    if (!valid) return;
-    in.c16 = tconn[k];
-    if constexpr (!AFFINE) {
-        const size_t e = (size_t)telems[k];
-        in.E = Ev[e]; in.nu = nuv[e];
-    }
-#pragma unroll
-    for (int a = 0; a < 8; a++) in.v[a] = gl[tile_loc(in.c16, a)];
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x101, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double row_prev(double x)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x111, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// stage 1 (three steps ahead): the lane's slot from the tile lists -- plain global loads, nothing depends on them yet
+struct TileRaw {
+    uint4 c16;
+    double E, nu;
+    unsigned fl;
+    bool valid;
+};
+template <bool AFFINE>
+__device__ __forceinline__ void tile_fetch_raw(TileRaw& rw, bool inside, size_t k, const int* __restrict__ telems,
+                                               const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
+                                               const double* __restrict__ Ev, const double* __restrict__ nuv)
+{
+    rw.valid = false; rw.fl = 0;
+    if (!inside) return;
+    const int e = telems[k];
+    rw.c16 = tconn[k];
+    rw.fl = tflags[k];
+    if (e < 0) return;   // padding of a 16-lane row
+    rw.valid = true;
+    if constexpr (!AFFINE) { rw.E = Ev[e]; rw.nu = nuv[e]; }
+}
+// stage 2 (two steps ahead): global node ids from the tile's list in LDS
+__device__ __forceinline__ void tile_resolve(TileIdx& in, const TileRaw& rw, const int* gl)
+{
+    in.valid = rw.valid; in.fl = rw.valid ? rw.fl : 0u; in.c16 = rw.c16; in.E = rw.E; in.nu = rw.nu;
+    if (!rw.valid) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) in.v[c_tminus[i]] = gl[tile_loc(in.c16, c_tminus[i])];
+    if (!(in.fl & 1u)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) in.v[c_tplus[i]] = gl[tile_loc(in.c16, c_tplus[i])];
+    }
+}
+// loads of one element: -x face nodes always, +x face nodes where the chain ends (the others come from the next lane, see
+// tile_complete)
 __device__ __forceinline__ void tile_fetch_data(TileData& dt, const TileIdx& in, size_t k, const double* __restrict__ geo,
                                                 size_t geo_stride, const double* __restrict__ x)
 {
@@ -84,9 +125,27 @@ __device__ __forceinline__ void tile_fetch_data(TileData& dt, const TileIdx& in,
 #pragma unroll
     for (int j = 0; j < 11; j++) dt.geo[j] = geo[(size_t)j * geo_stride + k];
 #pragma unroll
-    for (int a = 0; a < 8; a++)
+    for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int d = 0; d < 3; d++) dt.u[a][d] = x[(size_t)in.v[a] * 3 + d];
+        for (int d = 0; d < 3; d++) dt.u[c_tminus[i]][d] = x[(size_t)in.v[c_tminus[i]] * 3 + d];
+    if (!(in.fl & 1u)) {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) dt.u[c_tplus[i]][d] = x[(size_t)in.v[c_tplus[i]] * 3 + d];
+    }
+}
+// every lane of the wavefront: +x face values of the linked lanes from the next lane's -x face
+template <int N>
+__device__ __forceinline__ void tile_complete(double (&u)[8][N], unsigned fl)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int d = 0; d < N; d++) {
+            const double nx = row_next(u[c_tminus[i]][d]);
+            if (fl & 1u) u[c_tplus[i]][d] = nx;
+        }
 }
 
 // geometry records of the elements of the affine tiles (set-up): geo[j * stride + k], k = position in the tile lists
@@ -96,7 +155,7 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
                                                    double* __restrict__ geo)
 {
     const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ntel || !taff[k]) return;
+    if (k >= ntel || !taff[k] || telems[k] < 0) return;
     const size_t e = (size_t)telems[k];
     double X[4][3];
     constexpr int xa[4] = {0, 1, 3, 4};
@@ -119,16 +178,18 @@ template <bool AFFINE>
 __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
+                                                     const unsigned char* __restrict__ tflags,
                                                      const double* __restrict__ coords, const double* __restrict__ Ev,
                                                      const double* __restrict__ nuv, const double* __restrict__ x,
                                                      const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
                                                      const double* __restrict__ bc_shift, const double* __restrict__ geo,
                                                      size_t geo_stride, double g, double w, int max_nnode,
                                                      double* __restrict__ y, double* __restrict__ partial,
-                                                     const int* __restrict__ done)
+                                                     const int* __restrict__ done, long long* __restrict__ dbg)
 {
     if (done && *done) return;
     extern __shared__ double lds[];
+    const long long T0 = __builtin_readcyclecounter();   // DBG
     __shared__ double sh[4];
     // workgroups b and b + 8 share an XCD (and its L2): neighbouring tiles, which read the same nodes, go to one XCD
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
@@ -138,75 +199,132 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
     double* acc = lds;
     int* gl = reinterpret_cast<int*>(lds + 3 * (size_t)max_nnode);
-    for (int i = threadIdx.x; i < nnode; i += 256) {
-        gl[i] = tnodes[node_off + i];
-        acc[3 * i] = 0.0; acc[3 * i + 1] = 0.0; acc[3 * i + 2] = 0.0;
+    {   // node list -> LDS, sums zeroed (all loads of a lane in flight together: TILE_MAX_NODES <= 12 * 256)
+        int nv[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nnode) { gl[i] = nv[j]; acc[3 * i] = 0.0; acc[3 * i + 1] = 0.0; acc[3 * i + 2] = 0.0; }
+        }
     }
     __syncthreads();
+    const long long T1 = __builtin_readcyclecounter();   // DBG
     auto pos_of = [&](int s) { return (size_t)elem_off + steps[step_off + (s < nsteps ? s : 0)].x + threadIdx.x; };
-    auto idx_of = [&](TileIdx& in, int s) {
+    auto raw_of = [&](TileRaw& rw, int s) {
         const bool have = s < nsteps;
         const int2 st = steps[step_off + (have ? s : 0)];
-        tile_fetch_idx<AFFINE>(in, have && (int)threadIdx.x < (st.y & 0x7fffffff), (size_t)elem_off + st.x + threadIdx.x, telems,
-                               tconn, gl, Ev, nuv);
+        tile_fetch_raw<AFFINE>(rw, have && (int)threadIdx.x < (st.y & 0x7fffffff), (size_t)elem_off + st.x + threadIdx.x, telems,
+                               tconn, tflags, Ev, nuv);
     };
+    TileRaw r2, r3;            // steps s + 2, s + 3
     TileIdx i0, i1, i2;        // steps s, s + 1, s + 2
     TileData d0, d1;           // steps s, s + 1 (affine kernel)
-    idx_of(i0, 0);
-    idx_of(i1, 1);
+    raw_of(r2, 0); tile_resolve(i0, r2, gl);
+    raw_of(r2, 1); tile_resolve(i1, r2, gl);
+    raw_of(r2, 2);
     if constexpr (AFFINE) tile_fetch_data(d0, i0, pos_of(0), geo, geo_stride, x);
     for (int s = 0; s < nsteps; s++) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
-            idx_of(i2, s + 2);
+            raw_of(r3, s + 3);
+            tile_resolve(i2, r2, gl);
             tile_fetch_data(d1, i1, pos_of(s + 1), geo, geo_stride, x);
         }
-        if (i0.valid) {
-            double fe[8][3], dot;
-            if constexpr (AFFINE) {
+        double fe[8][3], dot;
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) fe[a][d] = 0.0;
+        if constexpr (AFFINE) {
+            tile_complete<3>(d0.u, i0.fl);
+            if (i0.valid) {
                 double A[3][3];
 #pragma unroll
                 for (int i = 0; i < 3; i++)
 #pragma unroll
                     for (int j = 0; j < 3; j++) A[i][j] = d0.geo[3 * i + j];
                 hex_forces_geom(A, d0.geo[9], d0.geo[10], d0.u, g, fe, dot);
-            } else {
-                double X[8][3], u[8][3];
+            }
+        } else {
+            double X[8][3], u[8][3];
 #pragma unroll
-                for (int a = 0; a < 8; a++)
+            for (int a = 0; a < 8; a++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) { X[a][d] = 0.0; u[a][d] = 0.0; }
+            if (i0.valid) {
+#pragma unroll
+                for (int a = 0; a < 8; a++) {
+                    if ((i0.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
 #pragma unroll
                     for (int d = 0; d < 3; d++) { X[a][d] = coords[(size_t)i0.v[a] * 3 + d]; u[a][d] = x[(size_t)i0.v[a] * 3 + d]; }
+                }
+            }
+            tile_complete<3>(X, i0.fl);
+            tile_complete<3>(u, i0.fl);
+            if (i0.valid) {
                 const DCoef D = dmat_coef(i0.E, i0.nu);
                 hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
             }
+        }
+        // +x face forces of a linked lane go to the next lane's -x face nodes
+        {
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(i0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double pv = row_prev(fe[c_tplus[i]][d]);
+                    if (recv) fe[c_tminus[i]][d] += pv;
+                }
+        }
+        if (i0.valid) {
 #pragma unroll
             for (int a = 0; a < 8; a++) {
+                if ((i0.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;   // handed over
                 const int la = tile_loc(i0.c16, a);
 #pragma unroll
-                for (int d = 0; d < 3; d++) acc[3 * la + d] += fe[a][d];   // one writer per node and colour
+                for (int d = 0; d < 3; d++)   // one writer per node and colour: the LDS unit's add is as good as a read-add-write
+                    __hip_atomic_fetch_add(&acc[3 * la + d], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         if (bar) __syncthreads();
-        if constexpr (AFFINE) { i0 = i1; i1 = i2; d0 = d1; }
-        else { i0 = i1; idx_of(i1, s + 2); }
+        if constexpr (AFFINE) { i0 = i1; i1 = i2; r2 = r3; d0 = d1; }
+        else { i0 = i1; tile_resolve(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernel)
     }
+    const long long T2 = __builtin_readcyclecounter();   // DBG
     double dot = 0.0;
-    for (int i = threadIdx.x; i < nown; i += 256) {
-        const size_t v = (size_t)gl[i];
-        const int kb = bc_node ? bc_node[v] : -1;
+    for (int i0n = 0; i0n < nown; i0n += 1024) {   // four owned nodes per lane and round: their loads in flight together
+        int kb[4];
+        double xv[4][3];
+        size_t vv[4];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const double xi = x[v * 3 + d];
-            double s = acc[3 * i + d];
-            if (kb >= 0 && bc_dof[kb + d] >= 0) s += bc_shift[kb + d] * xi;   // ApplyKBC INSERTs on the diagonal only
-            y[v * 3 + d] = s;
-            dot += xi * s;
+        for (int j = 0; j < 4; j++) {
+            const int i = i0n + (int)threadIdx.x + 256 * j;
+            vv[j] = (i < nown) ? (size_t)gl[i] : 0;
+            kb[j] = (i < nown && bc_node) ? bc_node[vv[j]] : -1;
+#pragma unroll
+            for (int d = 0; d < 3; d++) xv[j][d] = (i < nown) ? x[vv[j] * 3 + d] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0n + (int)threadIdx.x + 256 * j;
+            if (i >= nown) continue;
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                double sv = acc[3 * i + d];
+                if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sv += bc_shift[kb[j] + d] * xv[j][d];   // ApplyKBC INSERTs on the diagonal only
+                y[vv[j] * 3 + d] = sv;
+                dot += xv[j][d] * sv;
+            }
         }
     }
     for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
     __syncthreads();
     if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    if (dbg && threadIdx.x == 0) { dbg[4 * t] = T0; dbg[4 * t + 1] = T1; dbg[4 * t + 2] = T2; dbg[4 * t + 3] = __builtin_readcyclecounter(); }   // DBG
 }
 
 // the parallelepiped test of hex_forces on the host (same tolerance)
@@ -315,7 +433,10 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     std::vector<int> laff, lgen;
     std::vector<int> estamp((size_t)nel, -1), nstamp((size_t)nn, -1), local((size_t)nn, 0);
     std::vector<unsigned> cmask;
-    std::vector<int> el, nd, col, order;
+    std::vector<int> el, nd, col, order, chain_start;
+    std::vector<unsigned char> tflags;
+    long long visits = 0;
+    static const int c_plus[4] = {1, 2, 5, 6}, c_minus[4] = {0, 3, 4, 7};
     int ntiles = 0, max_nnode = 0;
     for (long long b = 0; b < nboxes; b++) {
         const int o0 = bstart[b], o1 = bstart[b + 1];
@@ -339,52 +460,78 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         std::sort(nd.begin() + rim0, nd.end());
         for (size_t i = rim0; i < nd.size(); i++) local[nd[i]] = (int)i;
         if ((int)nd.size() > TILE_MAX_NODES || nd.size() > 65535) return refuse("tile with too many nodes", (long long)nd.size(), nown);
-        // greedy colouring in element order
+        // chains: runs of elements (ascending ids) whose +x face is the next one's -x face, at most 16 long -- a chain
+        // sits in consecutive lanes of one 16-lane row and passes its shared-face values along the row (k_ebe_tile)
+        chain_start.clear();
+        for (size_t i = 0; i < el.size(); i++) {
+            bool linked = false;
+            if (i > 0 && (int)(i - chain_start.back()) < 16) {
+                linked = true;
+                for (int k = 0; k < 4; k++)
+                    linked = linked && conn[(size_t)el[i - 1] * 8 + c_plus[k]] == conn[(size_t)el[i] * 8 + c_minus[k]];
+            }
+            if (!linked) chain_start.push_back((int)i);
+        }
+        chain_start.push_back((int)el.size());
+        const int nchain = (int)chain_start.size() - 1;
+        // greedy colouring of the chains (two chains of one colour share no node)
         cmask.assign(nd.size(), 0u);
-        col.resize(el.size());
+        col.resize((size_t)nchain);
         int ncol = 0;
         bool all_aff = true;
-        for (size_t i = 0; i < el.size(); i++) {
+        for (int ch = 0; ch < nchain; ch++) {
             unsigned used = 0;
-            for (int a = 0; a < 8; a++) used |= cmask[local[conn[(size_t)el[i] * 8 + a]]];
+            for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++)
+                for (int a = 0; a < 8; a++) used |= cmask[local[conn[(size_t)el[i] * 8 + a]]];
             int c = 0;
             while (c < TILE_MAXC && ((used >> c) & 1u)) c++;
             if (c >= TILE_MAXC) return refuse("too many colours");
-            col[i] = c; ncol = std::max(ncol, c + 1);
-            for (int a = 0; a < 8; a++) cmask[local[conn[(size_t)el[i] * 8 + a]]] |= 1u << c;
-            all_aff = all_aff && aff[el[i]];
+            col[ch] = c; ncol = std::max(ncol, c + 1);
+            for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
+                for (int a = 0; a < 8; a++) cmask[local[conn[(size_t)el[i] * 8 + a]]] |= 1u << c;
+                all_aff = all_aff && aff[el[i]];
+            }
         }
         const int elem_off = (int)telems.size(), step_off = (int)steps.size();
         tnodes_off = (int)tnodes.size();
         tnodes.insert(tnodes.end(), nd.begin(), nd.end());
         for (int c = 0; c < ncol; c++) {
             const int first = (int)telems.size() - elem_off;
-            for (size_t i = 0; i < el.size(); i++)
-                if (col[i] == c) {
+            for (int ch = 0; ch < nchain; ch++) {
+                if (col[ch] != c) continue;
+                const int len = chain_start[ch + 1] - chain_start[ch];
+                const int used_in_row = ((int)telems.size() - elem_off - first) % 16;
+                if (used_in_row + len > 16)   // a chain does not straddle rows: pad the row
+                    for (int p = used_in_row; p < 16; p++) { telems.push_back(-1); tconn.push_back(make_uint4(0, 0, 0, 0)); tflags.push_back(0); }
+                for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
                     telems.push_back(el[i]);
                     unsigned l[8];
                     for (int a = 0; a < 8; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * 8 + a]];
                     tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
+                    tflags.push_back(i + 1 < chain_start[ch + 1] ? 1 : 0);   // bit 0: linked to the next lane
                 }
+            }
+            while (((int)telems.size() - elem_off - first) % 16) { telems.push_back(-1); tconn.push_back(make_uint4(0, 0, 0, 0)); tflags.push_back(0); }
             const int cnt = (int)telems.size() - elem_off - first;
             for (int r = 0; r < cnt; r += 256) {
                 const int n = std::min(256, cnt - r);
                 steps.push_back(make_int2(first + r, (r + 256 >= cnt) ? (int)((unsigned)n | 0x80000000u) : n));
             }
         }
+        visits += (long long)el.size();
         hdr.push_back(tnodes_off); hdr.push_back(nown); hdr.push_back((int)nd.size()); hdr.push_back(elem_off);
         hdr.push_back(step_off); hdr.push_back((int)steps.size() - step_off);
         max_nnode = std::max(max_nnode, (int)nd.size());
         (all_aff ? laff : lgen).push_back(t);
     }
     plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->max_nnode = max_nnode;
-    plan->tile_elements = (long long)telems.size();
+    plan->tile_elements = visits; plan->slots = (long long)telems.size();
     auto up = [&](auto& dbuf, const auto& vec) {
         dbuf.alloc(std::max<size_t>(vec.size(), 1));
         if (!vec.empty())
             FEM_HIP(hipMemcpyAsync(dbuf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
     };
-    up(plan->hdr, hdr); up(plan->steps, steps); up(plan->nodes, tnodes); up(plan->elems, telems); up(plan->conn16, tconn);
+    up(plan->hdr, hdr); up(plan->steps, steps); up(plan->nodes, tnodes); up(plan->elems, telems); up(plan->conn16, tconn); up(plan->flags, tflags);
     up(plan->list_aff, laff); up(plan->list_gen, lgen);
     if (!laff.empty()) {   // geometry records of the affine tiles' elements
         std::vector<unsigned char> taff(telems.size(), 0);
@@ -404,8 +551,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     FEM_HIP(hipStreamSynchronize(s));
     plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (verbose)
-        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine), <= %d nodes, %lld element visits for %d elements, %zu steps, set-up %.0f ms\n",
-                     ntiles, plan->n_aff, max_nnode, plan->tile_elements, nel, steps.size(), plan->t_setup_ms);
+        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine), <= %d nodes, %lld element visits in %lld lane slots for %d elements, %zu steps, set-up %.0f ms\n",
+                     ntiles, plan->n_aff, max_nnode, plan->tile_elements, plan->slots, nel, steps.size(), plan->t_setup_ms);
     return plan;
 }
 
@@ -431,12 +578,26 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                                     (int)(TILE_MAX_NODES * 28)));
         attr_set = true;
     }
+    static long long* dbg = nullptr;   // DBG
+    static int dbg_calls = 0;
+    if (std::getenv("FEM_AMD_TILE_DBG") && !dbg) FEM_HIP(hipMalloc(&dbg, sizeof(long long) * 4 * P.ntiles));
     if (P.n_aff)
         hipLaunchKernelGGL(k_ebe_tile<true>, dim3((P.n_aff + 7) / 8 * 8), dim3(256), shmem, s, P.n_aff, P.list_aff.p, P.hdr.p,
-                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
-                           A->bc_shift.p, P.geo.p, (size_t)P.tile_elements, g, w, P.max_nnode, y, part, done);
+                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
+                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done, dbg);
     if (P.n_gen)
         hipLaunchKernelGGL(k_ebe_tile<false>, dim3((P.n_gen + 7) / 8 * 8), dim3(256), shmem, s, P.n_gen, P.list_gen.p, P.hdr.p,
-                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
-                           A->bc_shift.p, P.geo.p, (size_t)P.tile_elements, g, w, P.max_nnode, y, part, done);
+                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
+                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done, dbg);
+    if (dbg && ++dbg_calls == 20) {   // DBG
+        FEM_HIP(hipStreamSynchronize(s));
+        std::vector<long long> h(4 * (size_t)P.ntiles);
+        FEM_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        long long tmin = h[0], tmax = h[3];
+        for (int t = 0; t < P.ntiles; t++) { tmin = std::min(tmin, h[4 * t]); tmax = std::max(tmax, h[4 * t + 3]); }
+        double a = 0, b = 0, c = 0;
+        for (int t = 0; t < P.ntiles; t++) { a += h[4 * t + 1] - h[4 * t]; b += h[4 * t + 2] - h[4 * t + 1]; c += h[4 * t + 3] - h[4 * t + 2]; }
+        std::fprintf(stderr, "[tile dbg] kernel span %lld ticks; per tile avg: init %.0f main %.0f final %.0f ticks\n", tmax - tmin, a / P.ntiles, b / P.ntiles, c / P.ntiles);
+        for (int t : {0, 1, 500, 1000, 2199}) if (t < P.ntiles) std::fprintf(stderr, "[tile dbg] tile %d: start %lld init %lld main %lld final %lld\n", t, h[4 * t] - tmin, h[4 * t + 1] - h[4 * t], h[4 * t + 2] - h[4 * t + 1], h[4 * t + 3] - h[4 * t + 2]);
+    }
 }

@@ -185,11 +185,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                                                      const double* __restrict__ bc_shift, const double* __restrict__ geo,
                                                      size_t geo_stride, double g, double w, int max_nnode,
                                                      double* __restrict__ y, double* __restrict__ partial,
-                                                     const int* __restrict__ done, long long* __restrict__ dbg)
+                                                     const int* __restrict__ done)
 {
     if (done && *done) return;
     extern __shared__ double lds[];
-    const long long T0 = __builtin_readcyclecounter();   // DBG
     __shared__ double sh[4];
     // workgroups b and b + 8 share an XCD (and its L2): neighbouring tiles, which read the same nodes, go to one XCD
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
@@ -210,7 +209,6 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         }
     }
     __syncthreads();
-    const long long T1 = __builtin_readcyclecounter();   // DBG
     auto pos_of = [&](int s) { return (size_t)elem_off + steps[step_off + (s < nsteps ? s : 0)].x + threadIdx.x; };
     auto raw_of = [&](TileRaw& rw, int s) {
         const bool have = s < nsteps;
@@ -232,21 +230,16 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             tile_resolve(i2, r2, gl);
             tile_fetch_data(d1, i1, pos_of(s + 1), geo, geo_stride, x);
         }
+        // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
         double fe[8][3], dot;
-#pragma unroll
-        for (int a = 0; a < 8; a++)
-#pragma unroll
-            for (int d = 0; d < 3; d++) fe[a][d] = 0.0;
         if constexpr (AFFINE) {
             tile_complete<3>(d0.u, i0.fl);
-            if (i0.valid) {
-                double A[3][3];
+            double A[3][3];
 #pragma unroll
-                for (int i = 0; i < 3; i++)
+            for (int i = 0; i < 3; i++)
 #pragma unroll
-                    for (int j = 0; j < 3; j++) A[i][j] = d0.geo[3 * i + j];
-                hex_forces_geom(A, d0.geo[9], d0.geo[10], d0.u, g, fe, dot);
-            }
+                for (int j = 0; j < 3; j++) A[i][j] = d0.geo[3 * i + j];
+            hex_forces_geom(A, d0.geo[9], d0.geo[10], d0.u, g, fe, dot);
         } else {
             double X[8][3], u[8][3];
 #pragma unroll
@@ -263,10 +256,8 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             }
             tile_complete<3>(X, i0.fl);
             tile_complete<3>(u, i0.fl);
-            if (i0.valid) {
-                const DCoef D = dmat_coef(i0.E, i0.nu);
-                hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
-            }
+            const DCoef D = dmat_coef(i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25);
+            hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
         }
         // +x face forces of a linked lane go to the next lane's -x face nodes
         {
@@ -293,7 +284,6 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         if constexpr (AFFINE) { i0 = i1; i1 = i2; r2 = r3; d0 = d1; }
         else { i0 = i1; tile_resolve(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernel)
     }
-    const long long T2 = __builtin_readcyclecounter();   // DBG
     double dot = 0.0;
     for (int i0n = 0; i0n < nown; i0n += 1024) {   // four owned nodes per lane and round: their loads in flight together
         int kb[4];
@@ -324,7 +314,6 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
     __syncthreads();
     if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-    if (dbg && threadIdx.x == 0) { dbg[4 * t] = T0; dbg[4 * t + 1] = T1; dbg[4 * t + 2] = T2; dbg[4 * t + 3] = __builtin_readcyclecounter(); }   // DBG
 }
 
 // the parallelepiped test of hex_forces on the host (same tolerance)
@@ -578,26 +567,12 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                                     (int)(TILE_MAX_NODES * 28)));
         attr_set = true;
     }
-    static long long* dbg = nullptr;   // DBG
-    static int dbg_calls = 0;
-    if (std::getenv("FEM_AMD_TILE_DBG") && !dbg) FEM_HIP(hipMalloc(&dbg, sizeof(long long) * 4 * P.ntiles));
     if (P.n_aff)
         hipLaunchKernelGGL(k_ebe_tile<true>, dim3((P.n_aff + 7) / 8 * 8), dim3(256), shmem, s, P.n_aff, P.list_aff.p, P.hdr.p,
                            P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
-                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done, dbg);
+                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done);
     if (P.n_gen)
         hipLaunchKernelGGL(k_ebe_tile<false>, dim3((P.n_gen + 7) / 8 * 8), dim3(256), shmem, s, P.n_gen, P.list_gen.p, P.hdr.p,
                            P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
-                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done, dbg);
-    if (dbg && ++dbg_calls == 20) {   // DBG
-        FEM_HIP(hipStreamSynchronize(s));
-        std::vector<long long> h(4 * (size_t)P.ntiles);
-        FEM_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-        long long tmin = h[0], tmax = h[3];
-        for (int t = 0; t < P.ntiles; t++) { tmin = std::min(tmin, h[4 * t]); tmax = std::max(tmax, h[4 * t + 3]); }
-        double a = 0, b = 0, c = 0;
-        for (int t = 0; t < P.ntiles; t++) { a += h[4 * t + 1] - h[4 * t]; b += h[4 * t + 2] - h[4 * t + 1]; c += h[4 * t + 3] - h[4 * t + 2]; }
-        std::fprintf(stderr, "[tile dbg] kernel span %lld ticks; per tile avg: init %.0f main %.0f final %.0f ticks\n", tmax - tmin, a / P.ntiles, b / P.ntiles, c / P.ntiles);
-        for (int t : {0, 1, 500, 1000, 2199}) if (t < P.ntiles) std::fprintf(stderr, "[tile dbg] tile %d: start %lld init %lld main %lld final %lld\n", t, h[4 * t] - tmin, h[4 * t + 1] - h[4 * t], h[4 * t + 2] - h[4 * t + 1], h[4 * t + 3] - h[4 * t + 2]);
-    }
+                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done);
 }

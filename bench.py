@@ -38,11 +38,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # fp64 FMA peak of MI355X: 256 CUs x 128 flop/clk x 2.4 GHz = 78.6 TFLOP/s; the data sheet quotes the
 # same figure for vector fp64 and for the f64 MFMA (the guide has no fp64 row of its own)
 FP64_PEAK_TFLOPS = 78.6
-# Element-by-element hex8 product, flops per element as coded in k_ebe_apply (FMA = 2), 8 Gauss points:
-# J 144 + G 144 (reference gradients of coordinates and x) + adjugate/det/inverse 42 + H = J^-1 G 54 +
-# strain/stress 28 + T = sigma J^-1 54 + f_a += T dNxi_a 144 = 610 per point, plus 48 for x_e.f_e
-# 
-EBE_FLOPS_PER_HEX8 = 8 * 610 + 48
+# fp64 work of the element-by-element hex8 kernels AS COMPILED, per element (tile kernels: per element visit):
+# (fp64 vector instructions, flops with fma = 2, all vector instructions) -- tools/count_ebe_flops.py prints them
+EBE_WORK = {
+    "k_ebe_tile<affine>": (478, 643, 726),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
+    "k_ebe_tile<general>": (1503, 2217, 1900),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
+    "k_ebe_apply<3,8,8,3>": (567, 789, 689),   # element buffer + gather, parallelepipeds
+    "k_ebe_apply<3,8,8,1>": (1503, 2217, 1669),  # element buffer + gather, distorted elements
+}
+FP64_ISSUE_RATE = 256 * 4 * 2.4e9 / 4.0        # fp64 vector instructions per second at 4 cycles per wave64 instruction
 
 
 def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:
@@ -290,16 +294,49 @@ def main():
         return r
 
     def ebe_roofline(avg_el_ms, launches, extra):
+        """The element kernel of the product the solve used.  Since round 2 the hex8 kernels do a sixth of the round-1
+        arithmetic (monomial basis, stored geometry of parallelepipeds) and sit under the memory roof, not the fp64 one: the
+        roofline is HBM on the bytes the kernel has to move, the fp64 figures ride along."""
         nel = mesh.nels
-        flops = float(nel) * EBE_FLOPS_PER_HEX8
-        achieved = flops / (avg_el_ms * 1e-3) / 1e12
-        r = {"bound": "fp64_valu",
-             "pipe": "fp64 vector FMA (v_fma_f64, no MFMA in the kernel); peak = 256 CUs x 128 flop/clk x 2.4 GHz, the "
-                     "data-sheet figure for vector fp64",
-             "kernel": "k_ebe_apply<3,8,8> (element-by-element MatMult inside KSPCG)", "achieved": achieved,
-             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-             "traffic": traffic_of("ebe_traffic.json"), "algorithmic_flops": flops, "avg_launch_ms": avg_el_ms,
-             "launches": launches, "flops_model": "as coded (4,928 per hex8), not a minimum-flop count"}
+        info = prob.K.get_mult_info()
+        affine = args.jitter == 0.0
+        if info["kind"] == 2:
+            kname = "k_ebe_tile<affine>" if affine else "k_ebe_tile<general>"
+            visits, slots, tnodes = info["element_visits"], info["lane_slots"], info["tile_nodes"]
+            # tile lists (local connectivity 16 B, element id 4 B, flag 1 B per lane slot; node lists 4 B per entry),
+            # stored geometry 88 B per visit (parallelepipeds) or E, nu 16 B per visit + the nodes' coordinates once,
+            # x read once, y written once
+            alg = slots * 21.0 + tnodes * 4.0 + nrows * 16.0
+            alg += visits * 88.0 if affine else visits * 16.0 + nrows * 8.0
+            model = ("tile lists 21 B/lane slot + node lists 4 B/entry + " +
+                     ("stored geometry 88 B/element visit" if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
+                     " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
+            traffic = traffic_of("ebe_traffic.json")
+        else:
+            kname = "k_ebe_apply<3,8,8,3>" if affine else "k_ebe_apply<3,8,8,1>"
+            visits = nel
+            alg = nel * (32.0 + 16.0 + 96.0) + nrows * 16.0      # connectivity, E / nu, 12 kept force components; x, coordinates
+            model = "connectivity 32 B + E, nu 16 B + kept forces 96 B per element + x and coordinates 24 B/node each"
+            traffic = None
+        instr, flops_per, valu = EBE_WORK[kname]
+        secs = avg_el_ms * 1e-3
+        achieved = alg / secs / 1e9
+        flops = float(visits) * flops_per
+        r = {"bound": "hbm",
+             "kernel": f"{kname} (element-by-element MatMult inside KSPCG" + (", the whole product in one pass)" if info["kind"] == 2 else ")"),
+             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+             "traffic": traffic, "algorithmic_bytes": alg, "bytes_model": model, "avg_launch_ms": avg_el_ms, "launches": launches,
+             "fp64": {"flops_per_element_visit": flops_per, "element_visits": visits, "elements": nel,
+                      "achieved_TFLOPs": flops / secs / 1e12, "frac_of_fp64_peak": flops / secs / 1e12 / FP64_PEAK_TFLOPS,
+                      "vector_instr_per_visit": valu,
+                      "issue_slot_frac": (visits / 64.0) * valu / FP64_ISSUE_RATE / secs,
+                      "note": "as compiled (tools/count_ebe_flops.py); round 1's Gauss loop needed 5,025 flops per element, "
+                              "the kernel was fp64-bound then (0.65 of peak) and is not any more"}}
+        if traffic:
+            r["pmc_GBs"] = traffic / secs / 1e9
+            r["frac_of_spec_pmc"] = r["pmc_GBs"] / HBM_PEAK_GBS
+        if info["kind"] == 2:
+            r["tiles"] = {k: info[k] for k in ("tiles", "affine_tiles", "element_visits", "lane_slots", "tile_nodes", "setup_ms")}
         r.update(extra)
         return r
 

@@ -69,6 +69,8 @@ _SIGS = {
     "fem_mat_set_mult_type": [_h, C.c_char_p],
     "fem_mat_set_profiling": [_h, C.c_int],
     "fem_mat_get_profile": [_h, C.c_int, _ip, _dp, _dp, _dp],
+    "fem_mat_get_mult_info": [_h, _ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
+                              C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _dp],
     "fem_mat_get_diagonal": [_h, _h],
     "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
     "fem_vec_create": [_h, C.c_longlong, C.POINTER(_h)],
@@ -490,6 +492,16 @@ class Mat:
         a, b, c = C.c_double(0), C.c_double(0), C.c_double(0)
         _ck(_lib.fem_mat_get_profile(self.h, int(max_products), C.byref(n), C.byref(a), C.byref(b), C.byref(c)))
         return n.value, a.value, b.value, c.value
+
+    def get_mult_info(self) -> dict:
+        """kind 0 assembled / 1 element buffer + gather / 2 one-pass tiles, and the tile plan's figures."""
+        k = C.c_int(0)
+        a, b, c, d, e = (C.c_longlong(0) for _ in range(5))
+        ms = C.c_double(0)
+        _ck(_lib.fem_mat_get_mult_info(self.h, C.byref(k), C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e),
+                                       C.byref(ms)))
+        return {"kind": k.value, "tiles": a.value, "affine_tiles": b.value, "element_visits": c.value, "lane_slots": d.value,
+                "tile_nodes": e.value, "setup_ms": ms.value}
 
     def set_mult_type(self, kind: str):
         """'assembled' (sliced block-ELL SpMV), 'ebe' (element-by-element recomputation: one-pass tile kernel on a mesh of

@@ -23,6 +23,7 @@ void coh_apply_1_impl(fem_ctx, int, const double*, const double*, const double*,
 void mat_set_mult_type_impl(fem_mat, const char*);
 void mat_set_profiling_impl(fem_mat, int);
 void mat_get_profile_impl(fem_mat, int, int*, double*, double*, double*);
+void mat_get_mult_info_impl(fem_mat, int*, long long*, long long*, long long*, long long*, long long*, double*);
 void mat_apply_kbc_impl(fem_mat, int, const int*);
 void mat_get_csr_impl(fem_mat, int*, int*, double*);
 void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
@@ -365,6 +366,15 @@ int fem_mat_get_profile(fem_mat A, int max_products, int* n, double* element_ms,
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
     mat_get_profile_impl(A, max_products, n, element_ms, gather_ms, penalty_ms);
+    FEM_CATCH
+}
+
+int fem_mat_get_mult_info(fem_mat A, int* kind, long long* tiles, long long* affine_tiles, long long* element_visits,
+                          long long* lane_slots, long long* tile_nodes, double* setup_ms)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_get_mult_info_impl(A, kind, tiles, affine_tiles, element_visits, lane_slots, tile_nodes, setup_ms);
     FEM_CATCH
 }
 

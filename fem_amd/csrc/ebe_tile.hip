@@ -34,6 +34,7 @@ struct EbeTilePlan {
     int ntiles = 0, n_aff = 0, n_gen = 0, max_nnode = 0;
     long long tile_elements = 0;         // elements computed per product (rim elements counted once per tile)
     long long slots = 0;                 // lanes of all steps (elements + the padding of 16-lane rows)
+    long long tile_nodes = 0;            // entries of all node lists
     DBuf<int> hdr;                       // [ntiles*6] node_off, nown, nnode, elem_off, step_off, nsteps
     DBuf<int2> steps;                    // rounds of <= 256 elements of one colour: {first (relative), count | barrier << 31}
     DBuf<int> nodes;                     // global node ids of every tile, owned ones first
@@ -514,7 +515,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         (all_aff ? laff : lgen).push_back(t);
     }
     plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->max_nnode = max_nnode;
-    plan->tile_elements = visits; plan->slots = (long long)telems.size();
+    plan->tile_elements = visits; plan->slots = (long long)telems.size(); plan->tile_nodes = (long long)tnodes.size();
     auto up = [&](auto& dbuf, const auto& vec) {
         dbuf.alloc(std::max<size_t>(vec.size(), 1));
         if (!vec.empty())
@@ -546,8 +547,11 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
 }
 
 int ebe_tile_partials(const EbeTilePlan& P) { return P.ntiles; }
-double ebe_tile_setup_ms(const EbeTilePlan& P) { return P.t_setup_ms; }
-long long ebe_tile_elements(const EbeTilePlan& P) { return P.tile_elements; }
+void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_tiles, long long* visits, long long* slots,
+                   long long* nodes, double* ms)
+{
+    *tiles = P.ntiles; *affine_tiles = P.n_aff; *visits = P.tile_elements; *slots = P.slots; *nodes = P.tile_nodes; *ms = P.t_setup_ms;
+}
 
 // y = K x, p.Kp partials into part[0 .. ntiles)
 void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done)

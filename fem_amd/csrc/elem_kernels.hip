@@ -1137,6 +1137,25 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
     ebe_mark(A);   // (the penalty rows used to be a stage of their own: the profile keeps its four marks per product)
 }
 
+void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_tiles, long long* visits, long long* slots,
+                   long long* nodes, double* ms);
+void mat_get_mult_info_impl(fem_mat A, int* kind, long long* tiles, long long* affine_tiles, long long* element_visits,
+                            long long* lane_slots, long long* tile_nodes, double* setup_ms)
+{
+    long long z = 0;
+    double zd = 0.0;
+    if (kind) *kind = !A->mult_ebe ? 0 : A->ebe_use_tile ? 2 : 1;
+    if (tiles) *tiles = 0;
+    if (affine_tiles) *affine_tiles = 0;
+    if (element_visits) *element_visits = 0;
+    if (lane_slots) *lane_slots = 0;
+    if (tile_nodes) *tile_nodes = 0;
+    if (setup_ms) *setup_ms = 0.0;
+    if (A->mult_ebe && A->ebe_use_tile)
+        ebe_tile_info(*A->pat->ebe_tile, tiles ? tiles : &z, affine_tiles ? affine_tiles : &z, element_visits ? element_visits : &z,
+                      lane_slots ? lane_slots : &z, tile_nodes ? tile_nodes : &z, setup_ms ? setup_ms : &zd);
+}
+
 void mat_set_profiling_impl(fem_mat A, int on)
 {
     A->profiling = on > 0 ? on : 0;

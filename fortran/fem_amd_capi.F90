@@ -363,6 +363,15 @@ module fem_amd_capi
       real(c_double), intent(out) :: element_ms, gather_ms, penalty_ms
       integer(c_int) :: ierr
     end function
+    function fem_mat_get_mult_info(mat, kind, tiles, affine_tiles, element_visits, lane_slots, tile_nodes, setup_ms) &
+        bind(C, name="fem_mat_get_mult_info") result(ierr)
+      import :: c_int, c_ptr, c_double, c_long_long
+      type(c_ptr), value :: mat
+      integer(c_int), intent(out) :: kind
+      integer(c_long_long), intent(out) :: tiles, affine_tiles, element_visits, lane_slots, tile_nodes
+      real(c_double), intent(out) :: setup_ms
+      integer(c_int) :: ierr
+    end function
     function fem_mat_get_diagonal(mat, d) bind(C, name="fem_mat_get_diagonal") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: mat, d

@@ -182,6 +182,12 @@ int fem_mat_set_mult_type(fem_mat mat, const char *type);
  * (element kernels / node gather / penalty rows, in ms). */
 int fem_mat_set_profiling(fem_mat mat, int on);
 int fem_mat_get_profile(fem_mat mat, int max_products, int *n, double *element_ms, double *gather_ms, double *penalty_ms);
+/* Which product MatMult runs and what its plan looks like: kind 0 assembled SpMV, 1 element buffer + node gather, 2 one-pass
+ * tiles (then: number of tiles, those of them whose elements are all parallelepipeds, element visits per product -- the
+ * elements of a tile's rim are computed by every tile that owns one of their nodes --, lane slots, entries of the tiles'
+ * node lists, host set-up time). */
+int fem_mat_get_mult_info(fem_mat mat, int *kind, long long *tiles, long long *affine_tiles, long long *element_visits,
+                          long long *lane_slots, long long *tile_nodes, double *setup_ms);
 /* MatMult: y = K x (sub-assembled product + halo sum when a halo is attached). */
 int fem_mat_mult(fem_mat mat, fem_vec x, fem_vec y);
 int fem_mat_get_diagonal(fem_mat mat, fem_vec d);

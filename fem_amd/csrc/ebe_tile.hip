@@ -18,7 +18,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <array>
 #include <memory>
+#include <thread>
 
 #include "hex8_ebe.h"
 #include "objects.h"
@@ -338,11 +340,43 @@ static bool host_hex_affine(const double (&X)[8][3])
 
 }  // namespace fem
 
-// Builds the plan (host; once per mesh).  Returns nullptr when the mesh is not one group of hex8 elements or a tile
-// would not fit (nodes, colours): the caller keeps the two-kernel product.
+// ---- set-up ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct TileOut {   // what one worker thread produced for its range of boxes (offsets local to the worker)
+    std::vector<int> hdr, tnodes, telems, laff, lgen;
+    std::vector<int2> steps;
+    std::vector<uint4> tconn;
+    std::vector<unsigned char> tflags, taff;   // taff: the slot belongs to a tile of parallelepipeds
+    long long visits = 0;
+    int ntiles = 0, max_nnode = 0;
+    const char* why = nullptr;   // refusal
+    long long why_a = 0, why_b = 0;
+};
+
+int worker_count()
+{
+    static const int env = std::getenv("FEM_AMD_SETUP_THREADS") ? std::atoi(std::getenv("FEM_AMD_SETUP_THREADS")) : 0;
+    const int hc = (int)std::thread::hardware_concurrency();
+    return std::max(1, env > 0 ? env : std::min(16, hc > 0 ? hc : 1));
+}
+template <class F>
+void parallel_ranges(long long n, int nthreads, F f)   // f(thread, first, last)
+{
+    nthreads = (int)std::max<long long>(1, std::min<long long>(nthreads, n));
+    std::vector<std::thread> th;
+    for (int i = 1; i < nthreads; i++) th.emplace_back(f, i, n * i / nthreads, n * (i + 1) / nthreads);
+    f(0, 0LL, n / nthreads);
+    for (auto& x : th) x.join();
+}
+
+}  // namespace
+
+// Builds the plan (host, a few worker threads; once per mesh).  Returns nullptr when the mesh is not one group of hex8
+// elements or a tile would not fit (nodes, colours): the caller keeps the two-kernel product.
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
 {
-    if (m->groups.size() != 1 || m->groups[0].type != FEM_HEX || m->pdim != 3) return nullptr;
+    if (m->groups.size() != 1 || m->groups[0].type != FEM_HEX || m->pdim != 3 || !m->pattern) return nullptr;
     static const bool verbose = std::getenv("FEM_AMD_EBE_VERBOSE") != nullptr;
     auto refuse = [&](const char* why, long long a = 0, long long b = 0) -> std::shared_ptr<EbeTilePlan> {
         if (verbose) std::fprintf(stderr, "[fem_amd] ebe tiles: not used (%s %lld %lld)\n", why, a, b);
@@ -352,34 +386,48 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     const int nel = grp.nel, nn = m->nnds;
     if (nel < 1) return nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    std::vector<int> conn((size_t)nel * 8);
+    const int NT = worker_count();
+    auto tl = t0;
+    // connectivity, coordinates and the node -> element lists of the symbolic phase (codes element << 3 | local node, ascending)
+    std::vector<int> conn((size_t)nel * 8), nptr((size_t)nn + 1);
     std::vector<double> xyz((size_t)nn * 3);
+    std::vector<unsigned> nlst((size_t)nel * 8);
     FEM_HIP(hipMemcpyAsync(conn.data(), grp.conn.p, conn.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipMemcpyAsync(xyz.data(), m->coords.p, xyz.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    FEM_HIP(hipMemcpyAsync(nptr.data(), m->pattern->n2e_ptr.p, nptr.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+    FEM_HIP(hipMemcpyAsync(nlst.data(), m->pattern->n2e.p, nlst.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipStreamSynchronize(s));
+    if (nptr[nn] != nel * 8) return refuse("node lists do not match the group");
+    if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: copies to the host %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
     // grid of the mean element size over the bounding box of the nodes; node -> box of NB nodes per direction
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
-    for (int v = 0; v < nn; v++)
-        for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], xyz[(size_t)v * 3 + d]); hi[d] = std::max(hi[d], xyz[(size_t)v * 3 + d]); }
     std::vector<unsigned char> aff((size_t)nel);
-    for (int e = 0; e < nel; e++) {
-        double X[8][3], mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-        for (int a = 0; a < 8; a++)
+    std::vector<std::array<double, 9>> part((size_t)NT, std::array<double, 9>{1e300, 1e300, 1e300, -1e300, -1e300, -1e300, 0, 0, 0});
+    parallel_ranges(nn, NT, [&](int th, long long v0, long long v1) {
+        auto& p = part[th];
+        for (long long v = v0; v < v1; v++)
+            for (int d = 0; d < 3; d++) { p[d] = std::min(p[d], xyz[(size_t)v * 3 + d]); p[3 + d] = std::max(p[3 + d], xyz[(size_t)v * 3 + d]); }
+    });
+    parallel_ranges(nel, NT, [&](int th, long long e0, long long e1) {
+        auto& p = part[th];
+        for (long long e = e0; e < e1; e++) {
+            double X[8][3];
+            for (int a = 0; a < 8; a++)
+                for (int d = 0; d < 3; d++) X[a][d] = xyz[(size_t)conn[(size_t)e * 8 + a] * 3 + d];
+            // spacing of the grid the nodes sit on: per direction the longest of the three mean edge vectors of the element
+            // (exact on a regular brick, unbiased under node jitter -- the bounding box of a jittered element is not)
             for (int d = 0; d < 3; d++) {
-                X[a][d] = xyz[(size_t)conn[(size_t)e * 8 + a] * 3 + d];
-                mn[d] = std::min(mn[d], X[a][d]); mx[d] = std::max(mx[d], X[a][d]);
+                const double ex = 0.25 * std::fabs((X[1][d] + X[2][d] + X[5][d] + X[6][d]) - (X[0][d] + X[3][d] + X[4][d] + X[7][d]));
+                const double ey = 0.25 * std::fabs((X[3][d] + X[2][d] + X[7][d] + X[6][d]) - (X[0][d] + X[1][d] + X[4][d] + X[5][d]));
+                const double ez = 0.25 * std::fabs((X[4][d] + X[5][d] + X[6][d] + X[7][d]) - (X[0][d] + X[1][d] + X[2][d] + X[3][d]));
+                p[6 + d] += std::max(ex, std::max(ey, ez));
             }
-        // spacing of the grid the nodes sit on: per direction the longest of the three mean edge vectors of the element
-        // (exact on a regular brick, unbiased under node jitter -- the bounding box of a jittered element is not)
-        for (int d = 0; d < 3; d++) {
-            const double ex = 0.25 * std::fabs((X[1][d] + X[2][d] + X[5][d] + X[6][d]) - (X[0][d] + X[3][d] + X[4][d] + X[7][d]));
-            const double ey = 0.25 * std::fabs((X[3][d] + X[2][d] + X[7][d] + X[6][d]) - (X[0][d] + X[1][d] + X[4][d] + X[5][d]));
-            const double ez = 0.25 * std::fabs((X[4][d] + X[5][d] + X[6][d] + X[7][d]) - (X[0][d] + X[1][d] + X[2][d] + X[3][d]));
-            hsum[d] += std::max(ex, std::max(ey, ez));
+            aff[(size_t)e] = host_hex_affine(X) ? 1 : 0;
         }
-        (void)mn; (void)mx;
-        aff[e] = host_hex_affine(X) ? 1 : 0;
-    }
+    });
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
+    for (auto& p : part)
+        for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[3 + d]); hsum[d] += p[6 + d]; }
+    if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: element pass %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
     static const int NB[3] = {15, 15, 7};
     long long nbox[3];
     double h[3];
@@ -390,7 +438,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         nbox[d] = (npts + NB[d] - 1) / NB[d];
     }
     if ((double)nbox[0] * nbox[1] * nbox[2] > 4.0 * nn + 1024.0) return refuse("grid does not describe the mesh");
-    auto box_of = [&](int v) {
+    auto box_of = [&](long long v) {
         long long b[3];
         for (int d = 0; d < 3; d++) {
             long long i = std::llround((xyz[(size_t)v * 3 + d] - lo[d]) / h[d]);
@@ -401,148 +449,188 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     // nodes sorted by box (counting sort: ascending node id inside a box)
     const long long nboxes = nbox[0] * nbox[1] * nbox[2];
     std::vector<long long> nbx((size_t)nn);
+    parallel_ranges(nn, NT, [&](int, long long v0, long long v1) { for (long long v = v0; v < v1; v++) nbx[(size_t)v] = box_of(v); });
     std::vector<int> bstart((size_t)nboxes + 1, 0);
-    for (int v = 0; v < nn; v++) { nbx[v] = box_of(v); bstart[(size_t)nbx[v] + 1]++; }
+    for (int v = 0; v < nn; v++) bstart[(size_t)nbx[v] + 1]++;
     for (long long b = 0; b < nboxes; b++) bstart[b + 1] += bstart[b];
     std::vector<int> border((size_t)nn), bfill(bstart.begin(), bstart.end() - 1);
     for (int v = 0; v < nn; v++) border[(size_t)bfill[nbx[v]]++] = v;
-    // node -> elements
-    std::vector<int> nptr((size_t)nn + 1, 0), nlst((size_t)nel * 8);
-    for (size_t k = 0; k < conn.size(); k++) nptr[(size_t)conn[k] + 1]++;
-    for (int v = 0; v < nn; v++) nptr[v + 1] += nptr[v];
+    nbx.clear(); nbx.shrink_to_fit();
+    // the boxes are dealt to the workers in contiguous ranges of about equal node counts
+    std::vector<long long> bsplit((size_t)NT + 1, nboxes);
+    bsplit[0] = 0;
     {
-        std::vector<int> f(nptr.begin(), nptr.end() - 1);
-        for (int e = 0; e < nel; e++)
-            for (int a = 0; a < 8; a++) nlst[(size_t)f[conn[(size_t)e * 8 + a]]++] = e;
+        long long b = 0;
+        for (int i = 1; i < NT; i++) {
+            const long long target = (long long)nn * i / NT;
+            while (b < nboxes && bstart[b] < target) b++;
+            bsplit[i] = b;
+        }
     }
-    auto plan = std::make_shared<EbeTilePlan>();
-    std::vector<int> hdr, tnodes, telems;
-    std::vector<int2> steps;
-    int tnodes_off = 0;
-    std::vector<uint4> tconn;
-    std::vector<int> laff, lgen;
-    std::vector<int> estamp((size_t)nel, -1), nstamp((size_t)nn, -1), local((size_t)nn, 0);
-    std::vector<unsigned> cmask;
-    std::vector<int> el, nd, col, order, chain_start;
-    std::vector<unsigned char> tflags;
-    long long visits = 0;
+    if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: node boxes %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
+    std::vector<TileOut> outs((size_t)NT);
     static const int c_plus[4] = {1, 2, 5, 6}, c_minus[4] = {0, 3, 4, 7};
-    int ntiles = 0, max_nnode = 0;
-    for (long long b = 0; b < nboxes; b++) {
-        const int o0 = bstart[b], o1 = bstart[b + 1];
-        if (o0 == o1) continue;
-        const int t = ntiles++;
-        el.clear(); nd.clear();
-        for (int k = o0; k < o1; k++) {   // owned nodes first (ascending ids), and the elements that touch them
-            const int v = border[k];
-            nstamp[v] = t; local[v] = (int)nd.size(); nd.push_back(v);
-            for (int q = nptr[v]; q < nptr[v + 1]; q++)
-                if (estamp[nlst[q]] != t) { estamp[nlst[q]] = t; el.push_back(nlst[q]); }
-        }
-        const int nown = (int)nd.size();
-        std::sort(el.begin(), el.end());
-        size_t rim0 = nd.size();
-        for (int e : el)
-            for (int a = 0; a < 8; a++) {
-                const int v = conn[(size_t)e * 8 + a];
-                if (nstamp[v] != t) { nstamp[v] = t; nd.push_back(v); }
-            }
-        std::sort(nd.begin() + rim0, nd.end());
-        for (size_t i = rim0; i < nd.size(); i++) local[nd[i]] = (int)i;
-        if ((int)nd.size() > TILE_MAX_NODES || nd.size() > 65535) return refuse("tile with too many nodes", (long long)nd.size(), nown);
-        // chains: runs of elements (ascending ids) whose +x face is the next one's -x face, at most 16 long -- a chain
-        // sits in consecutive lanes of one 16-lane row and passes its shared-face values along the row (k_ebe_tile)
-        chain_start.clear();
-        for (size_t i = 0; i < el.size(); i++) {
-            bool linked = false;
-            if (i > 0 && (int)(i - chain_start.back()) < 16) {
-                linked = true;
-                for (int k = 0; k < 4; k++)
-                    linked = linked && conn[(size_t)el[i - 1] * 8 + c_plus[k]] == conn[(size_t)el[i] * 8 + c_minus[k]];
-            }
-            if (!linked) chain_start.push_back((int)i);
-        }
-        chain_start.push_back((int)el.size());
-        const int nchain = (int)chain_start.size() - 1;
-        // greedy colouring of the chains (two chains of one colour share no node)
-        cmask.assign(nd.size(), 0u);
-        col.resize((size_t)nchain);
-        int ncol = 0;
-        bool all_aff = true;
-        for (int ch = 0; ch < nchain; ch++) {
-            unsigned used = 0;
-            for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++)
-                for (int a = 0; a < 8; a++) used |= cmask[local[conn[(size_t)el[i] * 8 + a]]];
-            int c = 0;
-            while (c < TILE_MAXC && ((used >> c) & 1u)) c++;
-            if (c >= TILE_MAXC) return refuse("too many colours");
-            col[ch] = c; ncol = std::max(ncol, c + 1);
-            for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
-                for (int a = 0; a < 8; a++) cmask[local[conn[(size_t)el[i] * 8 + a]]] |= 1u << c;
-                all_aff = all_aff && aff[el[i]];
-            }
-        }
-        const int elem_off = (int)telems.size(), step_off = (int)steps.size();
-        tnodes_off = (int)tnodes.size();
-        tnodes.insert(tnodes.end(), nd.begin(), nd.end());
-        for (int c = 0; c < ncol; c++) {
-            const int first = (int)telems.size() - elem_off;
-            for (int ch = 0; ch < nchain; ch++) {
-                if (col[ch] != c) continue;
-                const int len = chain_start[ch + 1] - chain_start[ch];
-                const int used_in_row = ((int)telems.size() - elem_off - first) % 16;
-                if (used_in_row + len > 16)   // a chain does not straddle rows: pad the row
-                    for (int p = used_in_row; p < 16; p++) { telems.push_back(-1); tconn.push_back(make_uint4(0, 0, 0, 0)); tflags.push_back(0); }
-                for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
-                    telems.push_back(el[i]);
-                    unsigned l[8];
-                    for (int a = 0; a < 8; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * 8 + a]];
-                    tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
-                    tflags.push_back(i + 1 < chain_start[ch + 1] ? 1 : 0);   // bit 0: linked to the next lane
+    auto work = [&](int th) {
+        TileOut& o = outs[th];
+        std::vector<int> estamp((size_t)nel, -1), nstamp((size_t)nn, -1), local((size_t)nn, 0);
+        std::vector<unsigned> cmask;
+        std::vector<int> el, nd, col, chain_start;
+        for (long long b = bsplit[th]; b < bsplit[th + 1]; b++) {
+            const int o0 = bstart[b], o1 = bstart[b + 1];
+            if (o0 == o1) continue;
+            const int t = o.ntiles++;
+            el.clear(); nd.clear();
+            for (int k = o0; k < o1; k++) {   // owned nodes first (ascending ids), and the elements that touch them
+                const int v = border[k];
+                nstamp[v] = t; local[v] = (int)nd.size(); nd.push_back(v);
+                for (int q = nptr[v]; q < nptr[v + 1]; q++) {
+                    const int e = (int)((nlst[q] & 0x3fffffffu) >> 3);
+                    if (estamp[e] != t) { estamp[e] = t; el.push_back(e); }
                 }
             }
-            while (((int)telems.size() - elem_off - first) % 16) { telems.push_back(-1); tconn.push_back(make_uint4(0, 0, 0, 0)); tflags.push_back(0); }
-            const int cnt = (int)telems.size() - elem_off - first;
-            for (int r = 0; r < cnt; r += 256) {
-                const int n = std::min(256, cnt - r);
-                steps.push_back(make_int2(first + r, (r + 256 >= cnt) ? (int)((unsigned)n | 0x80000000u) : n));
+            const int nown = (int)nd.size();
+            std::sort(el.begin(), el.end());
+            const size_t rim0 = nd.size();
+            for (int e : el)
+                for (int a = 0; a < 8; a++) {
+                    const int v = conn[(size_t)e * 8 + a];
+                    if (nstamp[v] != t) { nstamp[v] = t; nd.push_back(v); }
+                }
+            std::sort(nd.begin() + rim0, nd.end());
+            for (size_t i = rim0; i < nd.size(); i++) local[nd[i]] = (int)i;
+            if ((int)nd.size() > TILE_MAX_NODES || nd.size() > 65535) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
+            // chains: runs of elements (ascending ids) whose +x face is the next one's -x face, at most 16 long -- a chain
+            // sits in consecutive lanes of one 16-lane row and passes its shared-face values along the row (k_ebe_tile)
+            chain_start.clear();
+            for (size_t i = 0; i < el.size(); i++) {
+                bool linked = false;
+                if (i > 0 && (int)(i - chain_start.back()) < 16) {
+                    linked = true;
+                    for (int k = 0; k < 4; k++)
+                        linked = linked && conn[(size_t)el[i - 1] * 8 + c_plus[k]] == conn[(size_t)el[i] * 8 + c_minus[k]];
+                }
+                if (!linked) chain_start.push_back((int)i);
             }
+            chain_start.push_back((int)el.size());
+            const int nchain = (int)chain_start.size() - 1;
+            // greedy colouring of the chains (two chains of one colour share no node)
+            cmask.assign(nd.size(), 0u);
+            col.resize((size_t)nchain);
+            int ncol = 0;
+            bool all_aff = true;
+            for (int ch = 0; ch < nchain; ch++) {
+                unsigned used = 0;
+                for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++)
+                    for (int a = 0; a < 8; a++) used |= cmask[local[conn[(size_t)el[i] * 8 + a]]];
+                int c = 0;
+                while (c < TILE_MAXC && ((used >> c) & 1u)) c++;
+                if (c >= TILE_MAXC) { o.why = "too many colours"; return; }
+                col[ch] = c; ncol = std::max(ncol, c + 1);
+                for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
+                    for (int a = 0; a < 8; a++) cmask[local[conn[(size_t)el[i] * 8 + a]]] |= 1u << c;
+                    all_aff = all_aff && aff[el[i]];
+                }
+            }
+            const int elem_off = (int)o.telems.size(), step_off = (int)o.steps.size(), tnodes_off = (int)o.tnodes.size();
+            o.tnodes.insert(o.tnodes.end(), nd.begin(), nd.end());
+            auto pad = [&] { o.telems.push_back(-1); o.tconn.push_back(make_uint4(0, 0, 0, 0)); o.tflags.push_back(0); };
+            for (int c = 0; c < ncol; c++) {
+                const int first = (int)o.telems.size() - elem_off;
+                for (int ch = 0; ch < nchain; ch++) {
+                    if (col[ch] != c) continue;
+                    const int len = chain_start[ch + 1] - chain_start[ch];
+                    const int used_in_row = ((int)o.telems.size() - elem_off - first) % 16;
+                    if (used_in_row + len > 16)   // a chain does not straddle rows: pad the row
+                        for (int p = used_in_row; p < 16; p++) pad();
+                    for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
+                        o.telems.push_back(el[i]);
+                        unsigned l[8];
+                        for (int a = 0; a < 8; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * 8 + a]];
+                        o.tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
+                        o.tflags.push_back(i + 1 < chain_start[ch + 1] ? 1 : 0);   // bit 0: linked to the next lane
+                    }
+                }
+                while (((int)o.telems.size() - elem_off - first) % 16) pad();
+                const int cnt = (int)o.telems.size() - elem_off - first;
+                for (int r = 0; r < cnt; r += 256) {
+                    const int n = std::min(256, cnt - r);
+                    o.steps.push_back(make_int2(first + r, (r + 256 >= cnt) ? (int)((unsigned)n | 0x80000000u) : n));
+                }
+            }
+            o.visits += (long long)el.size();
+            o.hdr.push_back(tnodes_off); o.hdr.push_back(nown); o.hdr.push_back((int)nd.size()); o.hdr.push_back(elem_off);
+            o.hdr.push_back(step_off); o.hdr.push_back((int)o.steps.size() - step_off);
+            o.max_nnode = std::max(o.max_nnode, (int)nd.size());
+            (all_aff ? o.laff : o.lgen).push_back(t);
+            o.taff.resize(o.telems.size(), all_aff ? 1 : 0);
         }
-        visits += (long long)el.size();
-        hdr.push_back(tnodes_off); hdr.push_back(nown); hdr.push_back((int)nd.size()); hdr.push_back(elem_off);
-        hdr.push_back(step_off); hdr.push_back((int)steps.size() - step_off);
-        max_nnode = std::max(max_nnode, (int)nd.size());
-        (all_aff ? laff : lgen).push_back(t);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int i = 1; i < NT; i++) th.emplace_back(work, i);
+        work(0);
+        for (auto& x : th) x.join();
+    }
+    for (auto& o : outs)
+        if (o.why) return refuse(o.why, o.why_a, o.why_b);
+    if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: tiles %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
+    // the workers' pieces go to the device side by side (tiles keep the order of the boxes); only the small per-tile
+    // records are renumbered on the host
+    auto plan = std::make_shared<EbeTilePlan>();
+    std::vector<size_t> toff((size_t)NT + 1, 0), noff((size_t)NT + 1, 0), eoff((size_t)NT + 1, 0), soff((size_t)NT + 1, 0);
+    long long visits = 0;
+    int max_nnode = 0;
+    for (int i = 0; i < NT; i++) {
+        toff[i + 1] = toff[i] + (size_t)outs[i].ntiles; noff[i + 1] = noff[i] + outs[i].tnodes.size();
+        eoff[i + 1] = eoff[i] + outs[i].telems.size(); soff[i + 1] = soff[i] + outs[i].steps.size();
+        visits += outs[i].visits; max_nnode = std::max(max_nnode, outs[i].max_nnode);
+    }
+    const int ntiles = (int)toff[NT];
+    if (eoff[NT] > 0x7fffffffULL || noff[NT] > 0x7fffffffULL) return refuse("too many lane slots");
+    std::vector<int> hdr, laff, lgen;
+    hdr.reserve((size_t)ntiles * 6);
+    for (int i = 0; i < NT; i++) {
+        const TileOut& o = outs[i];
+        for (size_t k = 0; k < o.hdr.size(); k += 6) {
+            hdr.push_back(o.hdr[k] + (int)noff[i]); hdr.push_back(o.hdr[k + 1]); hdr.push_back(o.hdr[k + 2]);
+            hdr.push_back(o.hdr[k + 3] + (int)eoff[i]); hdr.push_back(o.hdr[k + 4] + (int)soff[i]); hdr.push_back(o.hdr[k + 5]);
+        }
+        for (int t : o.laff) laff.push_back(t + (int)toff[i]);
+        for (int t : o.lgen) lgen.push_back(t + (int)toff[i]);
     }
     plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->max_nnode = max_nnode;
-    plan->tile_elements = visits; plan->slots = (long long)telems.size(); plan->tile_nodes = (long long)tnodes.size();
+    plan->tile_elements = visits; plan->slots = (long long)eoff[NT]; plan->tile_nodes = (long long)noff[NT];
     auto up = [&](auto& dbuf, const auto& vec) {
         dbuf.alloc(std::max<size_t>(vec.size(), 1));
         if (!vec.empty())
             FEM_HIP(hipMemcpyAsync(dbuf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
     };
-    up(plan->hdr, hdr); up(plan->steps, steps); up(plan->nodes, tnodes); up(plan->elems, telems); up(plan->conn16, tconn); up(plan->flags, tflags);
-    up(plan->list_aff, laff); up(plan->list_gen, lgen);
+    up(plan->hdr, hdr); up(plan->list_aff, laff); up(plan->list_gen, lgen);
+    plan->steps.alloc(std::max<size_t>(soff[NT], 1)); plan->nodes.alloc(std::max<size_t>(noff[NT], 1));
+    plan->elems.alloc(std::max<size_t>(eoff[NT], 1)); plan->conn16.alloc(std::max<size_t>(eoff[NT], 1));
+    plan->flags.alloc(std::max<size_t>(eoff[NT], 1));
+    DBuf<unsigned char> d_taff(std::max<size_t>(eoff[NT], 1));
+    auto piece = [&](auto* dst, const auto& vec, size_t off) {
+        if (!vec.empty())
+            FEM_HIP(hipMemcpyAsync(dst + off, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
+    };
+    for (int i = 0; i < NT; i++) {
+        const TileOut& o = outs[i];
+        piece(plan->steps.p, o.steps, soff[i]); piece(plan->nodes.p, o.tnodes, noff[i]); piece(plan->elems.p, o.telems, eoff[i]);
+        piece(plan->conn16.p, o.tconn, eoff[i]); piece(plan->flags.p, o.tflags, eoff[i]); piece(d_taff.p, o.taff, eoff[i]);
+    }
+    FEM_HIP(hipStreamSynchronize(s));
     if (!laff.empty()) {   // geometry records of the affine tiles' elements
-        std::vector<unsigned char> taff(telems.size(), 0);
-        for (int t : laff) {
-            const int e0 = hdr[6 * (size_t)t + 3];
-            const int e1 = (t + 1 < ntiles) ? hdr[6 * (size_t)(t + 1) + 3] : (int)telems.size();
-            std::fill(taff.begin() + e0, taff.begin() + e1, 1);
-        }
-        DBuf<unsigned char> d_taff;
-        up(d_taff, taff);
-        plan->geo.alloc(telems.size() * 11);
+        plan->geo.alloc(eoff[NT] * 11);
         const ElemTable& tab = host_elem_tables()[FEM_HEX];
-        hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((telems.size() + 255) / 256)), dim3(256), 0, s, telems.size(), plan->elems.p,
+        hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((eoff[NT] + 255) / 256)), dim3(256), 0, s, eoff[NT], plan->elems.p,
                            d_taff.p, grp.conn.p, m->coords.p, grp.E.p, grp.nu.p, tab.w[0], plan->geo.p);
         FEM_HIP(hipStreamSynchronize(s));
     }
-    FEM_HIP(hipStreamSynchronize(s));
     plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (verbose)
-        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine), <= %d nodes, %lld element visits in %lld lane slots for %d elements, %zu steps, set-up %.0f ms\n",
-                     ntiles, plan->n_aff, max_nnode, plan->tile_elements, plan->slots, nel, steps.size(), plan->t_setup_ms);
+        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine), <= %d nodes, %lld element visits in %lld lane slots for %d elements, %zu steps, set-up %.0f ms (%d threads)\n",
+                     ntiles, plan->n_aff, max_nnode, plan->tile_elements, plan->slots, nel, soff[NT], plan->t_setup_ms, NT);
     return plan;
 }
 

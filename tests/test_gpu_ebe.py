@@ -26,8 +26,26 @@ def _half_jitter(m):
     return m
 
 
+def _shuffled(m, seed=3):
+    """the same hex8 mesh with the elements in random order and the nodes renumbered at random: no x-neighbours in
+    consecutive lanes (chains of one element), colours as the greedy pass finds them"""
+    rng = np.random.default_rng(seed)
+    pe = rng.permutation(m.nels)
+    pn = rng.permutation(m.nnds).astype(np.int32)     # new id of old node i
+    inv = np.empty_like(pn); inv[pn] = np.arange(m.nnds, dtype=np.int32)
+    m.conn = np.ascontiguousarray(pn[m.conn.reshape(m.nels, 8)[pe]].reshape(-1))
+    m.mat_id = np.ascontiguousarray(m.mat_id[pe])
+    m.coords = np.ascontiguousarray(m.coords[inv])
+    m.bcnode = m.bcnode.copy(); m.bcnode[:, 0] = pn[m.bcnode[:, 0]]
+    if len(m.fnode):
+        m.fnode = pn[m.fnode]
+    assert len(m.telsd) == 0
+    return m
+
+
 def _meshes():
     return {
+        "hex_shuffled": _shuffled(structured_hex(13, 11, 9, jitter=0.1)),
         "hex_uniform": structured_hex(7, 6, 5),                      # every element a cube: affine path
         "hex_sheared": _sheared(structured_hex(9, 8, 7)),
         "hex_half_jitter": _half_jitter(structured_hex(9, 8, 7)),

@@ -428,7 +428,14 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     for (auto& p : part)
         for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[3 + d]); hsum[d] += p[6 + d]; }
     if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: element pass %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
-    static const int NB[3] = {15, 15, 7};
+    // FEM_AMD_TILE_NB="nx,ny,nz": box size (experiments; 15,15,7 won the sweep at config 3)
+    int NB[3] = {15, 15, 7};
+    if (const char* ps = std::getenv("FEM_AMD_TILE_NB")) {
+        int q[3] = {0, 0, 0};
+        if (std::sscanf(ps, "%d,%d,%d", &q[0], &q[1], &q[2]) == 3 && q[0] > 0 && q[1] > 0 && q[2] > 0)
+            for (int d = 0; d < 3; d++) NB[d] = q[d];
+    }
+    const int max_nodes = TILE_MAX_NODES;
     long long nbox[3];
     double h[3];
     for (int d = 0; d < 3; d++) {
@@ -475,13 +482,18 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         std::vector<int> estamp((size_t)nel, -1), nstamp((size_t)nn, -1), local((size_t)nn, 0);
         std::vector<unsigned> cmask;
         std::vector<int> el, nd, col, chain_start;
+        std::vector<std::vector<int>> todo;   // owned-node sets still to be turned into tiles (a box, or the halves of one)
         for (long long b = bsplit[th]; b < bsplit[th + 1]; b++) {
             const int o0 = bstart[b], o1 = bstart[b + 1];
             if (o0 == o1) continue;
+            todo.clear();
+            todo.emplace_back(border.begin() + o0, border.begin() + o1);
+          while (!todo.empty()) {
+            std::vector<int> own = std::move(todo.back());
+            todo.pop_back();
             const int t = o.ntiles++;
             el.clear(); nd.clear();
-            for (int k = o0; k < o1; k++) {   // owned nodes first (ascending ids), and the elements that touch them
-                const int v = border[k];
+            for (int v : own) {   // owned nodes first (ascending ids), and the elements that touch them
                 nstamp[v] = t; local[v] = (int)nd.size(); nd.push_back(v);
                 for (int q = nptr[v]; q < nptr[v + 1]; q++) {
                     const int e = (int)((nlst[q] & 0x3fffffffu) >> 3);
@@ -498,7 +510,27 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 }
             std::sort(nd.begin() + rim0, nd.end());
             for (size_t i = rim0; i < nd.size(); i++) local[nd[i]] = (int)i;
-            if ((int)nd.size() > TILE_MAX_NODES || nd.size() > 65535) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
+            if ((int)nd.size() > max_nodes) {
+                // too many nodes for the LDS image (a box of a distorted mesh may hold more than its share): halve the set
+                // of owned nodes across its longest extent and try again (the later half first: tiles stay in box order)
+                if (nown < 2) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int v : own)
+                    for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], xyz[(size_t)v * 3 + d]); mx[d] = std::max(mx[d], xyz[(size_t)v * 3 + d]); }
+                int dl = 0;
+                for (int d = 1; d < 3; d++)
+                    if ((mx[d] - mn[d]) / h[d] > (mx[dl] - mn[dl]) / h[dl]) dl = d;
+                std::vector<int> byc(own);
+                std::nth_element(byc.begin(), byc.begin() + byc.size() / 2, byc.end(),
+                                 [&](int a, int c) { return xyz[(size_t)a * 3 + dl] < xyz[(size_t)c * 3 + dl] || (xyz[(size_t)a * 3 + dl] == xyz[(size_t)c * 3 + dl] && a < c); });
+                std::vector<int> lo_half(byc.begin(), byc.begin() + byc.size() / 2), hi_half(byc.begin() + byc.size() / 2, byc.end());
+                std::sort(lo_half.begin(), lo_half.end()); std::sort(hi_half.begin(), hi_half.end());
+                o.ntiles--;
+                for (int v : nd) nstamp[v] = -1;           // the stamps of the abandoned attempt carry the same tile number
+                for (int e : el) estamp[e] = -1;
+                todo.push_back(std::move(hi_half)); todo.push_back(std::move(lo_half));
+                continue;
+            }
             // chains: runs of elements (ascending ids) whose +x face is the next one's -x face, at most 16 long -- a chain
             // sits in consecutive lanes of one 16-lane row and passes its shared-face values along the row (k_ebe_tile)
             chain_start.clear();
@@ -547,7 +579,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                         unsigned l[8];
                         for (int a = 0; a < 8; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * 8 + a]];
                         o.tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
-                        o.tflags.push_back(i + 1 < chain_start[ch + 1] ? 1 : 0);   // bit 0: linked to the next lane
+                        o.tflags.push_back((unsigned char)(2 | (i + 1 < chain_start[ch + 1] ? 1 : 0)));   // bit 1: an element, bit 0: linked to the next lane
                     }
                 }
                 while (((int)o.telems.size() - elem_off - first) % 16) pad();
@@ -563,6 +595,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             o.max_nnode = std::max(o.max_nnode, (int)nd.size());
             (all_aff ? o.laff : o.lgen).push_back(t);
             o.taff.resize(o.telems.size(), all_aff ? 1 : 0);
+          }
         }
     };
     {
@@ -653,18 +686,16 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
     static bool attr_set = false;
     if (!attr_set) {
-        FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(TILE_MAX_NODES * 28)));
-        FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(TILE_MAX_NODES * 28)));
+        for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<true>), reinterpret_cast<const void*>(k_ebe_tile<false>)})
+            FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
         attr_set = true;
     }
-    if (P.n_aff)
-        hipLaunchKernelGGL(k_ebe_tile<true>, dim3((P.n_aff + 7) / 8 * 8), dim3(256), shmem, s, P.n_aff, P.list_aff.p, P.hdr.p,
-                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
-                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done);
-    if (P.n_gen)
-        hipLaunchKernelGGL(k_ebe_tile<false>, dim3((P.n_gen + 7) / 8 * 8), dim3(256), shmem, s, P.n_gen, P.list_gen.p, P.hdr.p,
-                           P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p,
-                           A->bc_shift.p, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, y, part, done);
+    auto go = [&](auto kern, int n, const int* list) {
+        if (!n) return;
+        hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.elems.p,
+                           P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
+                           (size_t)P.slots, g, w, P.max_nnode, y, part, done);
+    };
+    go(k_ebe_tile<true>, P.n_aff, P.list_aff.p);
+    go(k_ebe_tile<false>, P.n_gen, P.list_gen.p);
 }

@@ -117,6 +117,10 @@ int fem_ctx_create(int device, fem_ctx* out)
     FEM_HIP(hipGetDeviceProperties(&prop, device));
     c->num_cu = prop.multiProcessorCount;
     FEM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    FEM_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    FEM_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+    FEM_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
+    FEM_HIP(hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming));
     FEM_HIP(hipEventCreate(&c->t0));
     FEM_HIP(hipEventCreate(&c->t1));
     fem::upload_elem_tables(c->stream);
@@ -133,6 +137,8 @@ int fem_ctx_destroy(fem_ctx c)
     (void)hipStreamSynchronize(c->stream);
     (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->comm_stream);
+    (void)hipEventDestroy(c->ev_a); (void)hipEventDestroy(c->ev_b); (void)hipEventDestroy(c->ev_c);
     delete c;
     pool_trim();   // cached device blocks go back to the driver with the context
     FEM_CATCH

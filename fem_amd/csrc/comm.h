@@ -35,3 +35,5 @@ struct fem_comm_s {
 // halo operations on a mesh with an attached Halo (no-ops without one)
 // element (node v, component c) of `vec` lives at vec[v*sn + c*sc]
 void halo_sum(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc);
+// the same on a given stream (the Krylov solver runs it beside the interior part of the product)
+void halo_sum_on(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, hipStream_t s);

@@ -205,11 +205,12 @@ __global__ void __launch_bounds__(256) k_halo_unpack(int ninodes, const int* __r
 
 }  // namespace fem
 
-void halo_sum(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc)
+void halo_sum(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc) { halo_sum_on(mesh, vec, ncomp, sn, sc, mesh->ctx->stream); }
+
+void halo_sum_on(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, hipStream_t s)
 {
     Halo* h = mesh->halo.get();
     if (!h || h->comm->size == 1) return;
-    hipStream_t s = mesh->ctx->stream;
     const int nslots = h->neigh_ptr[h->nneigh];
     if (nslots == 0) return;
     FEM_CHECK((size_t)ncomp <= 6, 63, "halo_sum: too many components");

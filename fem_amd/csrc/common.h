@@ -96,6 +96,8 @@ inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 struct fem_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t comm_stream = nullptr;   // collectives and halo exchanges that run beside the compute stream (KSP overlap)
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;   // cross-stream hand-overs of the same
     hipEvent_t t0 = nullptr, t1 = nullptr;
     int num_cu = 256;
     void bind() const { FEM_HIP(hipSetDevice(device)); }

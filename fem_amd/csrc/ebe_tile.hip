@@ -22,6 +22,7 @@
 #include <memory>
 #include <thread>
 
+#include "comm.h"
 #include "hex8_ebe.h"
 #include "objects.h"
 
@@ -43,7 +44,10 @@ struct EbeTilePlan {
     DBuf<int> elems;                     // [slots] global element id of every lane slot, colour by colour; -1 = padding
     DBuf<uint4> conn16;                  // the same elements' eight tile-local node numbers (16 bit each)
     DBuf<unsigned char> flags;           // [slots] bit 0: the element's +x face is the -x face of the next lane's element
-    DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others
+    DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others; in both lists the tiles
+                                         // that own a node shared with another domain come first
+    int n_aff_if = 0, n_gen_if = 0;      // how many of each list those are
+    const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
     double t_setup_ms = 0.0;
 };
@@ -348,6 +352,7 @@ struct TileOut {   // what one worker thread produced for its range of boxes (of
     std::vector<int2> steps;
     std::vector<uint4> tconn;
     std::vector<unsigned char> tflags, taff;   // taff: the slot belongs to a tile of parallelepipeds
+    std::vector<unsigned char> tif;            // per tile: owns a node shared with another domain
     long long visits = 0;
     int ntiles = 0, max_nnode = 0;
     const char* why = nullptr;   // refusal
@@ -475,6 +480,16 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         }
     }
     if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: node boxes %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
+    // nodes shared with other domains (a partitioned mesh): tiles that own one are computed first, so that the halo exchange
+    // of their rows can run beside the others (ksp.hip)
+    std::vector<unsigned char> shared_node;
+    if (Halo* hl = m->halo.get(); hl && hl->ninodes > 0) {
+        std::vector<int> inodes((size_t)hl->ninodes);
+        FEM_HIP(hipMemcpyAsync(inodes.data(), hl->inodes.p, inodes.size() * sizeof(int), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        shared_node.assign((size_t)nn, 0);
+        for (int v : inodes) shared_node[(size_t)v] = 1;
+    }
     std::vector<TileOut> outs((size_t)NT);
     static const int c_plus[4] = {1, 2, 5, 6}, c_minus[4] = {0, 3, 4, 7};
     auto work = [&](int th) {
@@ -595,6 +610,10 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             o.max_nnode = std::max(o.max_nnode, (int)nd.size());
             (all_aff ? o.laff : o.lgen).push_back(t);
             o.taff.resize(o.telems.size(), all_aff ? 1 : 0);
+            bool iface = false;
+            if (!shared_node.empty())
+                for (int k = 0; k < nown && !iface; k++) iface = shared_node[(size_t)nd[k]] != 0;
+            o.tif.push_back(iface ? 1 : 0);
           }
         }
     };
@@ -621,6 +640,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     const int ntiles = (int)toff[NT];
     if (eoff[NT] > 0x7fffffffULL || noff[NT] > 0x7fffffffULL) return refuse("too many lane slots");
     std::vector<int> hdr, laff, lgen;
+    std::vector<unsigned char> tif;
     hdr.reserve((size_t)ntiles * 6);
     for (int i = 0; i < NT; i++) {
         const TileOut& o = outs[i];
@@ -630,7 +650,13 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         }
         for (int t : o.laff) laff.push_back(t + (int)toff[i]);
         for (int t : o.lgen) lgen.push_back(t + (int)toff[i]);
+        tif.insert(tif.end(), o.tif.begin(), o.tif.end());
     }
+    auto iface_first = [&](std::vector<int>& l) {
+        return (int)(std::stable_partition(l.begin(), l.end(), [&](int t) { return tif[(size_t)t] != 0; }) - l.begin());
+    };
+    plan->n_aff_if = iface_first(laff); plan->n_gen_if = iface_first(lgen);
+    plan->halo_seen = m->halo.get();
     plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->max_nnode = max_nnode;
     plan->tile_elements = visits; plan->slots = (long long)eoff[NT]; plan->tile_nodes = (long long)noff[NT];
     auto up = [&](auto& dbuf, const auto& vec) {
@@ -675,7 +701,8 @@ void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_til
 }
 
 // y = K x, p.Kp partials into part[0 .. ntiles)
-void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done)
+// phase -1: every tile; 0: the tiles that own nodes shared with other domains; 1: the others
+void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase)
 {
     fem_mesh m = A->mesh;
     hipStream_t s = A->ctx->stream;
@@ -696,6 +723,9 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
                            (size_t)P.slots, g, w, P.max_nnode, y, part, done);
     };
-    go(k_ebe_tile<true>, P.n_aff, P.list_aff.p);
-    go(k_ebe_tile<false>, P.n_gen, P.list_gen.p);
+    const int a0 = phase == 1 ? P.n_aff_if : 0, a1 = phase == 0 ? P.n_aff_if : P.n_aff;
+    const int g0 = phase == 1 ? P.n_gen_if : 0, g1 = phase == 0 ? P.n_gen_if : P.n_gen;
+    go(k_ebe_tile<true>, a1 - a0, P.list_aff.p + a0);
+    go(k_ebe_tile<false>, g1 - g0, P.list_gen.p + g0);
 }
+bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P) { return P.halo_seen == (const void*)A->mesh->halo.get(); }

@@ -974,7 +974,8 @@ static int ebe_blocks(const fem_mesh m)
 
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);   // ebe_tile.hip
 int ebe_tile_partials(const EbeTilePlan& P);
-void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done);
+void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase);
+bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P);
 
 void mat_set_mult_type_impl(fem_mat A, const char* type)
 {
@@ -1112,6 +1113,20 @@ int ebe_apply_elements(fem_mat A, const double* x, double* part, const int* done
     ebe_mark(A);
     return off;
 }
+// the one-pass product in two parts for a partitioned mesh (ksp.hip): phase 0 = the tiles that own nodes shared with other
+// domains, phase 1 = the rest; false when this Mat's product cannot be split that way
+bool ebe_tile_phase(fem_mat A, const double* x, double* y, double* partial, const int* done, int phase)
+{
+    if (!A->mult_ebe || !A->ebe_use_tile || !ebe_tile_split_valid(A, *A->pat->ebe_tile)) return false;
+    if (phase == 0) {   // (the profile's marks: before the first part, after the second)
+        A->sampling = A->profiling > 0 && (A->prod_count++ % (size_t)A->profiling) == 0;
+        ebe_mark(A);
+    }
+    if (phase >= 0) ebe_tile_mult(A, *A->pat->ebe_tile, x, y, partial ? partial : A->ebe_partial.p, done, phase);
+    if (phase == 1) { ebe_mark(A); ebe_mark(A); ebe_mark(A); }
+    return true;
+}
+
 void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const int* done)
 {
     fem_mesh m = A->mesh;
@@ -1120,7 +1135,7 @@ void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const
     if (A->ebe_use_tile) {
         A->sampling = A->profiling > 0 && (A->prod_count++ % (size_t)A->profiling) == 0;
         ebe_mark(A);
-        ebe_tile_mult(A, *A->pat->ebe_tile, x, y, part, done);
+        ebe_tile_mult(A, *A->pat->ebe_tile, x, y, part, done, -1);
         ebe_mark(A); ebe_mark(A); ebe_mark(A);   // (one stage: the profile keeps its four marks per product)
         return;
     }

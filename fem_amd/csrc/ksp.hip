@@ -29,6 +29,7 @@ using namespace fem;
 
 void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const int* done);
 void mat_set_mult_type_impl(fem_mat A, const char* type);
+bool ebe_tile_phase(fem_mat A, const double* x, double* y, double* partial, const int* done, int phase);   // elem_kernels.hip
 void mat_get_diagonal_raw(fem_mat A, double* d);
 
 namespace fem {
@@ -595,6 +596,15 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
         hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, s, n, pd, b->d.p, k->dinv.p, x->d.p, k->r.p, k->p.p, owned,
                            k->pzz.p, k->pzr.p);
     }
+    // Partitioned mesh + one-pass element-by-element product, FEM_AMD_OVERLAP=1: the tiles that own shared nodes run first and
+    // the halo sum of their rows of w travels on the context's second stream while the other tiles compute (two event
+    // hand-overs per iteration; the all-reduces stay on the compute stream, every domain issues everything in one order).
+    // Off by default: on one GPU with a single-rank RCCL communicator the hand-overs cost more than a neighbour exchange
+    // is expected to take and no second GPU was available to measure the other side.
+    static const bool overlap_env = std::getenv("FEM_AMD_OVERLAP") && std::atoi(std::getenv("FEM_AMD_OVERLAP")) != 0;
+    const bool overlap = comm && overlap_env && ebe_tile_phase(A, nullptr, nullptr, nullptr, nullptr, -2);
+    fem_ctx cx = A->ctx;
+    hipStream_t cs = cx->comm_stream;
     // multi-domain: reduce -> all-reduce -> logic reads st->red;  single domain: logic reduces the partials itself
     auto reduce_zz_zr = [&] {
         if (!comm) return;
@@ -613,6 +623,25 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
         const bool sample = k->profiling > 0 && (queued % k->profiling) == 0;
         queued++;
         if (sample) FEM_HIP(hipEventRecord(next_event(), s));
+        if (overlap) {
+            ebe_tile_phase(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done, 0);        // tiles with shared nodes
+            FEM_HIP(hipEventRecord(cx->ev_a, s));
+            ebe_tile_phase(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done, 1);        // the rest
+            if (sample) FEM_HIP(hipEventRecord(next_event(), s));
+            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr,
+                               A->spmv_grid, &st->red[2], &st->done);
+            FEM_HIP(hipStreamWaitEvent(cs, cx->ev_a, 0));                             // second stream: halo sum of w
+            halo_sum_on(A->mesh, k->w.p, pd, pd, 1, cs);
+            FEM_HIP(hipEventRecord(cx->ev_c, cs));
+            comm->allreduce_sum(&st->red[2], 1, s);                                   // p.Kp over the domains
+            FEM_HIP(hipStreamWaitEvent(s, cx->ev_c, 0));
+            hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, (const double*)nullptr, A->spmv_grid,
+                               mg ? (const double*)nullptr : k->dinv.p, k->p.p, k->w.p, x->d.p, k->r.p, owned, k->pzz.p,
+                               k->pzr.p);
+            if (mg) apply_pc_and_dots();
+            reduce_zz_zr();
+            return;
+        }
         mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
         if (sample) FEM_HIP(hipEventRecord(next_event(), s));
         if (reduce_pw_first)

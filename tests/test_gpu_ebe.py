@@ -140,6 +140,36 @@ def test_ebe_on_a_partitioned_mesh(oracle):
                 assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])
 
 
+@pytest.mark.parametrize("world,npr", [(4, (9, 8, 5)), (8, (5, 6, 5))])
+def test_exchange_beside_the_interior_tiles_gives_the_same_fields(world, npr):
+    """FEM_AMD_OVERLAP=1 (the halo sum of w on the second stream while the tiles without shared nodes compute) against the
+    one-stream schedule: same iteration count, bitwise the same displacements.  The switch is read once per process, so
+    both runs are child processes."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from tests.test_gpu_multidomain import _run_domains
+grid, out = _run_domains(%d, %r, 0.1, "-mat_mult_type ebe -ksp_rtol 1e-12")
+h = hashlib.sha256()
+for (u, s, its, reason, y, gid) in out:
+    assert reason > 0
+    h.update(np.ascontiguousarray(u).tobytes()); h.update(np.ascontiguousarray(y).tobytes())
+print("RESULT", [o[2] for o in out], h.hexdigest())
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), world, npr)
+    res = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, FEM_AMD_OVERLAP=flag, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "RESULT" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+        res.append([l for l in p.stdout.splitlines() if l.startswith("RESULT")][0])
+    assert res[0] == res[1]
+
+
 def test_ebe_full_size_config3(gpu_ctx):
     """Config 3 at full size: same iteration count (+-2) and displacement field as the assembled SpMV."""
     m = structured_hex(149)

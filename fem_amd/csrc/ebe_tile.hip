@@ -1,5 +1,5 @@
-// fem_amd/csrc/ebe_tile.hip -- MatMult by element-by-element recomputation, one pass: y = K x for a mesh of hex8
-// elements without the element-force buffer of the two-kernel product (elem_kernels.hip: k_ebe_apply + k_ebe_gather,
+// fem_amd/csrc/ebe_tile.hip -- MatMult by element-by-element recomputation, one pass: y = K x for a mesh of hex8 (or,
+// same plan in two dimensions, quad4) elements without the element-force buffer of the two-kernel product (elem_kernels.hip: k_ebe_apply + k_ebe_gather,
 // 1.3 GB of traffic per product at config 3, half of it that buffer written and read back).
 //
 // Tiles.  The nodes are binned into boxes (15 x 15 x 7 nodes of a regular grid; any mesh: boxes of the mean element
@@ -24,6 +24,7 @@
 
 #include "comm.h"
 #include "hex8_ebe.h"
+#include "quad4_ebe.h"
 #include "objects.h"
 
 using namespace fem;
@@ -323,6 +324,135 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// The tile product of a quad4 mesh (plane strain; config 2): the same plan in two dimensions -- 31 x 31 owned nodes per
+// tile, chains of 16 elements along x (two per element row, so the greedy pass needs four colours), LDS image 20 B per node
+// -- and the bilinear arithmetic of quad4_ebe.h.  At a million dofs the CG iteration is a handful of 10 microsecond
+// kernels: one kernel for the product instead of element forces + gather + a reduction of their partials.
+__global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+                                                     const int2* __restrict__ steps, const int* __restrict__ tnodes,
+                                                     const int* __restrict__ telems, const uint4* __restrict__ tconn,
+                                                     const unsigned char* __restrict__ tflags,
+                                                     const double* __restrict__ coords, const double* __restrict__ Ev,
+                                                     const double* __restrict__ nuv, const double* __restrict__ x,
+                                                     const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
+                                                     const double* __restrict__ bc_shift, double g, double w, int max_nnode,
+                                                     double* __restrict__ y, double* __restrict__ partial,
+                                                     const int* __restrict__ done)
+{
+    if (done && *done) return;
+    extern __shared__ double lds[];
+    __shared__ double sh[4];
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // XCD-wise, as k_ebe_tile
+    if (lb >= (unsigned)nlist) return;
+    const int t = list[lb];
+    const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
+    const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
+    double* acc = lds;
+    int* gl = reinterpret_cast<int*>(lds + 2 * (size_t)max_nnode);
+    {
+        int nv[12];
+#pragma unroll
+        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nnode) { gl[i] = nv[j]; acc[2 * i] = 0.0; acc[2 * i + 1] = 0.0; }
+        }
+    }
+    __syncthreads();
+    // a lane's element one step ahead: local numbers, flag, E and nu, and -- through the node list in LDS -- the gathers of the
+    // coordinates and of x for its -x edge (a linked lane takes the +x edge from the next lane, a chain's last lane loads it)
+    struct El { uint4 c16; double E, nu, X[4][2], u[4][2]; unsigned fl; };
+    auto fetch = [&](El& el, int s) {
+        el.fl = 0;
+        if (s >= nsteps) return;
+        const int2 st = steps[step_off + s];
+        if ((int)threadIdx.x >= (st.y & 0x7fffffff)) return;
+        const size_t k = (size_t)elem_off + st.x + threadIdx.x;
+        const int e = telems[k];
+        if (e < 0) return;
+        el.c16 = tconn[k];
+        el.fl = tflags[k];
+        el.E = Ev[e]; el.nu = nuv[e];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if ((el.fl & 1u) && (a == 1 || a == 2)) continue;
+            const size_t v = (size_t)gl[tile_loc(el.c16, a)];
+#pragma unroll
+            for (int d = 0; d < 2; d++) { el.X[a][d] = coords[v * 2 + d]; el.u[a][d] = x[v * 2 + d]; }
+        }
+    };
+    // two steps ahead: every tile of a million-dof mesh is resident at once (529 workgroups; three waves per SIMD at 160
+    // registers -- a third stage would not fit), so the kernel lasts as long as one tile's chain of latencies
+    El e0, e1, e2;
+    fetch(e0, 0); fetch(e1, 1);
+    for (int s = 0; s < nsteps; s++) {
+        const bool bar = steps[step_off + s].y < 0;
+        fetch(e2, s + 2);
+        const bool valid = (e0.fl & 2u) != 0, linked = (e0.fl & 1u) != 0;
+        {   // the +x edge (nodes 1, 2) of a linked lane: the next lane's -x edge (nodes 0, 3)
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const double x1 = row_next(e0.X[0][d]), x2 = row_next(e0.X[3][d]), u1 = row_next(e0.u[0][d]), u2 = row_next(e0.u[3][d]);
+                if (linked) { e0.X[1][d] = x1; e0.X[2][d] = x2; e0.u[1][d] = u1; e0.u[2][d] = u2; }
+            }
+        }
+        double fe[4][2], dot;
+        const DCoef D = dmat_coef(valid ? e0.E : 1.0, valid ? e0.nu : 0.25);
+        quad4_forces(e0.X, e0.u, g, w, D.d12, D.d44, fe, dot);
+        {   // +x edge forces of a linked lane go to the next lane's -x edge nodes
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(e0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const double p1 = row_prev(fe[1][d]), p2 = row_prev(fe[2][d]);
+                if (recv) { fe[0][d] += p1; fe[3][d] += p2; }
+            }
+        }
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (linked && (a == 1 || a == 2)) continue;   // handed over
+                const int la = tile_loc(e0.c16, a);
+#pragma unroll
+                for (int d = 0; d < 2; d++)   // one writer per node and colour
+                    __hip_atomic_fetch_add(&acc[2 * la + d], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (bar) __syncthreads();
+        e0 = e1; e1 = e2;
+    }
+    double dot = 0.0;
+    for (int i0n = 0; i0n < nown; i0n += 1024) {
+        int kb[4];
+        double xv[4][2];
+        size_t vv[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0n + (int)threadIdx.x + 256 * j;
+            vv[j] = (i < nown) ? (size_t)gl[i] : 0;
+            kb[j] = (i < nown && bc_node) ? bc_node[vv[j]] : -1;
+#pragma unroll
+            for (int d = 0; d < 2; d++) xv[j][d] = (i < nown) ? x[vv[j] * 2 + d] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0n + (int)threadIdx.x + 256 * j;
+            if (i >= nown) continue;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                double sv = acc[2 * i + d];
+                if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sv += bc_shift[kb[j] + d] * xv[j][d];   // ApplyKBC INSERTs on the diagonal only
+                y[vv[j] * 2 + d] = sv;
+                dot += xv[j][d] * sv;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 // the parallelepiped test of hex_forces on the host (same tolerance)
 static bool host_hex_affine(const double (&X)[8][3])
 {
@@ -381,7 +511,10 @@ void parallel_ranges(long long n, int nthreads, F f)   // f(thread, first, last)
 // elements or a tile would not fit (nodes, colours): the caller keeps the two-kernel product.
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
 {
-    if (m->groups.size() != 1 || m->groups[0].type != FEM_HEX || m->pdim != 3 || !m->pattern) return nullptr;
+    if (m->groups.size() != 1 || !m->pattern) return nullptr;
+    const bool hex = m->groups[0].type == FEM_HEX && m->pdim == 3;
+    if (!hex && !(m->groups[0].type == FEM_QUA && m->pdim == 2)) return nullptr;
+    const int npe = hex ? 8 : 4, pd = hex ? 3 : 2, nfp = npe / 2;   // nodes per element, dimensions, nodes of a face
     static const bool verbose = std::getenv("FEM_AMD_EBE_VERBOSE") != nullptr;
     auto refuse = [&](const char* why, long long a = 0, long long b = 0) -> std::shared_ptr<EbeTilePlan> {
         if (verbose) std::fprintf(stderr, "[fem_amd] ebe tiles: not used (%s %lld %lld)\n", why, a, b);
@@ -394,15 +527,15 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     const int NT = worker_count();
     auto tl = t0;
     // connectivity, coordinates and the node -> element lists of the symbolic phase (codes element << 3 | local node, ascending)
-    std::vector<int> conn((size_t)nel * 8), nptr((size_t)nn + 1);
-    std::vector<double> xyz((size_t)nn * 3);
-    std::vector<unsigned> nlst((size_t)nel * 8);
+    std::vector<int> conn((size_t)nel * npe), nptr((size_t)nn + 1);
+    std::vector<double> xyz((size_t)nn * pd);
+    std::vector<unsigned> nlst((size_t)nel * npe);
     FEM_HIP(hipMemcpyAsync(conn.data(), grp.conn.p, conn.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipMemcpyAsync(xyz.data(), m->coords.p, xyz.size() * sizeof(double), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipMemcpyAsync(nptr.data(), m->pattern->n2e_ptr.p, nptr.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipMemcpyAsync(nlst.data(), m->pattern->n2e.p, nlst.size() * sizeof(unsigned), hipMemcpyDeviceToHost, s));
     FEM_HIP(hipStreamSynchronize(s));
-    if (nptr[nn] != nel * 8) return refuse("node lists do not match the group");
+    if (nptr[nn] != nel * npe) return refuse("node lists do not match the group");
     if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: copies to the host %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
     // grid of the mean element size over the bounding box of the nodes; node -> box of NB nodes per direction
     std::vector<unsigned char> aff((size_t)nel);
@@ -410,23 +543,29 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     parallel_ranges(nn, NT, [&](int th, long long v0, long long v1) {
         auto& p = part[th];
         for (long long v = v0; v < v1; v++)
-            for (int d = 0; d < 3; d++) { p[d] = std::min(p[d], xyz[(size_t)v * 3 + d]); p[3 + d] = std::max(p[3 + d], xyz[(size_t)v * 3 + d]); }
+            for (int d = 0; d < pd; d++) { p[d] = std::min(p[d], xyz[(size_t)v * pd + d]); p[3 + d] = std::max(p[3 + d], xyz[(size_t)v * pd + d]); }
     });
     parallel_ranges(nel, NT, [&](int th, long long e0, long long e1) {
         auto& p = part[th];
         for (long long e = e0; e < e1; e++) {
-            double X[8][3];
-            for (int a = 0; a < 8; a++)
-                for (int d = 0; d < 3; d++) X[a][d] = xyz[(size_t)conn[(size_t)e * 8 + a] * 3 + d];
-            // spacing of the grid the nodes sit on: per direction the longest of the three mean edge vectors of the element
+            double X[8][3] = {};
+            for (int a = 0; a < npe; a++)
+                for (int d = 0; d < pd; d++) X[a][d] = xyz[(size_t)conn[(size_t)e * npe + a] * pd + d];
+            // spacing of the grid the nodes sit on: per direction the longest of the mean edge vectors of the element
             // (exact on a regular brick, unbiased under node jitter -- the bounding box of a jittered element is not)
-            for (int d = 0; d < 3; d++) {
-                const double ex = 0.25 * std::fabs((X[1][d] + X[2][d] + X[5][d] + X[6][d]) - (X[0][d] + X[3][d] + X[4][d] + X[7][d]));
-                const double ey = 0.25 * std::fabs((X[3][d] + X[2][d] + X[7][d] + X[6][d]) - (X[0][d] + X[1][d] + X[4][d] + X[5][d]));
-                const double ez = 0.25 * std::fabs((X[4][d] + X[5][d] + X[6][d] + X[7][d]) - (X[0][d] + X[1][d] + X[2][d] + X[3][d]));
-                p[6 + d] += std::max(ex, std::max(ey, ez));
+            for (int d = 0; d < pd; d++) {
+                if (hex) {
+                    const double ex = 0.25 * std::fabs((X[1][d] + X[2][d] + X[5][d] + X[6][d]) - (X[0][d] + X[3][d] + X[4][d] + X[7][d]));
+                    const double ey = 0.25 * std::fabs((X[3][d] + X[2][d] + X[7][d] + X[6][d]) - (X[0][d] + X[1][d] + X[4][d] + X[5][d]));
+                    const double ez = 0.25 * std::fabs((X[4][d] + X[5][d] + X[6][d] + X[7][d]) - (X[0][d] + X[1][d] + X[2][d] + X[3][d]));
+                    p[6 + d] += std::max(ex, std::max(ey, ez));
+                } else {
+                    const double ex = 0.5 * std::fabs((X[1][d] + X[2][d]) - (X[0][d] + X[3][d]));
+                    const double ey = 0.5 * std::fabs((X[3][d] + X[2][d]) - (X[0][d] + X[1][d]));
+                    p[6 + d] += std::max(ex, ey);
+                }
             }
-            aff[(size_t)e] = host_hex_affine(X) ? 1 : 0;
+            aff[(size_t)e] = (hex && host_hex_affine(X)) ? 1 : 0;
         }
     });
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
@@ -434,16 +573,16 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], p[d]); hi[d] = std::max(hi[d], p[3 + d]); hsum[d] += p[6 + d]; }
     if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: element pass %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
     // FEM_AMD_TILE_NB="nx,ny,nz": box size (experiments; 15,15,7 won the sweep at config 3)
-    int NB[3] = {15, 15, 7};
+    int NB[3] = {hex ? 15 : 31, hex ? 15 : 31, hex ? 7 : 1};   // quad4: 32 x 32 elements, 1,089 nodes of 20 B
     if (const char* ps = std::getenv("FEM_AMD_TILE_NB")) {
         int q[3] = {0, 0, 0};
         if (std::sscanf(ps, "%d,%d,%d", &q[0], &q[1], &q[2]) == 3 && q[0] > 0 && q[1] > 0 && q[2] > 0)
-            for (int d = 0; d < 3; d++) NB[d] = q[d];
+            for (int d = 0; d < pd; d++) NB[d] = q[d];
     }
     const int max_nodes = TILE_MAX_NODES;
-    long long nbox[3];
-    double h[3];
-    for (int d = 0; d < 3; d++) {
+    long long nbox[3] = {1, 1, 1};
+    double h[3] = {1.0, 1.0, 1.0};
+    for (int d = 0; d < pd; d++) {
         h[d] = hsum[d] / nel;
         if (!(h[d] > 0.0)) return refuse("flat mesh");
         const long long npts = (long long)std::llround((hi[d] - lo[d]) / h[d]) + 1;
@@ -451,9 +590,9 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     }
     if ((double)nbox[0] * nbox[1] * nbox[2] > 4.0 * nn + 1024.0) return refuse("grid does not describe the mesh");
     auto box_of = [&](long long v) {
-        long long b[3];
-        for (int d = 0; d < 3; d++) {
-            long long i = std::llround((xyz[(size_t)v * 3 + d] - lo[d]) / h[d]);
+        long long b[3] = {0, 0, 0};
+        for (int d = 0; d < pd; d++) {
+            long long i = std::llround((xyz[(size_t)v * pd + d] - lo[d]) / h[d]);
             b[d] = std::min(std::max(i / NB[d], 0LL), nbox[d] - 1);
         }
         return b[0] + nbox[0] * (b[1] + nbox[1] * b[2]);
@@ -519,8 +658,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             std::sort(el.begin(), el.end());
             const size_t rim0 = nd.size();
             for (int e : el)
-                for (int a = 0; a < 8; a++) {
-                    const int v = conn[(size_t)e * 8 + a];
+                for (int a = 0; a < npe; a++) {
+                    const int v = conn[(size_t)e * npe + a];
                     if (nstamp[v] != t) { nstamp[v] = t; nd.push_back(v); }
                 }
             std::sort(nd.begin() + rim0, nd.end());
@@ -531,13 +670,13 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 if (nown < 2) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
                 for (int v : own)
-                    for (int d = 0; d < 3; d++) { mn[d] = std::min(mn[d], xyz[(size_t)v * 3 + d]); mx[d] = std::max(mx[d], xyz[(size_t)v * 3 + d]); }
+                    for (int d = 0; d < pd; d++) { mn[d] = std::min(mn[d], xyz[(size_t)v * pd + d]); mx[d] = std::max(mx[d], xyz[(size_t)v * pd + d]); }
                 int dl = 0;
-                for (int d = 1; d < 3; d++)
+                for (int d = 1; d < pd; d++)
                     if ((mx[d] - mn[d]) / h[d] > (mx[dl] - mn[dl]) / h[dl]) dl = d;
                 std::vector<int> byc(own);
                 std::nth_element(byc.begin(), byc.begin() + byc.size() / 2, byc.end(),
-                                 [&](int a, int c) { return xyz[(size_t)a * 3 + dl] < xyz[(size_t)c * 3 + dl] || (xyz[(size_t)a * 3 + dl] == xyz[(size_t)c * 3 + dl] && a < c); });
+                                 [&](int a, int c) { return xyz[(size_t)a * pd + dl] < xyz[(size_t)c * pd + dl] || (xyz[(size_t)a * pd + dl] == xyz[(size_t)c * pd + dl] && a < c); });
                 std::vector<int> lo_half(byc.begin(), byc.begin() + byc.size() / 2), hi_half(byc.begin() + byc.size() / 2, byc.end());
                 std::sort(lo_half.begin(), lo_half.end()); std::sort(hi_half.begin(), hi_half.end());
                 o.ntiles--;
@@ -553,8 +692,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 bool linked = false;
                 if (i > 0 && (int)(i - chain_start.back()) < 16) {
                     linked = true;
-                    for (int k = 0; k < 4; k++)
-                        linked = linked && conn[(size_t)el[i - 1] * 8 + c_plus[k]] == conn[(size_t)el[i] * 8 + c_minus[k]];
+                    for (int k = 0; k < nfp; k++)
+                        linked = linked && conn[(size_t)el[i - 1] * npe + c_plus[k]] == conn[(size_t)el[i] * npe + c_minus[k]];
                 }
                 if (!linked) chain_start.push_back((int)i);
             }
@@ -568,13 +707,13 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             for (int ch = 0; ch < nchain; ch++) {
                 unsigned used = 0;
                 for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++)
-                    for (int a = 0; a < 8; a++) used |= cmask[local[conn[(size_t)el[i] * 8 + a]]];
+                    for (int a = 0; a < npe; a++) used |= cmask[local[conn[(size_t)el[i] * npe + a]]];
                 int c = 0;
                 while (c < TILE_MAXC && ((used >> c) & 1u)) c++;
                 if (c >= TILE_MAXC) { o.why = "too many colours"; return; }
                 col[ch] = c; ncol = std::max(ncol, c + 1);
                 for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
-                    for (int a = 0; a < 8; a++) cmask[local[conn[(size_t)el[i] * 8 + a]]] |= 1u << c;
+                    for (int a = 0; a < npe; a++) cmask[local[conn[(size_t)el[i] * npe + a]]] |= 1u << c;
                     all_aff = all_aff && aff[el[i]];
                 }
             }
@@ -591,8 +730,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                         for (int p = used_in_row; p < 16; p++) pad();
                     for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
                         o.telems.push_back(el[i]);
-                        unsigned l[8];
-                        for (int a = 0; a < 8; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * 8 + a]];
+                        unsigned l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        for (int a = 0; a < npe; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * npe + a]];
                         o.tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
                         o.tflags.push_back((unsigned char)(2 | (i + 1 < chain_start[ch + 1] ? 1 : 0)));   // bit 1: an element, bit 0: linked to the next lane
                     }
@@ -681,7 +820,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     FEM_HIP(hipStreamSynchronize(s));
     if (!laff.empty()) {   // geometry records of the affine tiles' elements
         plan->geo.alloc(eoff[NT] * 11);
-        const ElemTable& tab = host_elem_tables()[FEM_HEX];
+        const ElemTable& tab = host_elem_tables()[FEM_HEX];   // (only hex8 tiles are ever in this list)
         hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((eoff[NT] + 255) / 256)), dim3(256), 0, s, eoff[NT], plan->elems.p,
                            d_taff.p, grp.conn.p, m->coords.p, grp.E.p, grp.nu.p, tab.w[0], plan->geo.p);
         FEM_HIP(hipStreamSynchronize(s));
@@ -707,9 +846,24 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     fem_mesh m = A->mesh;
     hipStream_t s = A->ctx->stream;
     auto& grp = m->groups[0];
-    const ElemTable& tab = host_elem_tables()[FEM_HEX];
+    const ElemTable& tab = host_elem_tables()[grp.type];
     const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
     const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
+    if (grp.type == FEM_QUA) {
+        const size_t shq = (size_t)P.max_nnode * (2 * sizeof(double) + sizeof(int));
+        static bool qattr = false;
+        if (!qattr) {
+            FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_q4), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        TILE_MAX_NODES * 20));
+            qattr = true;
+        }
+        const int n0 = phase == 1 ? P.n_gen_if : 0, n1 = phase == 0 ? P.n_gen_if : P.n_gen;
+        if (n1 > n0)
+            hipLaunchKernelGGL(k_ebe_tile_q4, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shq, s, n1 - n0, P.list_gen.p + n0, P.hdr.p,
+                               P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn,
+                               A->bc_dof.p, A->bc_shift.p, g, w, P.max_nnode, y, part, done);
+        return;
+    }
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
     static bool attr_set = false;
     if (!attr_set) {

@@ -1043,8 +1043,8 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
         FEM_HIP(hipStreamSynchronize(s));
         P.ebe_ready = true;
     }
-    // `ebe` on a mesh of hex8 elements alone: the one-pass product by tiles (ebe_tile.hip); `ebe_gather` and every other
-    // mesh: element buffer + node gather.  FEM_AMD_EBE_TILE=0 keeps `ebe` on the latter as well (measurement).
+    // `ebe` on a mesh of hex8 (or of quad4) elements alone: the one-pass product by tiles (ebe_tile.hip); `ebe_gather` and
+    // every other mesh: element buffer + node gather.  FEM_AMD_EBE_TILE=0 keeps `ebe` on the latter as well (measurement).
     static const bool tile_env = !(std::getenv("FEM_AMD_EBE_TILE") && std::atoi(std::getenv("FEM_AMD_EBE_TILE")) == 0);
     if (t == "ebe" && tile_env && !P.ebe_tile_tried) {
         P.ebe_tile = ebe_tile_build(m, s);

@@ -172,8 +172,8 @@ int fem_mat_get_csr(fem_mat mat, int *rowptr, int *colind, double *val);
 /* How MatMult is carried out.  "assembled" (default): sliced block-ELL SpMV over the stored blocks.
  * "ebe": element-by-element recomputation from the mesh (PETSc's MATSHELL idea: same operator, no
  * matrix read; needs the usual assemble + ApplyKBC first, which also serve the preconditioners);
- * deterministic, about four times as fast as the SpMV on hex8 meshes.  On a mesh of hex8 elements alone the product is
- * one pass over tiles of elements with the nodal sums in LDS; every other mesh -- and "ebe_gather" on any mesh -- writes
+ * deterministic, about four times as fast as the SpMV on hex8 meshes.  On a mesh of hex8 elements alone (or of quad4
+ * elements alone) the product is one pass over tiles of elements with the nodal sums in LDS; every other mesh -- and "ebe_gather" on any mesh -- writes
  * element forces to a buffer and sums them node by node.  Also `-mat_mult_type` of the KSP. */
 int fem_mat_set_mult_type(fem_mat mat, const char *type);
 /* HIP-event profile of the element-by-element product on the product's own stream.  on = 0: off;

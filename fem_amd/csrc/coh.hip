@@ -249,6 +249,8 @@ void mat_add_cohesive_impl(fem_mat J, const double* utot, double dt, int rels_mo
     fem_mesh m = J->mesh;
     if (m->ncoh == 0) return;
     FEM_CHECK(dt > 0.0, 2, "fem_mat_add_cohesive: dt must be positive");
+    FEM_CHECK(!J->mult_ebe, 6, "fem_mat_add_cohesive: the element-by-element MatMult recomputes the solid elements only; "
+                                "a Mat that carries cohesive tangents needs -mat_mult_type assembled");
     J->ctx->bind();
     hipStream_t s = J->ctx->stream;
     const RelsNodes rn = rels_of(m, rels_mode, rels_nodes);

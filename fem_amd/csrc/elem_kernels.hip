@@ -986,6 +986,8 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
     ctx->bind();
     hipStream_t s = ctx->stream;
     const bool ebe = (t == "ebe" || t == "ebe_gather");
+    FEM_CHECK(!(ebe && A->unsymmetric), 6, "fem_mat_set_mult_type: this Mat carries cohesive tangents, which the element-by-element "
+                                            "product (solid elements only) does not know: -mat_mult_type assembled");
     fem_mesh m = A->mesh;
     MatPattern& P = *A->pat;
     if (ebe && !P.ebe_ready) {   // once per mesh: hand-over flags, workgroup classes, gather lists

@@ -47,6 +47,22 @@ def test_callbacks_match_oracle(gpu_ctx, oracle, rels):
     X.destroy(); prob.destroy()
 
 
+def test_element_by_element_product_is_refused_on_a_jacobian_with_cohesive_tangents(gpu_ctx):
+    """The matrix-free product recomputes the solid elements only: asking for it on a Mat that carries (or is about to
+    receive) cohesive tangents must fail loudly, not drop them."""
+    m = read_inp(DECK)
+    prob = driver.NonlinearProblem(gpu_ctx, m, "")
+    X = capi.Vec(gpu_ctx, m.ndof); X.set_array(np.zeros(m.ndof))
+    prob.calc_jacobian(X, prob.J)
+    with pytest.raises(capi.FemError, match="cohesive tangents"):
+        prob.J.set_mult_type("ebe")
+    K2 = prob.K.duplicate()
+    K2.set_mult_type("ebe_gather")                 # fine on the elastic matrix ...
+    with pytest.raises(capi.FemError, match="solid elements only"):
+        K2.add_cohesive(X, m.dt, 0, None)           # ... until tangents are added to it
+    K2.destroy(); X.destroy(); prob.destroy()
+
+
 def test_first_increment_reproduces_the_reference_log(gpu_ctx):
     """examples/SNES_test/cohesive_test/tmp:20-37 through the HIP path (see tests/test_oracle_golden.py for the deck):
     the old revision scaled the penalty force by dt, i.e. the prescribed values of this deck are t = 0.05 times the

@@ -489,6 +489,28 @@ struct TileOut {   // what one worker thread produced for its range of boxes (of
     long long why_a = 0, why_b = 0;
 };
 
+// open-addressing map int -> int for tile-sized sets (a few thousand keys), cleared by undoing its insertions
+struct SmallMap {
+    std::vector<int> key, val, used;
+    unsigned mask;
+    explicit SmallMap(unsigned cap_pow2) : key(cap_pow2, -1), val(cap_pow2, 0), mask(cap_pow2 - 1) {}
+    int* slot(int k, bool& fresh)
+    {
+        unsigned h = ((unsigned)k * 2654435761u) & mask;
+        while (key[h] != -1 && key[h] != k) h = (h + 1) & mask;
+        fresh = key[h] == -1;
+        if (fresh) { key[h] = k; used.push_back((int)h); }
+        return &val[h];
+    }
+    int get(int k) const
+    {
+        unsigned h = ((unsigned)k * 2654435761u) & mask;
+        while (key[h] != k) h = (h + 1) & mask;
+        return val[h];
+    }
+    void clear() { for (int h : used) key[h] = -1; used.clear(); }
+};
+
 int worker_count()
 {
     static const int env = std::getenv("FEM_AMD_SETUP_THREADS") ? std::atoi(std::getenv("FEM_AMD_SETUP_THREADS")) : 0;
@@ -633,9 +655,9 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     static const int c_plus[4] = {1, 2, 5, 6}, c_minus[4] = {0, 3, 4, 7};
     auto work = [&](int th) {
         TileOut& o = outs[th];
-        std::vector<int> estamp((size_t)nel, -1), nstamp((size_t)nn, -1), local((size_t)nn, 0);
         std::vector<unsigned> cmask;
-        std::vector<int> el, nd, col, chain_start;
+        std::vector<int> el, nd, col, chain_start, lconn;   // lconn: tile-local node numbers of el's nodes
+        SmallMap emap(1u << 15), nmap(1u << 15);            // elements / nodes of the tile in hand (far below 32 K each)
         std::vector<std::vector<int>> todo;   // owned-node sets still to be turned into tiles (a box, or the halves of one)
         for (long long b = bsplit[th]; b < bsplit[th + 1]; b++) {
             const int o0 = bstart[b], o1 = bstart[b + 1];
@@ -643,28 +665,41 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             todo.clear();
             todo.emplace_back(border.begin() + o0, border.begin() + o1);
           while (!todo.empty()) {
-            std::vector<int> own = std::move(todo.back());
+            std::vector<int> own = std::move(todo.back());   // ascending node ids
             todo.pop_back();
             const int t = o.ntiles++;
-            el.clear(); nd.clear();
-            for (int v : own) {   // owned nodes first (ascending ids), and the elements that touch them
-                nstamp[v] = t; local[v] = (int)nd.size(); nd.push_back(v);
+            // the elements that touch an owned node, then the tile's nodes: owned ones first, the others of those elements
+            // behind them, each part ascending -- tile-sized tables only, nothing of the size of the mesh
+            emap.clear(); nmap.clear();
+            el.clear();
+            const int nown = (int)own.size();
+            bool huge = nown > 16000;   // (a box of a mesh the grid fits badly: split before the tables fill up)
+            for (int k = 0; k < nown && !huge; k++) {
+                const int v = own[k];
                 for (int q = nptr[v]; q < nptr[v + 1]; q++) {
+                    bool fresh;
                     const int e = (int)((nlst[q] & 0x3fffffffu) >> 3);
-                    if (estamp[e] != t) { estamp[e] = t; el.push_back(e); }
+                    emap.slot(e, fresh);
+                    if (fresh) el.push_back(e);
                 }
+                huge = el.size() > 16000;
             }
-            const int nown = (int)nd.size();
             std::sort(el.begin(), el.end());
-            const size_t rim0 = nd.size();
-            for (int e : el)
+            nd.assign(own.begin(), own.end());
+            for (int k = 0; k < nown && !huge; k++) { bool fresh; *nmap.slot(own[k], fresh) = k; }
+            for (size_t i = 0; i < el.size() && !huge; i++) {
                 for (int a = 0; a < npe; a++) {
-                    const int v = conn[(size_t)e * npe + a];
-                    if (nstamp[v] != t) { nstamp[v] = t; nd.push_back(v); }
+                    bool fresh;
+                    const int v = conn[(size_t)el[i] * npe + a];
+                    int* s = nmap.slot(v, fresh);
+                    if (fresh) { *s = -1; nd.push_back(v); }
                 }
-            std::sort(nd.begin() + rim0, nd.end());
-            for (size_t i = rim0; i < nd.size(); i++) local[nd[i]] = (int)i;
-            if ((int)nd.size() > max_nodes) {
+                huge = nd.size() > 16000;
+            }
+            std::sort(nd.begin() + nown, nd.end());
+            for (size_t i = (size_t)nown; i < nd.size() && !huge; i++) { bool fresh; *nmap.slot(nd[i], fresh) = (int)i; }
+            auto local_of = [&](int v) { return nmap.get(v); };
+            if (huge || (int)nd.size() > max_nodes) {
                 // too many nodes for the LDS image (a box of a distorted mesh may hold more than its share): halve the set
                 // of owned nodes across its longest extent and try again (the later half first: tiles stay in box order)
                 if (nown < 2) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
@@ -680,11 +715,12 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 std::vector<int> lo_half(byc.begin(), byc.begin() + byc.size() / 2), hi_half(byc.begin() + byc.size() / 2, byc.end());
                 std::sort(lo_half.begin(), lo_half.end()); std::sort(hi_half.begin(), hi_half.end());
                 o.ntiles--;
-                for (int v : nd) nstamp[v] = -1;           // the stamps of the abandoned attempt carry the same tile number
-                for (int e : el) estamp[e] = -1;
                 todo.push_back(std::move(hi_half)); todo.push_back(std::move(lo_half));
                 continue;
             }
+            lconn.resize(el.size() * (size_t)npe);
+            for (size_t i = 0; i < el.size(); i++)
+                for (int a = 0; a < npe; a++) lconn[i * npe + a] = local_of(conn[(size_t)el[i] * npe + a]);
             // chains: runs of elements (ascending ids) whose +x face is the next one's -x face, at most 16 long -- a chain
             // sits in consecutive lanes of one 16-lane row and passes its shared-face values along the row (k_ebe_tile)
             chain_start.clear();
@@ -707,13 +743,13 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             for (int ch = 0; ch < nchain; ch++) {
                 unsigned used = 0;
                 for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++)
-                    for (int a = 0; a < npe; a++) used |= cmask[local[conn[(size_t)el[i] * npe + a]]];
+                    for (int a = 0; a < npe; a++) used |= cmask[lconn[(size_t)i * npe + a]];
                 int c = 0;
                 while (c < TILE_MAXC && ((used >> c) & 1u)) c++;
                 if (c >= TILE_MAXC) { o.why = "too many colours"; return; }
                 col[ch] = c; ncol = std::max(ncol, c + 1);
                 for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
-                    for (int a = 0; a < npe; a++) cmask[local[conn[(size_t)el[i] * npe + a]]] |= 1u << c;
+                    for (int a = 0; a < npe; a++) cmask[lconn[(size_t)i * npe + a]] |= 1u << c;
                     all_aff = all_aff && aff[el[i]];
                 }
             }
@@ -731,7 +767,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                     for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
                         o.telems.push_back(el[i]);
                         unsigned l[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                        for (int a = 0; a < npe; a++) l[a] = (unsigned)local[conn[(size_t)el[i] * npe + a]];
+                        for (int a = 0; a < npe; a++) l[a] = (unsigned)lconn[(size_t)i * npe + a];
                         o.tconn.push_back(make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16)));
                         o.tflags.push_back((unsigned char)(2 | (i + 1 < chain_start[ch + 1] ? 1 : 0)));   // bit 1: an element, bit 0: linked to the next lane
                     }

@@ -20,7 +20,7 @@ m1 = read_inp(os.path.join(ROOT, "tests", "golden", "decks", "cohesive_test_2.in
 m = tile_deck(m1, copies)
 ctx = capi.Context(0)
 print(f"config 5: {copies} copies, {m.nels} elements, {m.nnds} nodes, {m.ndof} dofs, {m.nsteps} increments")
-for opts in ("-ksp_type preonly -pc_type lu", "-ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-10"):
+for opts in ("-ksp_type preonly -pc_type lu", "-ksp_type bcgs -pc_type jacobi -ksp_rtol 1e-12 -ksp_atol 1e-16"):
     for rep in range(2):
         t0 = time.perf_counter()
         r = driver.run_nonlinear(m, opts, ctx=ctx, recover_stress=True)

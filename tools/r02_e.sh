@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-2 GPU call D (after the element-by-element rewrite): whole GPU suite, headline bench (+ the distorted mesh, the
+# Round-2 GPU call E (final state of the round): whole GPU suite, headline bench (+ the distorted mesh, the
 # two-kernel product, config 2), rocprofv3 stats of the bench with the multigrid leg, PMC passes of the tile kernel.
 set -eo pipefail
 export TMPDIR=/tmp
-O=gpurun_out/r02d
+O=gpurun_out/r02e
 mkdir -p $O
 echo "== tests"; timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > $O/pytest.txt 2>&1 || { tail -40 $O/pytest.txt; exit 1; }
 tail -2 $O/pytest.txt
@@ -19,4 +19,8 @@ echo "== bench config 2"; timeout -k 10 300 python3 bench.py --config 2 --steps 
 echo "== rocprofv3 stats (bench with the mg leg)"; (cd /tmp && timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu > $GRAFT_REPO_ROOT/$O/bench_profiled.json 2> $GRAFT_REPO_ROOT/$O/bench_profiled.err)
 find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; rm -rf $O/prof_stats
 head -12 $O/kernel_stats.csv | cut -c1-160
-echo "== done"
+echo "== main part done"
+echo "== config 5"; timeout -k 10 300 python3 tools/config5_timing.py 1000 > $O/config5.txt 2>&1; cat $O/config5.txt
+echo "== single-rank RCCL communicator, one stream / exchange beside the interior"; timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mg --force-comm > $O/bench_c3_forcecomm.json 2> $O/bench_c3_forcecomm.err
+FEM_AMD_OVERLAP=1 timeout -k 10 300 python3 bench.py --steps 3 --warmup 1 --no-cpu --no-mg --force-comm > $O/bench_c3_forcecomm_overlap.json 2> $O/bench_c3_forcecomm.err
+echo "== all done"

@@ -18,6 +18,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <sched.h>
+
 #include <array>
 #include <memory>
 #include <thread>
@@ -511,6 +513,17 @@ struct SmallMap {
     void clear() { for (int h : used) key[h] = -1; used.clear(); }
 };
 
+// A worker thread inherits the CPU mask of the thread that starts it, and a host program may have pinned that one to a
+// single core (an OpenMP runtime with OMP_PROC_BIND does; bench.py's process is such a case): give the worker every CPU
+// the process may use -- the cgroup quota still applies.
+void unpin_this_thread()
+{
+    cpu_set_t all;
+    CPU_ZERO(&all);
+    for (int i = 0; i < CPU_SETSIZE; i++) CPU_SET(i, &all);
+    (void)sched_setaffinity(0, sizeof(all), &all);
+}
+
 int worker_count()
 {
     static const int env = std::getenv("FEM_AMD_SETUP_THREADS") ? std::atoi(std::getenv("FEM_AMD_SETUP_THREADS")) : 0;
@@ -522,7 +535,8 @@ void parallel_ranges(long long n, int nthreads, F f)   // f(thread, first, last)
 {
     nthreads = (int)std::max<long long>(1, std::min<long long>(nthreads, n));
     std::vector<std::thread> th;
-    for (int i = 1; i < nthreads; i++) th.emplace_back(f, i, n * i / nthreads, n * (i + 1) / nthreads);
+    for (int i = 1; i < nthreads; i++)
+        th.emplace_back([=] { unpin_this_thread(); f(i, n * i / nthreads, n * (i + 1) / nthreads); });
     f(0, 0LL, n / nthreads);
     for (auto& x : th) x.join();
 }
@@ -794,7 +808,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     };
     {
         std::vector<std::thread> th;
-        for (int i = 1; i < NT; i++) th.emplace_back(work, i);
+        for (int i = 1; i < NT; i++) th.emplace_back([&work, i] { unpin_this_thread(); work(i); });
         work(0);
         for (auto& x : th) x.join();
     }

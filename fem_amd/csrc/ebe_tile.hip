@@ -673,14 +673,44 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         std::vector<int> el, nd, col, chain_start, lconn;   // lconn: tile-local node numbers of el's nodes
         SmallMap emap(1u << 15), nmap(1u << 15);            // elements / nodes of the tile in hand (far below 32 K each)
         std::vector<std::vector<int>> todo;   // owned-node sets still to be turned into tiles (a box, or the halves of one)
+        std::vector<unsigned char> todo_force;   // per set: halve it before anything else
         for (long long b = bsplit[th]; b < bsplit[th + 1]; b++) {
             const int o0 = bstart[b], o1 = bstart[b + 1];
             if (o0 == o1) continue;
-            todo.clear();
+            todo.clear(); todo_force.clear();
             todo.emplace_back(border.begin() + o0, border.begin() + o1);
+            todo_force.push_back(0);
           while (!todo.empty()) {
             std::vector<int> own = std::move(todo.back());   // ascending node ids
             todo.pop_back();
+            const bool force = todo_force.back();
+            todo_force.pop_back();
+            // halves of a set of owned nodes, across its longest extent and along a plane of the node grid where there is one
+            // (the later half is pushed first: tiles stay in box order)
+            auto split_own = [&] {
+                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+                for (int v : own)
+                    for (int d = 0; d < pd; d++) { mn[d] = std::min(mn[d], xyz[(size_t)v * pd + d]); mx[d] = std::max(mx[d], xyz[(size_t)v * pd + d]); }
+                int dl = 0;
+                for (int d = 1; d < pd; d++)
+                    if ((mx[d] - mn[d]) / h[d] > (mx[dl] - mn[dl]) / h[dl]) dl = d;
+                std::vector<int> byc(own);
+                auto before = [&](int a, int c) {
+                    const double xa = xyz[(size_t)a * pd + dl], xc = xyz[(size_t)c * pd + dl];
+                    return xa < xc || (xa == xc && a < c);
+                };
+                std::nth_element(byc.begin(), byc.begin() + byc.size() / 2, byc.end(), before);
+                const double cut = xyz[(size_t)byc[byc.size() / 2] * pd + dl] - 0.25 * h[dl];   // below the median node's grid plane
+                std::vector<int> lo_half, hi_half;
+                for (int v : own) (xyz[(size_t)v * pd + dl] < cut ? lo_half : hi_half).push_back(v);
+                if (lo_half.empty() || hi_half.empty()) {   // no plane to cut along: by rank
+                    lo_half.assign(byc.begin(), byc.begin() + byc.size() / 2); hi_half.assign(byc.begin() + byc.size() / 2, byc.end());
+                    std::sort(lo_half.begin(), lo_half.end()); std::sort(hi_half.begin(), hi_half.end());
+                }
+                todo.push_back(std::move(hi_half)); todo_force.push_back(0);
+                todo.push_back(std::move(lo_half)); todo_force.push_back(0);
+            };
+            if (force && own.size() >= 2) { split_own(); continue; }
             const int t = o.ntiles++;
             // the elements that touch an owned node, then the tile's nodes: owned ones first, the others of those elements
             // behind them, each part ascending -- tile-sized tables only, nothing of the size of the mesh
@@ -715,21 +745,10 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             auto local_of = [&](int v) { return nmap.get(v); };
             if (huge || (int)nd.size() > max_nodes) {
                 // too many nodes for the LDS image (a box of a distorted mesh may hold more than its share): halve the set
-                // of owned nodes across its longest extent and try again (the later half first: tiles stay in box order)
+                // of owned nodes and try again
                 if (nown < 2) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
-                double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-                for (int v : own)
-                    for (int d = 0; d < pd; d++) { mn[d] = std::min(mn[d], xyz[(size_t)v * pd + d]); mx[d] = std::max(mx[d], xyz[(size_t)v * pd + d]); }
-                int dl = 0;
-                for (int d = 1; d < pd; d++)
-                    if ((mx[d] - mn[d]) / h[d] > (mx[dl] - mn[dl]) / h[dl]) dl = d;
-                std::vector<int> byc(own);
-                std::nth_element(byc.begin(), byc.begin() + byc.size() / 2, byc.end(),
-                                 [&](int a, int c) { return xyz[(size_t)a * pd + dl] < xyz[(size_t)c * pd + dl] || (xyz[(size_t)a * pd + dl] == xyz[(size_t)c * pd + dl] && a < c); });
-                std::vector<int> lo_half(byc.begin(), byc.begin() + byc.size() / 2), hi_half(byc.begin() + byc.size() / 2, byc.end());
-                std::sort(lo_half.begin(), lo_half.end()); std::sort(hi_half.begin(), hi_half.end());
                 o.ntiles--;
-                todo.push_back(std::move(hi_half)); todo.push_back(std::move(lo_half));
+                split_own();
                 continue;
             }
             lconn.resize(el.size() * (size_t)npe);

@@ -219,10 +219,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         }
     }
     __syncthreads();
-    auto pos_of = [&](int s) { return (size_t)elem_off + steps[step_off + (s < nsteps ? s : 0)].x + threadIdx.x; };
+    auto pos_of = [&](int s) { return (size_t)elem_off + (s < nsteps ? steps[step_off + s].x : 0) + threadIdx.x; };   // (a tile of nodes without elements has no steps)
     auto raw_of = [&](TileRaw& rw, int s) {
         const bool have = s < nsteps;
-        const int2 st = steps[step_off + (have ? s : 0)];
+        const int2 st = have ? steps[step_off + s] : make_int2(0, 0);
         tile_fetch_raw<AFFINE>(rw, have && (int)threadIdx.x < (st.y & 0x7fffffff), (size_t)elem_off + st.x + threadIdx.x, telems,
                                tconn, tflags, Ev, nuv);
     };

@@ -43,8 +43,16 @@ def _shuffled(m, seed=3):
     return m
 
 
+def _with_isolated_nodes(m, k=70):
+    """k nodes that belong to no element, far away from the mesh: tiles that own nodes but compute nothing"""
+    extra = np.array([[50.0 + i, 60.0 + 0.5 * i, 70.0] for i in range(k)])
+    m.coords = np.ascontiguousarray(np.vstack([m.coords, extra]))
+    return m
+
+
 def _meshes():
     return {
+        "hex_isolated_nodes": _with_isolated_nodes(structured_hex(6, 5, 4, jitter=0.1)),
         "hex_shuffled": _shuffled(structured_hex(13, 11, 9, jitter=0.1)),
         "hex_uniform": structured_hex(7, 6, 5),                      # every element a cube: affine path
         "hex_sheared": _sheared(structured_hex(9, 8, 7)),

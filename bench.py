@@ -41,6 +41,7 @@ FP64_PEAK_TFLOPS = 78.6
 # fp64 work of the element-by-element hex8 kernels AS COMPILED, per element (tile kernels: per element visit):
 # (fp64 vector instructions, flops with fma = 2, all vector instructions) -- tools/count_ebe_flops.py prints them
 EBE_WORK = {
+    "k_ebe_tile<cartesian>": (286, 336, 533),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
     "k_ebe_tile<affine>": (478, 643, 726),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
     "k_ebe_tile<general>": (1503, 2217, 1900),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
     "k_ebe_apply<3,8,8,3>": (567, 789, 689),   # element buffer + gather, parallelepipeds
@@ -301,15 +302,17 @@ def main():
         info = prob.K.get_mult_info()
         affine = args.jitter == 0.0
         if info["kind"] == 2:
-            kname = "k_ebe_tile<affine>" if affine else "k_ebe_tile<general>"
+            # bench meshes: the regular brick (axis-aligned elements) or, with --jitter, distorted elements throughout
+            kname = "k_ebe_tile<cartesian>" if affine else "k_ebe_tile<general>"
             visits, slots, tnodes = info["element_visits"], info["lane_slots"], info["tile_nodes"]
             # tile lists (local connectivity 16 B, element id 4 B, flag 1 B per lane slot; node lists 4 B per entry),
-            # stored geometry 88 B per visit (parallelepipeds) or E, nu 16 B per visit + the nodes' coordinates once,
+            # stored geometry 40 B per visit (axis-aligned bricks; 88 B for other parallelepipeds) or E, nu 16 B per visit + the
+            # nodes' coordinates once,
             # x read once, y written once
             alg = slots * 21.0 + tnodes * 4.0 + nrows * 16.0
-            alg += visits * 88.0 if affine else visits * 16.0 + nrows * 8.0
+            alg += visits * 40.0 if affine else visits * 16.0 + nrows * 8.0
             model = ("tile lists 21 B/lane slot + node lists 4 B/entry + " +
-                     ("stored geometry 88 B/element visit" if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
+                     ("stored geometry 40 B/element visit" if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
                      " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
             traffic = traffic_of("ebe_traffic.json")
         else:

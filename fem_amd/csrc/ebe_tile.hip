@@ -50,6 +50,8 @@ struct EbeTilePlan {
     DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others; in both lists the tiles
                                          // that own a node shared with another domain come first
     int n_aff_if = 0, n_gen_if = 0;      // how many of each list those are
+    DBuf<int> list_cart;                 // tiles of axis-aligned bricks (a third list, same order rule); not in list_aff
+    int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
     double t_setup_ms = 0.0;
@@ -128,12 +130,13 @@ __device__ __forceinline__ void tile_resolve(TileIdx& in, const TileRaw& rw, con
 }
 // loads of one element: -x face nodes always, +x face nodes where the chain ends (the others come from the next lane, see
 // tile_complete)
+template <int NG>
 __device__ __forceinline__ void tile_fetch_data(TileData& dt, const TileIdx& in, size_t k, const double* __restrict__ geo,
                                                 size_t geo_stride, const double* __restrict__ x)
 {
     if (!in.valid) return;
 #pragma unroll
-    for (int j = 0; j < 11; j++) dt.geo[j] = geo[(size_t)j * geo_stride + k];
+    for (int j = 0; j < NG; j++) dt.geo[j] = geo[(size_t)j * geo_stride + k];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -175,6 +178,12 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
     hex_affine_jac(X[0], X[1], X[2], X[3], J);
     const DCoef D = dmat_coef(Ev[e], nuv[e]);
     hex_affine_geom(J, w, D.d12, D.d44, A, lw, mw);
+    if (taff[k] == 2) {   // a tile of axis-aligned bricks: the diagonal of adj(J) and the two factors
+        for (int i = 0; i < 3; i++) geo[(size_t)i * ntel + k] = A[i][i];
+        geo[(size_t)3 * ntel + k] = lw;
+        geo[(size_t)4 * ntel + k] = mw;
+        return;
+    }
     for (int i = 0; i < 3; i++)
         for (int j = 0; j < 3; j++) geo[(size_t)(3 * i + j) * ntel + k] = A[i][j];
     geo[(size_t)9 * ntel + k] = lw;
@@ -184,7 +193,7 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
 // one tile per workgroup.  LDS: acc[3 * nnode] nodal sums, then gl[nnode] global node ids.
 // steps[step_off .. step_off + nsteps): {first element (relative), count | barrier-after << 31}: rounds of 256 elements
 // of one colour, a barrier behind the last round of a colour
-template <bool AFFINE>
+template <int KIND>   // 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal)
 __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
@@ -198,6 +207,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                                                      const int* __restrict__ done)
 {
     if (done && *done) return;
+    constexpr bool AFFINE = KIND != 0;
     extern __shared__ double lds[];
     __shared__ double sh[4];
     // workgroups b and b + 8 share an XCD (and its L2): neighbouring tiles, which read the same nodes, go to one XCD
@@ -232,17 +242,22 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     raw_of(r2, 0); tile_resolve(i0, r2, gl);
     raw_of(r2, 1); tile_resolve(i1, r2, gl);
     raw_of(r2, 2);
-    if constexpr (AFFINE) tile_fetch_data(d0, i0, pos_of(0), geo, geo_stride, x);
+    constexpr int NG = KIND == 2 ? 5 : 11;
+    if constexpr (AFFINE) tile_fetch_data<NG>(d0, i0, pos_of(0), geo, geo_stride, x);
     for (int s = 0; s < nsteps; s++) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
             raw_of(r3, s + 3);
             tile_resolve(i2, r2, gl);
-            tile_fetch_data(d1, i1, pos_of(s + 1), geo, geo_stride, x);
+            tile_fetch_data<NG>(d1, i1, pos_of(s + 1), geo, geo_stride, x);
         }
         // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
         double fe[8][3], dot;
-        if constexpr (AFFINE) {
+        if constexpr (KIND == 2) {
+            tile_complete<3>(d0.u, i0.fl);
+            const double a[3] = {d0.geo[0], d0.geo[1], d0.geo[2]};
+            hex_forces_cart(a, d0.geo[3], d0.geo[4], d0.u, g, fe, dot);
+        } else if constexpr (KIND == 1) {
             tile_complete<3>(d0.u, i0.fl);
             double A[3][3];
 #pragma unroll
@@ -480,7 +495,7 @@ static bool host_hex_affine(const double (&X)[8][3])
 namespace {
 
 struct TileOut {   // what one worker thread produced for its range of boxes (offsets local to the worker)
-    std::vector<int> hdr, tnodes, telems, laff, lgen;
+    std::vector<int> hdr, tnodes, telems, laff, lgen, lcart;
     std::vector<int2> steps;
     std::vector<uint4> tconn;
     std::vector<unsigned char> tflags, taff;   // taff: the slot belongs to a tile of parallelepipeds
@@ -601,7 +616,13 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                     p[6 + d] += std::max(ex, ey);
                 }
             }
-            aff[(size_t)e] = (hex && host_hex_affine(X)) ? 1 : 0;
+            unsigned char cls = (hex && host_hex_affine(X)) ? 1 : 0;
+            if (cls) {   // an axis-aligned brick: the three edges at node 0 run along x, y, z exactly
+                const bool cart = X[1][1] == X[0][1] && X[1][2] == X[0][2] && X[3][0] == X[0][0] && X[3][2] == X[0][2] &&
+                                  X[4][0] == X[0][0] && X[4][1] == X[0][1];
+                if (cart) cls = 2;
+            }
+            aff[(size_t)e] = cls;
         }
     });
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
@@ -772,7 +793,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             cmask.assign(nd.size(), 0u);
             col.resize((size_t)nchain);
             int ncol = 0;
-            bool all_aff = true;
+            bool all_aff = true, all_cart = true;
             for (int ch = 0; ch < nchain; ch++) {
                 unsigned used = 0;
                 for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++)
@@ -783,7 +804,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 col[ch] = c; ncol = std::max(ncol, c + 1);
                 for (int i = chain_start[ch]; i < chain_start[ch + 1]; i++) {
                     for (int a = 0; a < npe; a++) cmask[lconn[(size_t)i * npe + a]] |= 1u << c;
-                    all_aff = all_aff && aff[el[i]];
+                    all_aff = all_aff && aff[el[i]]; all_cart = all_cart && aff[el[i]] == 2;
                 }
             }
             const int elem_off = (int)o.telems.size(), step_off = (int)o.steps.size(), tnodes_off = (int)o.tnodes.size();
@@ -816,8 +837,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             o.hdr.push_back(tnodes_off); o.hdr.push_back(nown); o.hdr.push_back((int)nd.size()); o.hdr.push_back(elem_off);
             o.hdr.push_back(step_off); o.hdr.push_back((int)o.steps.size() - step_off);
             o.max_nnode = std::max(o.max_nnode, (int)nd.size());
-            (all_aff ? o.laff : o.lgen).push_back(t);
-            o.taff.resize(o.telems.size(), all_aff ? 1 : 0);
+            (all_cart ? o.lcart : all_aff ? o.laff : o.lgen).push_back(t);
+            o.taff.resize(o.telems.size(), all_cart ? 2 : all_aff ? 1 : 0);
             bool iface = false;
             if (!shared_node.empty())
                 for (int k = 0; k < nown && !iface; k++) iface = shared_node[(size_t)nd[k]] != 0;
@@ -847,7 +868,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     }
     const int ntiles = (int)toff[NT];
     if (eoff[NT] > 0x7fffffffULL || noff[NT] > 0x7fffffffULL) return refuse("too many lane slots");
-    std::vector<int> hdr, laff, lgen;
+    std::vector<int> hdr, laff, lgen, lcart;
     std::vector<unsigned char> tif;
     hdr.reserve((size_t)ntiles * 6);
     for (int i = 0; i < NT; i++) {
@@ -857,22 +878,24 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             hdr.push_back(o.hdr[k + 3] + (int)eoff[i]); hdr.push_back(o.hdr[k + 4] + (int)soff[i]); hdr.push_back(o.hdr[k + 5]);
         }
         for (int t : o.laff) laff.push_back(t + (int)toff[i]);
+        for (int t : o.lcart) lcart.push_back(t + (int)toff[i]);
         for (int t : o.lgen) lgen.push_back(t + (int)toff[i]);
         tif.insert(tif.end(), o.tif.begin(), o.tif.end());
     }
     auto iface_first = [&](std::vector<int>& l) {
         return (int)(std::stable_partition(l.begin(), l.end(), [&](int t) { return tif[(size_t)t] != 0; }) - l.begin());
     };
-    plan->n_aff_if = iface_first(laff); plan->n_gen_if = iface_first(lgen);
+    plan->n_aff_if = iface_first(laff); plan->n_gen_if = iface_first(lgen); plan->n_cart_if = iface_first(lcart);
     plan->halo_seen = m->halo.get();
-    plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->max_nnode = max_nnode;
+    plan->ntiles = ntiles; plan->n_aff = (int)laff.size(); plan->n_gen = (int)lgen.size(); plan->n_cart = (int)lcart.size();
+    plan->max_nnode = max_nnode;
     plan->tile_elements = visits; plan->slots = (long long)eoff[NT]; plan->tile_nodes = (long long)noff[NT];
     auto up = [&](auto& dbuf, const auto& vec) {
         dbuf.alloc(std::max<size_t>(vec.size(), 1));
         if (!vec.empty())
             FEM_HIP(hipMemcpyAsync(dbuf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
     };
-    up(plan->hdr, hdr); up(plan->list_aff, laff); up(plan->list_gen, lgen);
+    up(plan->hdr, hdr); up(plan->list_aff, laff); up(plan->list_gen, lgen); up(plan->list_cart, lcart);
     plan->steps.alloc(std::max<size_t>(soff[NT], 1)); plan->nodes.alloc(std::max<size_t>(noff[NT], 1));
     plan->elems.alloc(std::max<size_t>(eoff[NT], 1)); plan->conn16.alloc(std::max<size_t>(eoff[NT], 1));
     plan->flags.alloc(std::max<size_t>(eoff[NT], 1));
@@ -887,7 +910,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         piece(plan->conn16.p, o.tconn, eoff[i]); piece(plan->flags.p, o.tflags, eoff[i]); piece(d_taff.p, o.taff, eoff[i]);
     }
     FEM_HIP(hipStreamSynchronize(s));
-    if (!laff.empty()) {   // geometry records of the affine tiles' elements
+    if (!laff.empty() || !lcart.empty()) {   // geometry records of the affine / Cartesian tiles' elements
         plan->geo.alloc(eoff[NT] * 11);
         const ElemTable& tab = host_elem_tables()[FEM_HEX];   // (only hex8 tiles are ever in this list)
         hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((eoff[NT] + 255) / 256)), dim3(256), 0, s, eoff[NT], plan->elems.p,
@@ -896,8 +919,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     }
     plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (verbose)
-        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine), <= %d nodes, %lld element visits in %lld lane slots for %d elements, %zu steps, set-up %.0f ms (%d threads)\n",
-                     ntiles, plan->n_aff, max_nnode, plan->tile_elements, plan->slots, nel, soff[NT], plan->t_setup_ms, NT);
+        std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine, %d Cartesian), <= %d nodes, %lld element visits in %lld lane slots for %d elements, %zu steps, set-up %.0f ms (%d threads)\n",
+                     ntiles, plan->n_aff, plan->n_cart, max_nnode, plan->tile_elements, plan->slots, nel, soff[NT], plan->t_setup_ms, NT);
     return plan;
 }
 
@@ -905,7 +928,7 @@ int ebe_tile_partials(const EbeTilePlan& P) { return P.ntiles; }
 void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_tiles, long long* visits, long long* slots,
                    long long* nodes, double* ms)
 {
-    *tiles = P.ntiles; *affine_tiles = P.n_aff; *visits = P.tile_elements; *slots = P.slots; *nodes = P.tile_nodes; *ms = P.t_setup_ms;
+    *tiles = P.ntiles; *affine_tiles = P.n_aff + P.n_cart; *visits = P.tile_elements; *slots = P.slots; *nodes = P.tile_nodes; *ms = P.t_setup_ms;
 }
 
 // y = K x, p.Kp partials into part[0 .. ntiles)
@@ -936,7 +959,8 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
     static bool attr_set = false;
     if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<true>), reinterpret_cast<const void*>(k_ebe_tile<false>)})
+        for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<0>), reinterpret_cast<const void*>(k_ebe_tile<1>),
+                              reinterpret_cast<const void*>(k_ebe_tile<2>)})
             FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
         attr_set = true;
     }
@@ -946,9 +970,11 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
                            (size_t)P.slots, g, w, P.max_nnode, y, part, done);
     };
+    const int c0 = phase == 1 ? P.n_cart_if : 0, c1 = phase == 0 ? P.n_cart_if : P.n_cart;
     const int a0 = phase == 1 ? P.n_aff_if : 0, a1 = phase == 0 ? P.n_aff_if : P.n_aff;
     const int g0 = phase == 1 ? P.n_gen_if : 0, g1 = phase == 0 ? P.n_gen_if : P.n_gen;
-    go(k_ebe_tile<true>, a1 - a0, P.list_aff.p + a0);
-    go(k_ebe_tile<false>, g1 - g0, P.list_gen.p + g0);
+    go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
+    go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
+    go(k_ebe_tile<0>, g1 - g0, P.list_gen.p + g0);
 }
 bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P) { return P.halo_seen == (const void*)A->mesh->halo.get(); }

@@ -291,6 +291,99 @@ __device__ __forceinline__ void hex_forces_affine(const double (&X)[8][3], const
     hex_finish(cU, F, g8, gg8, fe, dot);
 }
 
+// Axis-aligned bricks (the "Cartesian cell" class): adj(J) is diagonal, a[i] = det * d xi_i / d x_i, and the seven sparse
+// applications of L lose their zero terms by hand -- 177 instead of 321 fp64 instructions, 40 instead of 88 B of stored
+// geometry per element.  RM: rows of G that are not zero, CM: columns of T that are wanted.
+template <int RM, int CM>
+__device__ __forceinline__ void cart_T(const double (&a)[3], const double (&G)[3][3], double lw, double mw, double m2,
+                                       double (&T)[3][3])
+{
+    constexpr bool r0 = RM & 1, r1 = (RM >> 1) & 1, r2 = (RM >> 2) & 1;
+    double H[3][3];   // H[l][i] = a[i] G[i][l] for the rows i of RM (the other entries are zero and never touched)
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        if (r0) H[l][0] = a[0] * G[0][l];
+        if (r1) H[l][1] = a[1] * G[1][l];
+        if (r2) H[l][2] = a[2] * G[2][l];
+    }
+    double tr = 0.0;
+    if (r0 && r1 && r2) tr = (H[0][0] + H[1][1]) + H[2][2];
+    else if (r0 && r1) tr = H[0][0] + H[1][1];
+    else if (r0 && r2) tr = H[0][0] + H[2][2];
+    else if (r1 && r2) tr = H[1][1] + H[2][2];
+    else if (r0) tr = H[0][0];
+    else if (r1) tr = H[1][1];
+    else tr = H[2][2];
+    const double lt = lw * tr;
+    const bool has[3] = {r0, r1, r2};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        if (!((CM >> j) & 1)) continue;
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            double s;
+            if (l == j) s = has[j] ? fma(m2, H[j][j], lt) : lt;
+            else if (has[j] && has[l]) s = mw * (H[l][j] + H[j][l]);
+            else if (has[j]) s = mw * H[l][j];
+            else if (has[l]) s = mw * H[j][l];
+            else s = 0.0;
+            T[l][j] = s * a[j];
+        }
+    }
+}
+__device__ __forceinline__ void hex_cart_apply(const double (&a)[3], double lw, double mw, const Mono (&cU)[3], Mono (&F)[3])
+{
+    const double m2 = mw + mw;
+    double G[3][3], T[3][3];
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].x; G[1][l] = cU[l].y; G[2][l] = cU[l].z; }
+    cart_T<7, 7>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].x = T[l][0]; F[l].y = T[l][1]; F[l].z = T[l][2]; }
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[1][l] = cU[l].xy; G[2][l] = cU[l].xz; }
+    cart_T<6, 6>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xy = T[l][1]; F[l].xz = T[l][2]; }
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].xy; G[2][l] = cU[l].yz; }
+    cart_T<5, 5>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xy += T[l][0]; F[l].yz = T[l][2]; }
+#pragma unroll
+    for (int l = 0; l < 3; l++) { G[0][l] = cU[l].xz; G[1][l] = cU[l].yz; }
+    cart_T<3, 3>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) { F[l].xz += T[l][0]; F[l].yz += T[l][1]; }
+#pragma unroll
+    for (int l = 0; l < 3; l++) G[0][l] = G[1][l] = G[2][l] = cU[l].xyz;
+    cart_T<1, 1>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz = T[l][0];
+    cart_T<2, 2>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz += T[l][1];
+    cart_T<4, 4>(a, G, lw, mw, m2, T);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz += T[l][2];
+}
+// nodal forces of an axis-aligned brick from its stored geometry (a[3], lw, mw) and the nodal values u
+__device__ __forceinline__ void hex_forces_cart(const double (&a)[3], double lw, double mw, const double (&u)[8][3], double g,
+                                                double (&fe)[8][3], double& dot)
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cU[3], F[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a_ = 0; a_ < 8; a_++) v[a_] = u[a_][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+    }
+    hex_cart_apply(a, lw, mw, cU, F);
+    hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
 // nodal forces of a parallelepiped from its stored geometry (hex_affine_geom) and the nodal values u
 __device__ __forceinline__ void hex_forces_geom(const double (&A)[3][3], double lw, double mw, const double (&u)[8][3], double g,
                                                 double (&fe)[8][3], double& dot)

@@ -81,7 +81,7 @@ while i < len(lines):
 lines = asm_of("fem_amd/csrc/ebe_tile.hip")
 i = 0
 while i < len(lines):
-    m = re.match(r"^(_ZN3fem10k_ebe_tileILb([01])E\w+):", lines[i])
+    m = re.match(r"^(_ZN3fem10k_ebe_tileILi([012])E\w+):", lines[i])
     if not m:
         i += 1
         continue
@@ -113,5 +113,5 @@ while i < len(lines):
             else:
                 cur = 0
         weight[k] = cur
-    report("k_ebe_tile<%s> per element visit" % ("affine" if m.group(2) == "1" else "general"), count(body, weight))
+    report("k_ebe_tile<%s> per element visit" % {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)], count(body, weight))
     i = j

@@ -244,27 +244,27 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     raw_of(r2, 2);
     constexpr int NG = KIND == 2 ? 5 : 11;
     if constexpr (AFFINE) tile_fetch_data<NG>(d0, i0, pos_of(0), geo, geo_stride, x);
-    for (int s = 0; s < nsteps; s++) {
+    auto do_step = [&](int s, TileData& dcur, TileData& dnext) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
             raw_of(r3, s + 3);
             tile_resolve(i2, r2, gl);
-            tile_fetch_data<NG>(d1, i1, pos_of(s + 1), geo, geo_stride, x);
+            tile_fetch_data<NG>(dnext, i1, pos_of(s + 1), geo, geo_stride, x);
         }
         // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
         double fe[8][3], dot;
         if constexpr (KIND == 2) {
-            tile_complete<3>(d0.u, i0.fl);
-            const double a[3] = {d0.geo[0], d0.geo[1], d0.geo[2]};
-            hex_forces_cart(a, d0.geo[3], d0.geo[4], d0.u, g, fe, dot);
+            tile_complete<3>(dcur.u, i0.fl);
+            const double a[3] = {dcur.geo[0], dcur.geo[1], dcur.geo[2]};
+            hex_forces_cart(a, dcur.geo[3], dcur.geo[4], dcur.u, g, fe, dot);
         } else if constexpr (KIND == 1) {
-            tile_complete<3>(d0.u, i0.fl);
+            tile_complete<3>(dcur.u, i0.fl);
             double A[3][3];
 #pragma unroll
             for (int i = 0; i < 3; i++)
 #pragma unroll
-                for (int j = 0; j < 3; j++) A[i][j] = d0.geo[3 * i + j];
-            hex_forces_geom(A, d0.geo[9], d0.geo[10], d0.u, g, fe, dot);
+                for (int j = 0; j < 3; j++) A[i][j] = dcur.geo[3 * i + j];
+            hex_forces_geom(A, dcur.geo[9], dcur.geo[10], dcur.u, g, fe, dot);
         } else {
             double X[8][3], u[8][3];
 #pragma unroll
@@ -306,8 +306,12 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             }
         }
         if (bar) __syncthreads();
-        if constexpr (AFFINE) { i0 = i1; i1 = i2; r2 = r3; d0 = d1; }
-        else { i0 = i1; tile_resolve(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernel)
+        if constexpr (AFFINE) { i0 = i1; i1 = i2; r2 = r3; }
+        else { i0 = i1; tile_resolve(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernels)
+    };
+    for (int s = 0; s < nsteps; s++) {   // (letting the two data buffers change roles instead of copying one costs registers: spills)
+        do_step(s, d0, d1);
+        if constexpr (AFFINE) d0 = d1;
     }
     double dot = 0.0;
     for (int i0n = 0; i0n < nown; i0n += 1024) {   // four owned nodes per lane and round: their loads in flight together

@@ -101,3 +101,34 @@ def parse_inp(text: str) -> Mesh:
 def read_inp(path: str) -> Mesh:
     with open(path) as f:
         return parse_inp(f.read())
+
+
+def write_inp(path: str, m: Mesh) -> None:
+    """The deck of a Mesh in the format parse_inp reads (current 8-integer header; 17 significant digits, so that a
+    deck written here and read back -- by this reader or by a Fortran list-directed READ -- carries the same numbers)."""
+    names = {v: k for k, v in TYPE_NAMES.items()}
+
+    def fl(x):
+        return repr(float(x))
+
+    out = [f"{m.stype} {m.pdim} {m.nodal_bw}",
+           f"{m.nels} {m.nnds} {m.mats.shape[0]} {len(m.cohmats)} 0 {len(m.fnode)} {len(m.telsd)} {len(m.bcnode)}",
+           f"{fl(m.t)} {fl(m.dt)}"]
+    nlmat = m.nlmat if m.nlmat is not None else np.zeros(m.nels, dtype=np.int32)
+    for e in range(m.nels):
+        nodes = " ".join(str(int(v) + 1) for v in m.conn[m.eptr[e]:m.eptr[e + 1]])
+        out.append(f"{names[int(m.eltype[e])]} {nodes} {int(m.mat_id[e]) + 1} {int(nlmat[e])}")
+    for v in range(m.nnds):
+        out.append(" ".join(fl(c) for c in m.coords[v]))
+    for row in m.mats:
+        out.append(" ".join(fl(c) for c in row))
+    for law, props in m.cohmats:
+        out.append(f"{law} " + " ".join(fl(c) for c in props))
+    for i in range(len(m.bcnode)):
+        out.append(f"{int(m.bcnode[i, 0]) + 1} " + " ".join(str(int(f)) for f in m.bcnode[i, 1:]) + " " + " ".join(fl(c) for c in m.bcval[i]))
+    for i in range(len(m.fnode)):
+        out.append(f"{int(m.fnode[i]) + 1} " + " ".join(fl(c) for c in m.fval[i]))
+    for i in range(len(m.telsd)):
+        out.append(f"{int(m.telsd[i, 0]) + 1} {int(m.telsd[i, 1])} " + " ".join(fl(c) for c in m.tval[i]))
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")

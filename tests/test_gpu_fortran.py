@@ -127,6 +127,38 @@ def test_fortran_driver_with_the_element_by_element_product(tmp_path, oracle):
     assert np.abs(full[:, 2:] - so).max() <= 1e-9 * np.abs(so).max()
 
 
+@pytest.mark.parametrize("np_", [1, 2])
+def test_fortran_driver_on_a_hex8_deck_with_the_one_pass_product(tmp_path, oracle, np_):
+    """A 3-D deck of distorted hex8 elements written in the reference's format, through the Fortran driver with
+    `-mat_mult_type ebe` -- on such a mesh the one-pass tile product -- on one domain and on two (in-process communicator):
+    displacements and nodal stresses of the oracle."""
+    _need(EXE)
+    from fem_amd.inp import write_inp
+    from fem_amd.mesh import structured_hex
+    m = structured_hex(7, 6, 5, jitter=0.12)
+    deck = str(tmp_path / "hex.inp")
+    write_inp(deck, m)
+    cmd = [EXE, "-f", deck, "-ksp_rtol", "1e-13", "-mat_mult_type", "ebe", "-o", str(tmp_path / "0_output")]
+    if np_ > 1:
+        cmd += ["-np", str(np_)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    uo, so, _ = oracle.run(m, "lu")
+    if np_ == 1:
+        full = np.loadtxt(tmp_path / "0_output_000000.full.txt", skiprows=1)
+        assert np.abs(full[:, :3].ravel() - uo).max() <= 1e-10 * np.abs(uo).max()
+        assert np.abs(full[:, 3:] - so).max() <= 1e-9 * np.abs(so).max()
+    else:
+        seen = np.zeros(m.nnds, dtype=bool)
+        for r in range(np_):
+            full = np.loadtxt(tmp_path / f"{r}_output_000000.full.txt", skiprows=1, ndmin=2)
+            gid = full[:, 0].astype(int)
+            seen[gid] = True
+            assert np.abs(full[:, 1:4] - uo.reshape(-1, 3)[gid]).max() <= 1e-10 * np.abs(uo).max()
+            assert np.abs(full[:, 4:] - so[gid]).max() <= 1e-9 * np.abs(so).max()
+        assert seen.all()
+
+
 def test_plain_c_client_of_the_abi(tmp_path):
     """include/fem_amd.h consumed by gcc as C99 (no C++ types leak through the boundary)."""
     exe = tmp_path / "abi_smoke"

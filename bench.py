@@ -383,6 +383,15 @@ def main():
             "roofline": roof,
         }
         out.update(side)
+        if args.mult == "ebe" and hex_case and args.pc == "jacobi":
+            # the CG iteration as a whole against the HBM roof: bytes of the product kernel (PMC where taken, else its
+            # algorithmic bytes) + the two vector kernels (x += a p, r -= a w, z, dots: 7 passes; p = z + b p: 4 passes)
+            prod = roof.get("traffic") or roof.get("algorithmic_bytes") or 0.0
+            it_bytes = prod + 11.0 * nrows * 8.0
+            it_s = t_sol / args.steps / max(its, 1)
+            out["cg_iteration_roofline"] = {"bound": "hbm", "bytes": it_bytes, "product_bytes": prod,
+                                            "vector_bytes": 11.0 * nrows * 8.0, "achieved": it_bytes / it_s / 1e9,
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_bytes / it_s / 1e9 / HBM_PEAK_GBS}
         if world > 1 and args.n == 149 and args.jitter == 0.0 and hex_case:
             # weak scaling of a non-optimal-order solver: the global problem needs more iterations (measured on
             # one GPU holding the whole problem, DESIGN.md section 5: 724 / 1102 / 1048 / 1412 at N = 1 / 2 / 4 / 8)

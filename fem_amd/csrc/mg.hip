@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
                 }
                 my[(jw - j0) >> 2][lane] = word;
             }
-            for (int s = 0; s < 27; s++) {
+            for (int s = 13; s < 27; s++) {   // the centre and the 13 "upper" neighbours; k_galerkin_mirror fills the other half
                 int T = -1;
                 const bool inside = neighbour_box(g, A, s, T);   // wave-uniform
                 double acc[CC];
@@ -329,6 +329,22 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
             first = false;
         }
     }
+}
+
+// K is symmetric, so A_1(T, A) = A_1(A, T)^T: stencil slot s < 13 of box A is the transpose of slot 26 - s of the neighbour
+// that slot points at (zero where there is none) -- the fine-level product computes 14 of the 27 slots
+template <int CS>
+__global__ void __launch_bounds__(256) k_galerkin_mirror(Grid3 g, double* __restrict__ st)
+{
+    constexpr int CC = CS * CS;
+    const int nb = g.nb();
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)13 * CC * nb) return;
+    const int A = (int)(t % nb), e = (int)((t / nb) % CC), s = (int)(t / ((size_t)nb * CC));
+    int T = -1;
+    double v = 0.0;
+    if (neighbour_box(g, A, s, T)) v = st[((size_t)(26 - s) * CC + (e % CS) * CS + e / CS) * nb + T];
+    st[((size_t)s * CC + e) * nb + A] = v;
 }
 
 // A_{l+1} = T^T A_l T between two box levels (children = 2x2x2 boxes), T = [I, R(d); 0, I]
@@ -909,6 +925,7 @@ static bool setup_t(Multigrid& mg)
     hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, geom_of(mg.lev[0]),
                        mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->values(),
                        mg.w.p, mg.lev[0].st.p, err.p);
+    hipLaunchKernelGGL((k_galerkin_mirror<CS>), dim3(g1((size_t)13 * CS * CS * nb)), dim3(256), 0, s, g, mg.lev[0].st.p);
     if (comm) {
         // A_1 = sum over the domains of P_r^T K_r P_r (sub-assembled matrices, same P on shared nodes);
         // the flag travels along so that every domain raises the same error

@@ -193,7 +193,9 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
 // one tile per workgroup.  LDS: acc[3 * nnode] nodal sums, then gl[nnode] global node ids.
 // steps[step_off .. step_off + nsteps): {first element (relative), count | barrier-after << 31}: rounds of 256 elements
 // of one colour, a barrier behind the last round of a colour
-template <int KIND>   // 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal)
+// OP 0: y = K x.  OP 1, 2: the nodal stress sums of RecoverNodalStress + src/main.F90:258-279 over the same tiles (x = the
+// displacements; y = component 0 / 3 of stress_node(nnds, 6), column-major; divided by the valence where one is given)
+template <int KIND, int OP = 0>   // 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal)
 __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
@@ -204,9 +206,11 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                                                      const double* __restrict__ bc_shift, const double* __restrict__ geo,
                                                      size_t geo_stride, double g, double w, int max_nnode,
                                                      double* __restrict__ y, double* __restrict__ partial,
-                                                     const int* __restrict__ done)
+                                                     const int* __restrict__ done, const double* __restrict__ valence,
+                                                     size_t nn)
 {
     if (done && *done) return;
+    static_assert(OP == 0 || KIND == 0, "the stress passes read the coordinates");
     constexpr bool AFFINE = KIND != 0;
     extern __shared__ double lds[];
     __shared__ double sh[4];
@@ -281,8 +285,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             }
             tile_complete<3>(X, i0.fl);
             tile_complete<3>(u, i0.fl);
-            const DCoef D = dmat_coef(i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25);
-            hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
+            if constexpr (OP == 0) {
+                const DCoef D = dmat_coef(i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25);
+                hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
+            } else hex_nodal_stress<OP - 1>(X, u, g, i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25, fe);
         }
         // +x face forces of a linked lane go to the next lane's -x face nodes
         {
@@ -322,14 +328,20 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         for (int j = 0; j < 4; j++) {
             const int i = i0n + (int)threadIdx.x + 256 * j;
             vv[j] = (i < nown) ? (size_t)gl[i] : 0;
-            kb[j] = (i < nown && bc_node) ? bc_node[vv[j]] : -1;
+            kb[j] = (OP == 0 && i < nown && bc_node) ? bc_node[vv[j]] : -1;
 #pragma unroll
-            for (int d = 0; d < 3; d++) xv[j][d] = (i < nown) ? x[vv[j] * 3 + d] : 0.0;
+            for (int d = 0; d < 3; d++) xv[j][d] = (OP == 0 && i < nown) ? x[vv[j] * 3 + d] : 0.0;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int i = i0n + (int)threadIdx.x + 256 * j;
             if (i >= nown) continue;
+            if constexpr (OP != 0) {   // stress_node(i,:) / global_count_node (src/main.F90:277-279; no solid element: 0)
+                const double rv = valence ? valence[vv[j]] : 1.0;
+#pragma unroll
+                for (int d = 0; d < 3; d++) y[(size_t)d * nn + vv[j]] = (valence && rv != 0.0) ? acc[3 * i + d] / rv : acc[3 * i + d];
+                continue;
+            }
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 double sv = acc[3 * i + d];
@@ -339,6 +351,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             }
         }
     }
+    if constexpr (OP != 0) return;
     for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
     __syncthreads();
@@ -935,6 +948,17 @@ void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_til
     *tiles = P.ntiles; *affine_tiles = P.n_aff + P.n_cart; *visits = P.tile_elements; *slots = P.slots; *nodes = P.tile_nodes; *ms = P.t_setup_ms;
 }
 
+static void hex_tile_kernel_attributes()
+{
+    static bool attr_set = false;
+    if (attr_set) return;
+    for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<0>), reinterpret_cast<const void*>(k_ebe_tile<1>),
+                          reinterpret_cast<const void*>(k_ebe_tile<2>), reinterpret_cast<const void*>(k_ebe_tile<0, 1>),
+                          reinterpret_cast<const void*>(k_ebe_tile<0, 2>)})
+        FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
+    attr_set = true;
+}
+
 // y = K x, p.Kp partials into part[0 .. ntiles)
 // phase -1: every tile; 0: the tiles that own nodes shared with other domains; 1: the others
 void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase)
@@ -961,18 +985,12 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         return;
     }
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
-    static bool attr_set = false;
-    if (!attr_set) {
-        for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<0>), reinterpret_cast<const void*>(k_ebe_tile<1>),
-                              reinterpret_cast<const void*>(k_ebe_tile<2>)})
-            FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
-        attr_set = true;
-    }
+    hex_tile_kernel_attributes();
     auto go = [&](auto kern, int n, const int* list) {
         if (!n) return;
         hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.elems.p,
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
-                           (size_t)P.slots, g, w, P.max_nnode, y, part, done);
+                           (size_t)P.slots, g, w, P.max_nnode, y, part, done, (const double*)nullptr, (size_t)0);
     };
     const int c0 = phase == 1 ? P.n_cart_if : 0, c1 = phase == 0 ? P.n_cart_if : P.n_cart;
     const int a0 = phase == 1 ? P.n_aff_if : 0, a1 = phase == 0 ? P.n_aff_if : P.n_aff;
@@ -980,5 +998,33 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
     go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
     go(k_ebe_tile<0>, g1 - g0, P.list_gen.p + g0);
+}
+// stress_node(nnds, 6) of a hex8 mesh over the tiles of the product (RecoverNodalStress per element, the sum over the
+// elements of a node src/main.F90:258-268 in LDS, the division by the valence :277-279 on the way out): two passes of
+// three components, every tile through the kernel of the distorted elements (it reads the coordinates)
+bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* S, const double* valence)
+{
+    auto& grp = m->groups[0];
+    if (m->groups.size() != 1 || grp.type != FEM_HEX) return false;
+    hipStream_t s = m->ctx->stream;
+    const ElemTable& tab = host_elem_tables()[grp.type];
+    const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
+    const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int)), nn = (size_t)m->nnds;
+    hex_tile_kernel_attributes();
+    auto go = [&](auto kern, int n, const int* list, double* out) {
+        if (!n) return;
+        hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.elems.p,
+                           P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, U, (const int*)nullptr, (const int*)nullptr,
+                           (const double*)nullptr, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, out, (double*)nullptr,
+                           (const int*)nullptr, valence, nn);
+    };
+    for (int half = 0; half < 2; half++) {
+        double* out = S + (size_t)(3 * half) * nn;
+        for (auto [n, list] : {std::pair<int, const int*>{P.n_cart, P.list_cart.p}, {P.n_aff, P.list_aff.p}, {P.n_gen, P.list_gen.p}}) {
+            if (half == 0) go(k_ebe_tile<0, 1>, n, list, out);
+            else go(k_ebe_tile<0, 2>, n, list, out);
+        }
+    }
+    return true;
 }
 bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P) { return P.halo_seen == (const void*)A->mesh->halo.get(); }

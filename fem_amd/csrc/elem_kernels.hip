@@ -975,6 +975,7 @@ static int ebe_blocks(const fem_mesh m)
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);   // ebe_tile.hip
 int ebe_tile_partials(const EbeTilePlan& P);
 void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase);
+bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* S, const double* valence);
 bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P);
 
 void mat_set_mult_type_impl(fem_mat A, const char* type)
@@ -1384,6 +1385,20 @@ void recover_nodal_stress_dev(fem_mesh m, const double* U, double* S)
     hipStream_t s = ctx->stream;
     const size_t nn = (size_t)m->nnds;
     const auto P = mesh_pattern(m);
+    const bool multi = m->halo && m->halo->comm->size > 1;
+    auto finish_multi = [&] {   // partitioned meshes sum the partial nodal sums across domains first (replaces Mat_Stress ADD +
+                                // assembly, src/main.F90:286-289), then divide
+        halo_sum(m, S, m->cpdim, 1, nn);
+        hipLaunchKernelGGL(k_divide_by_valence, dim3(std::min<unsigned>(cdiv(nn * m->cpdim, 256), 8192)), dim3(256), 0, s, nn,
+                           m->cpdim, S, m->valence_d.p);
+    };
+    // hex8 mesh with the tile plan of the one-pass product: the same tiles sum the nodal stresses in LDS (no element buffer)
+    static const bool tile_env = !(std::getenv("FEM_AMD_STRESS_TILE") && std::atoi(std::getenv("FEM_AMD_STRESS_TILE")) == 0);
+    if (tile_env && P->ebe_tile && ebe_tile_stress(m, *P->ebe_tile, U, S, multi ? nullptr : m->valence_d.p)) {
+        if (multi) finish_multi();
+        FEM_HIP(hipGetLastError());
+        return;
+    }
     std::vector<DBuf<double>> buf(m->groups.size());
     StressViews sv{};
     for (size_t gi = 0; gi < m->groups.size(); gi++) {
@@ -1400,17 +1415,12 @@ void recover_nodal_stress_dev(fem_mesh m, const double* U, double* S)
     }
     // single domain: the division by the valence rides on the gather; partitioned meshes sum the partial nodal
     // sums across domains first (replaces Mat_Stress ADD + assembly, src/main.F90:286-289)
-    const bool multi = m->halo && m->halo->comm->size > 1;
     const double* val = multi ? nullptr : m->valence_d.p;
     if (m->cpdim == 6)
         hipLaunchKernelGGL(k_stress_gather<6>, dim3(cdiv(nn, 256)), dim3(256), 0, s, m->nnds, P->n2e_ptr.p, P->n2e.p, sv, val, S);
     else
         hipLaunchKernelGGL(k_stress_gather<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, m->nnds, P->n2e_ptr.p, P->n2e.p, sv, val, S);
-    if (multi) {
-        halo_sum(m, S, m->cpdim, 1, nn);
-        hipLaunchKernelGGL(k_divide_by_valence, dim3(std::min<unsigned>(cdiv(nn * m->cpdim, 256), 8192)), dim3(256), 0, s, nn,
-                           m->cpdim, S, m->valence_d.p);
-    }
+    if (multi) finish_multi();
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));   // the element buffers go back to the pool at scope end
 }

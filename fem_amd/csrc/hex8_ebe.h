@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "elements.h"
+
 namespace fem {
 
 // hex8: the same product in the monomial basis of the trilinear element (sum factorisation written out).
@@ -434,6 +436,123 @@ __device__ __forceinline__ void hex_forces(const double (&X)[8][3], const double
         for (int q = 0; q < 4; q++) hex_pair((q & 1) ? 1.0 : -1.0, (q & 2) ? 1.0 : -1.0, cX, cU, w, lam, mu, F);
     }
     hex_finish(cU, F, g8, gg8, fe, dot);
+}
+
+// ---- nodal stresses of one hex8 element (RecoverNodalStress, src/m_global.F90:489-516) ----------------------------
+// Strain and stress at the 2x2x2 Gauss points (CalcElStress, src/m_local.F90:114-120), extrapolated to the nodes with N2^-1: the
+// nodal values of the trilinear function that takes the Gauss-point values at the Gauss points.  In the monomial basis:
+// the eight moments of the point values against the sign patterns, scaled by the powers of 1/g, and the butterfly back to
+// the nodes -- no 8 x 8 table.  HALF 0: sigma_xx, sigma_yy, sigma_zz; HALF 1: sigma_xy, sigma_yz, sigma_zx (the Voigt
+// order of BMat, src/m_local.F90:160-168); the tile kernel keeps three sums per node in LDS, so the six components take
+// two passes.
+template <int HALF>
+__device__ __forceinline__ void hex_point_strain(const double (&J)[3][3], const double (&G)[3][3], double (&e)[3])
+{
+    double adj[3][3];   // adj[i][j] = det * d xi_j / d x_i
+    adj[0][0] = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    adj[1][0] = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    adj[2][0] = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    adj[0][1] = J[0][2] * J[2][1] - J[0][1] * J[2][2];
+    adj[1][1] = J[0][0] * J[2][2] - J[0][2] * J[2][0];
+    adj[2][1] = J[0][1] * J[2][0] - J[0][0] * J[2][1];
+    adj[0][2] = J[0][1] * J[1][2] - J[0][2] * J[1][1];
+    adj[1][2] = J[0][2] * J[1][0] - J[0][0] * J[1][2];
+    adj[2][2] = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double det = J[0][0] * adj[0][0] + J[0][1] * adj[1][0] + J[0][2] * adj[2][0];
+    double rd = __builtin_amdgcn_rcp(det);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    rd = fma(fma(-det, rd, 1.0), rd, rd);
+    auto H = [&](int l, int i) { return adj[i][0] * G[0][l] + adj[i][1] * G[1][l] + adj[i][2] * G[2][l]; };   // det * du_l/dx_i
+    if constexpr (HALF == 0) { e[0] = H(0, 0) * rd; e[1] = H(1, 1) * rd; e[2] = H(2, 2) * rd; }
+    else { e[0] = (H(0, 1) + H(1, 0)) * rd; e[1] = (H(1, 2) + H(2, 1)) * rd; e[2] = (H(2, 0) + H(0, 2)) * rd; }
+}
+template <int HALF>
+__device__ __forceinline__ void hex_nodal_stress(const double (&X)[8][3], const double (&u)[8][3], double g, double E,
+                                                 double nu, double (&sn)[8][3])
+{
+    const double g8 = 0.125 * g, gg8 = g8 * g;
+    Mono cX[3], cU[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8], c0;
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = X[a][j];
+        cX[j] = hex_mono(v, g8, gg8, c0);
+#pragma unroll
+        for (int a = 0; a < 8; a++) v[a] = u[a][j];
+        cU[j] = hex_mono(v, g8, gg8, c0);
+    }
+    Mono M[3];        // moments of the strains at the points against the sign patterns of the monomials (sigma = D eps,
+    double M0[3];     // DMat src/m_local.F90:204, is applied to the moments: one matrix for all eight points)
+#pragma unroll
+    for (int c = 0; c < 3; c++) { M[c] = Mono{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0}; M0[c] = 0.0; }
+#pragma clang loop unroll(disable)
+    for (int q = 0; q < 4; q++) {   // the Gauss points (s1 g, s2 g, -+g), gradients as in hex_pair
+        const double s1 = (q & 1) ? 1.0 : -1.0, s2 = (q & 2) ? 1.0 : -1.0, s12 = s1 * s2;
+        double Jm[3][3], Jp[3][3], Gm[3][3], Gp[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            {
+                const Mono& c = cX[j];
+                const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+                const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+                Jm[0][j] = B1 - B2; Jp[0][j] = B1 + B2;
+                Jm[1][j] = A1 - A2; Jp[1][j] = A1 + A2;
+                Jm[2][j] = Jp[2][j] = fma(s2, A2, A3);
+            }
+            {
+                const Mono& c = cU[j];
+                const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+                const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+                Gm[0][j] = B1 - B2; Gp[0][j] = B1 + B2;
+                Gm[1][j] = A1 - A2; Gp[1][j] = A1 + A2;
+                Gm[2][j] = Gp[2][j] = fma(s2, A2, A3);
+            }
+        }
+        double sm[3], sp[3];
+        hex_point_strain<HALF>(Jm, Gm, sm);
+        hex_point_strain<HALF>(Jp, Gp, sp);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const double U = sp[c] + sm[c], V = sp[c] - sm[c];
+            M0[c] += U;
+            M[c].x = fma(s1, U, M[c].x);
+            M[c].y = fma(s2, U, M[c].y);
+            M[c].z += V;
+            M[c].xy = fma(s12, U, M[c].xy);
+            M[c].xz = fma(s1, V, M[c].xz);
+            M[c].yz = fma(s2, V, M[c].yz);
+            M[c].xyz = fma(s12, V, M[c].xyz);
+        }
+    }
+    // coefficients of the trilinear fit (the points sit at +-g: one factor 1/g per coordinate), then its nodal values
+    const double r8 = 0.125, r1 = 0.125 / g, r2 = r1 / g, r3 = r2 / g;
+    const DCoef D = dmat_coef(E, nu);
+    auto dmat = [&](double& a, double& b, double& c) {
+        if constexpr (HALF == 0) {
+            const double exx = a, eyy = b, ezz = c;
+            a = D.d11 * exx + D.d12 * eyy + D.d12 * ezz;
+            b = D.d12 * exx + D.d11 * eyy + D.d12 * ezz;
+            c = D.d12 * exx + D.d12 * eyy + D.d11 * ezz;
+        } else { a *= D.d44; b *= D.d44; c *= D.d44; }
+    };
+    dmat(M0[0], M0[1], M0[2]);
+    dmat(M[0].x, M[1].x, M[2].x); dmat(M[0].y, M[1].y, M[2].y); dmat(M[0].z, M[1].z, M[2].z);
+    dmat(M[0].xy, M[1].xy, M[2].xy); dmat(M[0].xz, M[1].xz, M[2].xz); dmat(M[0].yz, M[1].yz, M[2].yz);
+    dmat(M[0].xyz, M[1].xyz, M[2].xyz);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double c0 = r8 * M0[c], P = r1 * M[c].x, Q = r1 * M[c].y, R = r1 * M[c].z;
+        const double PQ = r2 * M[c].xy, PR = r2 * M[c].xz, QR = r2 * M[c].yz, PQR = r3 * M[c].xyz;
+        const double a0m = c0 - R, a0p = c0 + R, axm = P - PR, axp = P + PR, aym = Q - QR, ayp = Q + QR;
+        const double bm = PQ - PQR, bp = PQ + PQR;                       // zeta -, +
+        const double p0m = a0m - aym, q0m = a0m + aym, pxm = axm - bm, qxm = axm + bm;   // eta -, + at zeta -
+        const double p0p = a0p - ayp, q0p = a0p + ayp, pxp = axp - bp, qxp = axp + bp;   // eta -, + at zeta +
+        sn[0][c] = p0m - pxm; sn[1][c] = p0m + pxm;
+        sn[3][c] = q0m - qxm; sn[2][c] = q0m + qxm;
+        sn[4][c] = p0p - pxp; sn[5][c] = p0p + pxp;
+        sn[7][c] = q0p - qxp; sn[6][c] = q0p + qxp;
+    }
 }
 
 }  // namespace fem

@@ -107,6 +107,34 @@ def test_ebe_product_matches_assembled_product_and_oracle(gpu_ctx, oracle, name)
         o.destroy()
 
 
+@pytest.mark.parametrize("name", ["hex_isolated_nodes", "hex_shuffled", "hex_uniform", "hex_sheared", "hex_half_jitter",
+                                  "hex_67nodes_x", "hex_tiles", "hex_tiles_flat"])
+def test_nodal_stress_over_the_tiles_matches_the_element_buffer_path(gpu_ctx, oracle, name):
+    """Once a hex8 mesh carries the tile plan of the one-pass product, RecoverNodalStress + the nodal average
+    (src/main.F90:253-279) run over the same tiles (sums in LDS, strains in the monomial basis, two passes of three
+    components); before that the element buffer + ordered gather serve.  Same field up to rounding, reproducible, and
+    equal to the oracle's nodal stress of the same displacements."""
+    m = _meshes()[name]
+    dm = capi.DeviceMesh(gpu_ctx, m)
+    K = capi.Mat(dm)
+    K.assemble_elements(); K.apply_kbc()
+    rng = np.random.default_rng(11)
+    u = 1e-3 * rng.standard_normal(m.ndof)
+    U = capi.Vec(gpu_ctx, m.ndof)
+    U.set_array(u)
+    s_buf = dm.recover_nodal_stress(U)
+    K.set_mult_type("ebe")
+    assert K.get_mult_info()["kind"] == 2                        # the tile plan exists now
+    s_tile = dm.recover_nodal_stress(U)
+    assert np.array_equal(s_tile, dm.recover_nodal_stress(U))
+    scale = np.abs(s_buf).max()
+    assert np.abs(s_tile - s_buf).max() <= 1e-12 * scale
+    s_ref, _ = oracle.recover_nodal_stress(m, u)                 # (already divided by the valence)
+    assert np.abs(s_tile - s_ref).max() <= 1e-11 * scale
+    for o in (U, K, dm):
+        o.destroy()
+
+
 @pytest.mark.parametrize("name", ["hex5_jitter", "quad9_jitter", "tet", "mixed_tri_qua"])
 @pytest.mark.parametrize("pc", ["jacobi", "mg -pc_mg_type additive", "mg"])
 def test_cg_with_ebe_operator_matches_oracle(gpu_ctx, oracle, name, pc):

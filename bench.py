@@ -41,8 +41,10 @@ FP64_PEAK_TFLOPS = 78.6
 # fp64 work of the element-by-element hex8 kernels AS COMPILED, per element (tile kernels: per element visit):
 # (fp64 vector instructions, flops with fma = 2, all vector instructions) -- tools/count_ebe_flops.py prints them
 EBE_WORK = {
-    "k_ebe_tile<cartesian>": (286, 336, 533),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
-    "k_ebe_tile<affine>": (478, 643, 726),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
+    "k_ebe_tile_x<cartesian>": (281, 349, None),  # one-pass tiles, axis-aligned bricks, x of the tile in LDS (persistent 512-thread
+                                                  # workgroups; the arithmetic of k_ebe_tile<cartesian>, other instructions not counted)
+    "k_ebe_tile<cartesian>": (281, 349, 562),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
+    "k_ebe_tile<affine>": (475, 658, 766),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
     "k_ebe_tile<general>": (1503, 2217, 1900),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
     "k_ebe_apply<3,8,8,3>": (567, 789, 689),   # element buffer + gather, parallelepipeds
     "k_ebe_apply<3,8,8,1>": (1503, 2217, 1669),  # element buffer + gather, distorted elements
@@ -317,15 +319,17 @@ def main():
         affine = args.jitter == 0.0
         if info["kind"] == 2:
             # bench meshes: the regular brick (axis-aligned elements) or, with --jitter, distorted elements throughout
-            kname = "k_ebe_tile<cartesian>" if affine else "k_ebe_tile<general>"
+            x_in_lds = os.environ.get("FEM_AMD_TILE_X", "1") != "0"     # (the library's default for brick tiles)
+            kname = ("k_ebe_tile_x<cartesian>" if x_in_lds else "k_ebe_tile<cartesian>") if affine else "k_ebe_tile<general>"
             visits, slots, tnodes = info["element_visits"], info["lane_slots"], info["tile_nodes"]
             # tile lists (local connectivity 16 B, element id 4 B, flag 1 B per lane slot; node lists 4 B per entry),
             # stored geometry 40 B per visit (axis-aligned bricks; 88 B for other parallelepipeds) or E, nu 16 B per visit + the
             # nodes' coordinates once,
             # x read once, y written once
-            alg = slots * 21.0 + tnodes * 4.0 + nrows * 16.0
+            slot_bytes = 17.0 if (affine and x_in_lds) else 21.0     # (the persistent kernel does not read the element ids)
+            alg = slots * slot_bytes + tnodes * 4.0 + nrows * 16.0
             alg += visits * 40.0 if affine else visits * 16.0 + nrows * 8.0
-            model = ("tile lists 21 B/lane slot + node lists 4 B/entry + " +
+            model = (f"tile lists {slot_bytes:.0f} B/lane slot + node lists 4 B/entry + " +
                      ("stored geometry 40 B/element visit" if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
                      " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
             traffic = traffic_of("ebe_traffic.json") if affine else None   # (the PMC passes were taken on the regular brick)
@@ -346,7 +350,9 @@ def main():
              "fp64": {"flops_per_element_visit": flops_per, "element_visits": visits, "elements": nel,
                       "achieved_TFLOPs": flops / secs / 1e12, "frac_of_fp64_peak": flops / secs / 1e12 / FP64_PEAK_TFLOPS,
                       "vector_instr_per_visit": valu,
-                      "issue_slot_frac": (visits / 64.0) * valu / FP64_ISSUE_RATE / secs,
+                      "fp64_instr_per_visit": instr,
+                      "issue_slot_frac": (visits / 64.0) * (valu or instr) / FP64_ISSUE_RATE / secs,
+                      "issue_slot_frac_counts": "all vector instructions" if valu else "fp64 instructions only",
                       "note": "as compiled (tools/count_ebe_flops.py); round 1's Gauss loop needed 5,025 flops per element, "
                               "the kernel was fp64-bound then (0.65 of peak) and is not any more"}}
         if traffic:

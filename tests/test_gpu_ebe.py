@@ -206,6 +206,61 @@ print("RESULT", [o[2] for o in out], h.hexdigest())
     assert res[0] == res[1]
 
 
+def test_brick_tiles_with_x_in_lds_match_the_gathering_kernel(tmp_path):
+    """Axis-aligned bricks: the persistent 512-thread kernel that keeps x of a tile in LDS (default) and the 256-thread
+    kernel that gathers x from global memory (FEM_AMD_TILE_X=0) -- each reproducible, each within 1e-13 per row of the
+    assembled product, and within rounding of each other (same colours, one writer per node and colour; the compiler
+    contracts the two instantiations of the arithmetic differently).  The switch is read once per process: both runs are
+    child processes."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+from fem_amd import capi
+from fem_amd.mesh import structured_hex
+ctx = capi.Context(0)
+out = {}
+for dims in ((40, 35, 3), (33, 20, 17), (7, 6, 5)):
+    m = structured_hex(*dims)
+    dm = capi.DeviceMesh(ctx, m)
+    K = capi.Mat(dm)
+    K.assemble_elements(); K.apply_kbc()
+    X, Y = capi.Vec(ctx, m.ndof), capi.Vec(ctx, m.ndof)
+    x = np.random.default_rng(2).standard_normal(m.ndof)
+    X.set_array(x)
+    K.mult(X, Y)
+    ya = Y.get_array()
+    K.set_mult_type("ebe")
+    info = K.get_mult_info()
+    assert info["kind"] == 2 and info["affine_tiles"] == info["tiles"]
+    K.mult(X, Y)
+    y = Y.get_array()
+    K.mult(X, Y)
+    assert np.array_equal(y, Y.get_array())
+    free = np.abs(ya) < 1e20 * np.abs(x).max()                  # (penalty rows: 1e30 x)
+    assert np.abs(y - ya)[free].max() <= 1e-13 * np.abs(ya[free]).max()
+    assert np.abs(y - ya)[~free].max() <= 1e-13 * np.abs(ya[~free]).max()
+    out["y%%dx%%dx%%d" %% dims] = y
+np.savez(sys.argv[1], **out)
+print("RESULT")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))),)
+    ys = []
+    for flag in ("0", "1"):
+        f = str(tmp_path / f"y{flag}.npz")
+        env = dict(os.environ, FEM_AMD_TILE_X=flag)
+        p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "RESULT" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+        ys.append(np.load(f))
+    for k in ys[0].files:
+        a, b = ys[0][k], ys[1][k]
+        free = np.abs(a) < 1e20
+        assert np.abs(a - b)[free].max() <= 1e-14 * np.abs(a[free]).max(), k
+        assert np.abs(a - b)[~free].max() <= 1e-14 * np.abs(a[~free]).max(), k
+
+
 def test_ebe_full_size_config3(gpu_ctx):
     """Config 3 at full size: same iteration count (+-2) and displacement field as the assembled SpMV."""
     m = structured_hex(149)

@@ -81,24 +81,27 @@ while i < len(lines):
 lines = asm_of("fem_amd/csrc/ebe_tile.hip")
 i = 0
 while i < len(lines):
-    m = re.match(r"^(_ZN3fem10k_ebe_tileILi([012])E\w+):", lines[i])
-    if not m:
+    m = re.match(r"^(_ZN3fem10k_ebe_tileILi([012])E(?:Li(\d)E)?\w+):", lines[i])
+    if not m or (m.group(3) and m.group(3) != "0"):   # (the stress passes <0,1>, <0,2> are not products)
         i += 1
         continue
+    xk = "k_ebe_tile_x" in m.group(1)
     j = i
     while not lines[j].startswith(".Lfunc_end"):
         j += 1
     body = lines[i:j]
-    # the step loop: the depth-1 loop that holds the LDS adds -- every block the compiler marks "in Loop: Header=<that one>",
-    # inner loops (depth 2: the Gauss pairs of the general path) four times
+    # the step loop: the loop that holds the LDS adds (depth 1; depth 2 in the persistent kernel, whose outer loop walks the
+    # tiles) -- every block the compiler marks "in Loop: Header=<that one>"; loops inside it (the Gauss pairs of the general
+    # path) four times
     first_add = next(k for k, l in enumerate(body) if "ds_add_f64" in l)
+    depth = 2 if xk else 1
     hdr = None
     for k in range(first_add, -1, -1):
-        mm = re.search(r"Header=(BB\d+_\d+) Depth=1", body[k])
+        mm = re.search(r"Header=(BB\d+_\d+) Depth=%d" % depth, body[k])
         if mm:
             hdr = mm.group(1)
             break
-        mm = re.match(r"^\.L(BB\d+_\d+):.*Loop Header: Depth=1", body[k])
+        mm = re.match(r"^\.L(BB\d+_\d+):.*Loop Header: Depth=%d" % depth, body[k])
         if mm:
             hdr = mm.group(1)
             break
@@ -106,12 +109,17 @@ while i < len(lines):
     cur = 0
     for k, l in enumerate(body):
         if re.match(r"^(\.LBB|; %bb)", l):
-            if ("Header=" + hdr + " Depth=1") in l or re.match(r"^\.L" + hdr + ":", l):
+            if ("Header=" + hdr + " Depth=%d" % depth) in l or re.match(r"^\.L" + hdr + ":", l):
                 cur = 1
-            elif "Depth=2" in l or ("Parent Loop " + hdr) in l:
+            elif ("Depth=%d" % (depth + 1)) in l and ("Parent Loop " + hdr) in l:
+                cur = 4
+            elif not xk and ("Depth=2" in l or ("Parent Loop " + hdr) in l):
                 cur = 4
             else:
                 cur = 0
         weight[k] = cur
-    report("k_ebe_tile<%s> per element visit" % {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)], count(body, weight))
+    report("%s<%s> per element visit" % ("k_ebe_tile_x" if xk else "k_ebe_tile", {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)]),
+           count(body, weight))
     i = j
+print("k_ebe_tile_x<cartesian>: the arithmetic of k_ebe_tile<cartesian> (hex_forces_cart); its rounds, the stage-in and the write-out "
+      "are one loop to the compiler, so the other vector instructions of a round are not counted separately")

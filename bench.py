@@ -41,8 +41,8 @@ FP64_PEAK_TFLOPS = 78.6
 # fp64 work of the element-by-element hex8 kernels AS COMPILED, per element (tile kernels: per element visit):
 # (fp64 vector instructions, flops with fma = 2, all vector instructions) -- tools/count_ebe_flops.py prints them
 EBE_WORK = {
-    "k_ebe_tile_x<cartesian>": (281, 349, None),  # one-pass tiles, axis-aligned bricks, x of the tile in LDS (persistent 512-thread
-                                                  # workgroups; the arithmetic of k_ebe_tile<cartesian>, other instructions not counted)
+    "k_ebe_tile_x<cartesian>": (286, 336, 548),  # one-pass tiles of a mesh of axis-aligned bricks, x of the tile in LDS (three
+                                                  # workgroups per CU)
     "k_ebe_tile<cartesian>": (281, 349, 562),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
     "k_ebe_tile<affine>": (475, 658, 766),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
     "k_ebe_tile<general>": (1503, 2217, 1900),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
@@ -326,7 +326,7 @@ def main():
             # stored geometry 40 B per visit (axis-aligned bricks; 88 B for other parallelepipeds) or E, nu 16 B per visit + the
             # nodes' coordinates once,
             # x read once, y written once
-            slot_bytes = 17.0 if (affine and x_in_lds) else 21.0     # (the persistent kernel does not read the element ids)
+            slot_bytes = 17.0 if (affine and x_in_lds) else 21.0     # (the brick kernel does not read the element ids)
             alg = slots * slot_bytes + tnodes * 4.0 + nrows * 16.0
             alg += visits * 40.0 if affine else visits * 16.0 + nrows * 8.0
             model = (f"tile lists {slot_bytes:.0f} B/lane slot + node lists 4 B/entry + " +

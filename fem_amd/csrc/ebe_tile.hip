@@ -14,7 +14,7 @@
 // Traffic at config 3: tile lists 0.1 GB + x / coordinates through L2 + E, nu + y = about 0.5 GB.
 // Kernels.  k_ebe_tile<KIND>: one tile per 256-thread workgroup, two workgroups per CU, corner values gathered from global
 // memory (distorted elements, parallelepipeds; with OP 1, 2 the nodal stress sums over the same tiles).  k_ebe_tile_x<2>:
-// axis-aligned bricks -- one persistent 512-thread workgroup per CU that keeps x of its tile in LDS.  k_ebe_tile_q4: quad4.
+// meshes of axis-aligned bricks -- smaller tiles, x of the tile in LDS, three workgroups per CU.  k_ebe_tile_q4: quad4.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -37,6 +37,7 @@ using namespace fem;
 namespace fem {
 
 constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
+constexpr int TILE_X_MAX_NODES = 1536, TILE_X_MAX_OWN = 768;   // tiles of the brick kernel with x in LDS (k_ebe_tile_x): 6 / 3 per thread
 constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB); <= 12 * 256
 
 struct EbeTilePlan {
@@ -362,227 +363,158 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
-// The same product with x of the tile in LDS (stored-geometry tiles only): ONE persistent workgroup of 512 threads per CU.
-// The LDS image grows to 48 B per node (sums and x), which leaves room for one tile per CU, so the workgroup walks through
-// its share of the tiles and takes the steps of a tile two at a time (the slots of a colour are contiguous: a 512-lane
-// round is two 256-lane steps).  No gathers from global memory inside the rounds: corner values come from LDS, the slot
-// records and the stored geometry stream in one round ahead, and the node list and x of the NEXT tile travel to registers
-// while the rounds of this one run.  The XCD of a workgroup keeps a contiguous eighth of the list, as in k_ebe_tile.
-template <int KIND>   // 1: parallelepipeds, 2: axis-aligned bricks
-__global__ void __launch_bounds__(512, 1) k_ebe_tile_x(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+// Axis-aligned bricks with x of the tile in LDS.  On a mesh of bricks the plan uses small tiles (15 x 7 x 7 owned nodes: 1,024
+// elements = one 256-lane step in each of the four colours, 1,377 nodes), so that x of all the tile's nodes (24 B each) and the sums of its
+// owned nodes (24 B each) are 51 KB of LDS and THREE workgroups share a CU: their phases (stage-in, steps, write-out)
+// overlap, which one big tile per CU could not offer (see DESIGN.md 4d for the persistent 512-thread kernel this replaced).
+// No gathers from global memory inside the steps: corner values come from LDS (SoA: consecutive lanes read consecutive
+// words), the slot records and the 40 B of stored geometry stream in one step ahead, the steps of the tile sit in the lanes
+// of every wavefront (v_readlane: nothing waits for a scalar load).  The LDS adds of a step are issued BEHIND the barrier
+// that closes the previous colour and the next step's corner values are read ahead of it (x is read-only), so the adds run
+// under the next step's arithmetic; contributions to rim nodes are not added at all (their sums belong to other tiles).
+template <int KIND>   // 2: axis-aligned bricks
+__global__ void __launch_bounds__(256, 3) k_ebe_tile_x(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
                                                        const int2* __restrict__ steps, const int* __restrict__ tnodes,
-                                                       const int* __restrict__ telems, const uint4* __restrict__ tconn,
-                                                       const unsigned char* __restrict__ tflags, const double* __restrict__ x,
-                                                       const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
-                                                       const double* __restrict__ bc_shift, const double* __restrict__ geo,
-                                                       size_t geo_stride, double g, int max_nnode, double* __restrict__ y,
-                                                       double* __restrict__ partial, const int* __restrict__ done)
+                                                       const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
+                                                       const double* __restrict__ x, const int* __restrict__ bc_node,
+                                                       const int* __restrict__ bc_dof, const double* __restrict__ bc_shift,
+                                                       const double* __restrict__ geo, size_t geo_stride, double g, int max_nnode,
+                                                       int max_nown, double* __restrict__ y, double* __restrict__ partial,
+                                                       const int* __restrict__ done)
 {
     if (done && *done) return;
-    static_assert(KIND == 1 || KIND == 2, "stored geometry only");
-    constexpr int NG = KIND == 2 ? 5 : 11;
-    constexpr int NPT = 6;                   // nodes per thread: TILE_MAX_NODES <= 6 * 512
-    constexpr int NPO = 4;                   // owned nodes per thread: at most 2048 per tile (checked at set-up)
+    static_assert(KIND == 2, "stored diagonal of adj(J)");
+    constexpr int NG = 5;
+    constexpr int NPT = TILE_X_MAX_NODES / 256, NPO = TILE_X_MAX_OWN / 256;   // nodes / owned nodes per thread
     extern __shared__ double lds[];
-    __shared__ double sh[8];
-    const int per = gridDim.x / 8, xcd = blockIdx.x % 8, wg = blockIdx.x / 8;
-    const int chunk = (nlist + 7) / 8, lb_end = min(nlist, (xcd + 1) * chunk);
-    int lb = xcd * chunk + wg;
-    if (lb >= lb_end) return;
-    const size_t MN = (size_t)max_nnode;
-    double* acc = lds;                       // acc[d * MN + i]
-    double* xs = lds + 3 * MN;               // xs[d * MN + i]
-    int* gown = reinterpret_cast<int*>(lds + 6 * MN);   // global ids of the owned nodes (the first nown of the list)
-    // the headers of this workgroup's tiles sit in the lanes of every wavefront (lane k: its k-th tile; at most 64 per
-    // launch, the host cuts longer lists): nothing inside the loop waits for a scalar load
-    struct Tile { int t, node_off, nown, nnode, elem_off, step_off, nsteps; };
-    int hl[7] = {0, 0, 0, 0, 0, 0, 0};
-    {
-        const int l = lb + per * (int)(threadIdx.x & 63);
-        if (l < lb_end) {
-            hl[0] = list[l];
+    __shared__ double sh[4];
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // (XCD map as in k_ebe_tile)
+    if (lb >= (unsigned)nlist) return;
+    const int t = list[lb];
+    const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
+    const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
+    const size_t MN = (size_t)max_nnode, MO = (size_t)max_nown;
+    double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
+    double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
+    int nv[NPT];
+    {   // stage in: node list, x -> LDS, sums zeroed (all loads of a lane in flight together)
+        double xv[NPT][3];
 #pragma unroll
-            for (int i = 0; i < 6; i++) hl[1 + i] = hdr[6 * hl[0] + i];
-        }
-    }
-    auto tile_at = [&](int k) {
-        Tile T;
-        T.t = __builtin_amdgcn_readlane(hl[0], k); T.node_off = __builtin_amdgcn_readlane(hl[1], k);
-        T.nown = __builtin_amdgcn_readlane(hl[2], k); T.nnode = __builtin_amdgcn_readlane(hl[3], k);
-        T.elem_off = __builtin_amdgcn_readlane(hl[4], k); T.step_off = __builtin_amdgcn_readlane(hl[5], k);
-        T.nsteps = __builtin_amdgcn_readlane(hl[6], k);
-        return T;
-    };
-    auto load_ids = [&](const Tile& T, int (&nv)[NPT]) {
-#pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 512 * j; nv[j] = (i < T.nnode) ? tnodes[T.node_off + i] : 0; }
-    };
-    auto load_x = [&](const Tile& T, const int (&nv)[NPT], double (&xv)[NPT][3]) {
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
-            const int i = threadIdx.x + 512 * j;
+            const int i = threadIdx.x + 256 * j;
 #pragma unroll
-            for (int d = 0; d < 3; d++) xv[j][d] = (i < T.nnode) ? x[(size_t)nv[j] * 3 + d] : 0.0;
+            for (int d = 0; d < 3; d++) xv[j][d] = (i < nnode) ? x[(size_t)nv[j] * 3 + d] : 0.0;
         }
-    };
-    // the steps of a tile sit in the lanes of every wavefront (lane s: step s; at most 64, checked at set-up); a round: the
-    // step at s and, where that step does not end its colour, the next one beside it
-    struct Round { int first, count, next; bool bar; };
-    auto load_steps = [&](const Tile& T) {
-        const int l = threadIdx.x & 63;
-        return l < T.nsteps ? steps[T.step_off + l] : make_int2(0, 0);
-    };
-    auto round_at = [&](const Tile& T, const int2& sv, int s) {
-        Round r{0, 0, s, false};
-        if (s >= T.nsteps) return r;
-        const int ax = __builtin_amdgcn_readlane(sv.x, s), ay = __builtin_amdgcn_readlane(sv.y, s);
-        r.first = ax; r.count = ay & 0x7fffffff; r.bar = ay < 0; r.next = s + 1;
-        if (!r.bar) { const int by = __builtin_amdgcn_readlane(sv.y, s + 1); r.count += by & 0x7fffffff; r.bar = by < 0; r.next = s + 2; }
-        return r;
-    };
-    struct Slot { uint4 c16; unsigned fl; double geo[NG]; };   // fl bit 1: an element (0: padding or past the round), bit 0: linked to the next lane
-    auto fetch = [&](Slot& q, const Tile& T, const Round& r) {
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nnode) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) xs[d * MN + i] = xv[j][d];
+            }
+            if (i < nown) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc[d * MO + i] = 0.0;
+            }
+        }
+    }
+    int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for now, needed at the write-out
+#pragma unroll
+    for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 256 * j < nown) ? bc_node[nv[j]] : -1;
+    // the steps of the tile in the lanes of every wavefront (lane s: step s; at most 64, checked by the host)
+    const int2 sv = ((int)(threadIdx.x & 63) < nsteps) ? steps[step_off + (threadIdx.x & 63)] : make_int2(0, 0);
+    struct Slot { uint4 c16; unsigned fl; double geo[NG]; };   // fl bit 1: an element (0: padding or past the step), bit 0: linked to the next lane
+    auto fetch = [&](Slot& q, int s) {
         q.fl = 0;
-        if ((int)threadIdx.x >= r.count) return;
-        const size_t k = (size_t)T.elem_off + r.first + threadIdx.x;
+        if (s >= nsteps) return;
+        const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
+        if ((int)threadIdx.x >= cnt) return;
+        const size_t k = (size_t)elem_off + first + threadIdx.x;
         q.c16 = tconn[k];
         q.fl = tflags[k];
 #pragma unroll
         for (int j = 0; j < NG; j++) q.geo[j] = geo[(size_t)j * geo_stride + k];
     };
-
-    // T: the tile in work (the workgroup's kt-th), Tn: the next one (its ids, x, steps and first slots travel during T's rounds)
-    const int ntl = (lb_end - lb + per - 1) / per;     // tiles of this workgroup
-    int kt = 0;
-    Tile T = tile_at(0), Tn = T;
-    bool more = ntl > 1;
-    if (more) Tn = tile_at(1);
-    int nv[NPT];
-    double xv[NPT][3];
-    load_ids(T, nv);
-    int2 sv = load_steps(T), svn = sv;
-    load_x(T, nv, xv);
-    Round rc = round_at(T, sv, 0);
-    Slot q0, q1;
-    fetch(q0, T, rc);
-    int t_done = -1;
-    for (;;) {
-        // stage in: the tile's x and zeroed sums (the previous tile's write-out has read its sums: barrier first)
-        int kb[NPO];
-        __syncthreads();
-        if (t_done >= 0 && threadIdx.x == 0) partial[t_done] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+    // corner values of a step's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
+    auto read_u = [&](double (&u)[8][3], const Slot& q) {
+        const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
 #pragma unroll
-        for (int j = 0; j < NPT; j++) {
-            const int i = threadIdx.x + 512 * j;
-            if (i < T.nnode) {
+        for (int i = 0; i < 4; i++) {
+            const int la = tile_loc(q.c16, c_tminus[i]);
 #pragma unroll
-                for (int d = 0; d < 3; d++) { xs[d * MN + i] = xv[j][d]; acc[d * MN + i] = 0.0; }
-            }
-            if (j < NPO && i < T.nown) gown[i] = nv[j];
+            for (int d = 0; d < 3; d++) u[c_tminus[i]][d] = valid ? xs[d * MN + la] : 0.0;
         }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 512 * j < T.nown) ? bc_node[nv[j]] : -1;
-        if (more) { load_ids(Tn, nv); svn = load_steps(Tn); }
-        int round_no = 0;
-        // corner values of a round's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
-        auto read_u = [&](double (&u)[8][3], const Slot& q) {
-            const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
+        if (valid && !linked) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int la = tile_loc(q.c16, c_tminus[i]);
+                const int la = tile_loc(q.c16, c_tplus[i]);
 #pragma unroll
-                for (int d = 0; d < 3; d++) u[c_tminus[i]][d] = valid ? xs[d * MN + la] : 0.0;
-            }
-            if (valid && !linked) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int la = tile_loc(q.c16, c_tplus[i]);
-#pragma unroll
-                    for (int d = 0; d < 3; d++) u[c_tplus[i]][d] = xs[d * MN + la];
-                }
-            }
-        };
-        // The sums of a round go to LDS BEHIND the barrier that closes the previous colour, and the next round's corner values
-        // are read ahead of it (x is read-only): the LDS adds of a round run under the arithmetic of the next one.
-        double u[8][3];
-        read_u(u, q0);
-        bool prev_bar = false;
-        while (rc.count > 0) {
-            const Round rn = round_at(T, sv, rc.next);
-            if (more && round_no == 1) load_x(Tn, nv, xv);   // (its ids have had a round to arrive; ahead of this round's loads)
-            fetch(q1, T, rn);
-            const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
-            round_no++;
-            tile_complete<3>(u, q0.fl);
-            double fe[8][3], dot;
-            if constexpr (KIND == 2) {
-                const double a[3] = {q0.geo[0], q0.geo[1], q0.geo[2]};
-                hex_forces_cart(a, q0.geo[3], q0.geo[4], u, g, fe, dot);
-            } else {
-                double A[3][3];
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int j = 0; j < 3; j++) A[i][j] = q0.geo[3 * i + j];
-                hex_forces_geom(A, q0.geo[9], q0.geo[10], u, g, fe, dot);
-            }
-            {
-                const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++)
-#pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        const double pv = row_prev(fe[c_tplus[i]][d]);
-                        if (recv) fe[c_tminus[i]][d] += pv;
-                    }
-            }
-            read_u(u, q1);
-            if (prev_bar) __syncthreads();
-            if (valid) {
-#pragma unroll
-                for (int a = 0; a < 8; a++) {
-                    if (linked && (a == 1 || a == 2 || a == 5 || a == 6)) continue;   // handed over
-                    const int la = tile_loc(q0.c16, a);
-                    if (la >= T.nown) continue;   // a rim node: its sum belongs to another tile
-#pragma unroll
-                    for (int d = 0; d < 3; d++)
-                        __hip_atomic_fetch_add(&acc[d * MN + la], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-            prev_bar = rc.bar;
-            rc = rn; q0 = q1;
-        }
-        __syncthreads();   // every sum is in
-        if (more && round_no <= 1) load_x(Tn, nv, xv);   // (a tile of one round, or of nodes without elements)
-        double dot = 0.0;
-#pragma unroll
-        for (int j = 0; j < NPO; j++) {
-            const int i = threadIdx.x + 512 * j;
-            if (i >= T.nown) continue;
-            const size_t v = (size_t)gown[i];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                double sv = acc[d * MN + i];
-                const double xi = xs[d * MN + i];
-                if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sv += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
-                y[v * 3 + d] = sv;
-                dot += xi * sv;
+                for (int d = 0; d < 3; d++) u[c_tplus[i]][d] = xs[d * MN + la];
             }
         }
-        for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
-        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;   // (read behind the next barrier; next written a tile later)
-        t_done = T.t;
-        if (!more) break;
-        rc = round_at(Tn, svn, 0);   // the first slots of the next tile travel during its stage-in
-        fetch(q0, Tn, rc);
-        kt++;
-        T = Tn; sv = svn;
-        more = kt + 1 < ntl;
-        if (more) Tn = tile_at(kt + 1);
-    }
+    };
+    Slot q0, q1;
+    fetch(q0, 0);
     __syncthreads();
-    if (threadIdx.x == 0) partial[t_done] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
+    double u[8][3];
+    read_u(u, q0);
+    bool prev_bar = false;   // the previous step closed a colour: its sums must be in before this step adds
+    for (int s = 0; s < nsteps; s++) {
+        const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
+        fetch(q1, s + 1);
+        const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
+        // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
+        tile_complete<3>(u, q0.fl);
+        double fe[8][3], dot;
+        const double a[3] = {q0.geo[0], q0.geo[1], q0.geo[2]};
+        hex_forces_cart(a, q0.geo[3], q0.geo[4], u, g, fe, dot);
+        {   // +x face forces of a linked lane go to the next lane's -x face nodes
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double pv = row_prev(fe[c_tplus[i]][d]);
+                    if (recv) fe[c_tminus[i]][d] += pv;
+                }
+        }
+        read_u(u, q1);
+        if (prev_bar) __syncthreads();
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (linked && (c == 1 || c == 2 || c == 5 || c == 6)) continue;   // handed over
+                const int la = tile_loc(q0.c16, c);
+                if (la >= nown) continue;     // a rim node: its sum belongs to another tile
+#pragma unroll
+                for (int d = 0; d < 3; d++)   // one writer per node and colour
+                    __hip_atomic_fetch_add(&acc[d * MO + la], fe[c][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        prev_bar = bar;
+        q0 = q1;
+    }
+    __syncthreads();   // every sum is in
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPO; j++) {
+        const int i = threadIdx.x + 256 * j;
+        if (i >= nown) continue;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            double sum = acc[d * MO + i];
+            const double xi = xs[d * MN + i];
+            if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
+            y[(size_t)nv[j] * 3 + d] = sum;
+            dot += xi * sum;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
 // The tile product of a quad4 mesh (plane strain; config 2): the same plan in two dimensions -- 31 x 31 owned nodes per
@@ -876,6 +808,11 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: element pass %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
     // FEM_AMD_TILE_NB="nx,ny,nz": box size (experiments; 15,15,7 won the sweep at config 3)
     int NB[3] = {hex ? 15 : 31, hex ? 15 : 31, hex ? 7 : 1};   // quad4: 32 x 32 elements, 1,089 nodes of 20 B
+    if (hex) {   // a mesh of axis-aligned bricks: small tiles (16 x 8 x 8 elements), x of a tile in LDS, three tiles per CU (k_ebe_tile_x)
+        long long ncart = 0;
+        for (int e = 0; e < nel; e++) ncart += aff[(size_t)e] == 2;
+        if (ncart * 10 >= (long long)nel * 9) { NB[1] = 7; NB[2] = 7; }
+    }
     if (const char* ps = std::getenv("FEM_AMD_TILE_NB")) {
         int q[3] = {0, 0, 0};
         if (std::sscanf(ps, "%d,%d,%d", &q[0], &q[1], &q[2]) == 3 && q[0] > 0 && q[1] > 0 && q[2] > 0)
@@ -1225,33 +1162,22 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     const int c0 = phase == 1 ? P.n_cart_if : 0, c1 = phase == 0 ? P.n_cart_if : P.n_cart;
     const int a0 = phase == 1 ? P.n_aff_if : 0, a1 = phase == 0 ? P.n_aff_if : P.n_aff;
     const int g0 = phase == 1 ? P.n_gen_if : 0, g1 = phase == 0 ? P.n_gen_if : P.n_gen;
+    // bricks: x of the tile in LDS where the plan's tiles are small enough for three workgroups per CU (FEM_AMD_TILE_X=0: never)
     static const bool x_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
-    if (x_env && P.max_nsteps <= 64 && P.max_nown <= 2048) {   // x of the tile in LDS, one persistent 512-thread workgroup per CU
-        static int ncu = 0;
-        if (!ncu) {
-            FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        TILE_MAX_NODES * 48 + 2048 * 4));
-            int dev = 0;
-            FEM_HIP(hipGetDevice(&dev));
-            FEM_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-            ncu = std::max(8, ncu / 8 * 8);
+    const size_t shx = ((size_t)P.max_nnode + (size_t)P.max_nown) * 3 * sizeof(double);
+    constexpr size_t shx_max = 54 * 1024;
+    if (x_env && c1 > c0 && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_MAX_NODES && P.max_nown <= TILE_X_MAX_OWN && shx <= shx_max) {
+        static bool xattr = false;
+        if (!xattr) {
+            FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
+            xattr = true;
         }
-        const size_t shx = (size_t)P.max_nnode * 6 * sizeof(double) + 2048 * sizeof(int);
-        auto gox = [&](auto kern, int n, const int* list) {
-            if (!n) return;
-            for (int o = 0; o < n; o += 64 * ncu) {   // (a workgroup keeps the headers of its tiles in the 64 lanes of a wavefront)
-                const int m = std::min(n - o, 64 * ncu);
-                hipLaunchKernelGGL(kern, dim3(std::min(ncu, (m + 7) / 8 * 8)), dim3(512), shx, s, m, list + o, P.hdr.p, P.steps.p,
-                                   P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
-                                   (size_t)P.slots, g, P.max_nnode, y, part, done);
-            }
-        };
-        gox(k_ebe_tile_x<2>, c1 - c0, P.list_cart.p + c0);
-        go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
-    } else {
-        go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
-        go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
-    }
+        const int n = c1 - c0;
+        hipLaunchKernelGGL(k_ebe_tile_x<2>, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, P.list_cart.p + c0, P.hdr.p, P.steps.p, P.nodes.p,
+                           P.conn16.p, P.flags.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode,
+                           P.max_nown, y, part, done);
+    } else go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
+    go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
     go(k_ebe_tile<0>, g1 - g0, P.list_gen.p + g0);
 }
 // stress_node(nnds, 6) of a hex8 mesh over the tiles of the product (RecoverNodalStress per element, the sum over the

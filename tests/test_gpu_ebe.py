@@ -207,9 +207,9 @@ print("RESULT", [o[2] for o in out], h.hexdigest())
 
 
 def test_brick_tiles_with_x_in_lds_match_the_gathering_kernel(tmp_path):
-    """Axis-aligned bricks: the persistent 512-thread kernel that keeps x of a tile in LDS (default) and the 256-thread
-    kernel that gathers x from global memory (FEM_AMD_TILE_X=0) -- each reproducible, each within 1e-13 per row of the
-    assembled product, and within rounding of each other (same colours, one writer per node and colour; the compiler
+    """Meshes of axis-aligned bricks: the kernel that keeps x of a (small) tile in LDS (default) and the kernel that
+    gathers x from global memory (FEM_AMD_TILE_X=0) over the same plan -- each reproducible, each within 1e-13 per row of
+    the assembled product, and within rounding of each other (same colours, one writer per node and colour; the compiler
     contracts the two instantiations of the arithmetic differently).  The switch is read once per process: both runs are
     child processes."""
     import os

@@ -81,7 +81,7 @@ while i < len(lines):
 lines = asm_of("fem_amd/csrc/ebe_tile.hip")
 i = 0
 while i < len(lines):
-    m = re.match(r"^(_ZN3fem10k_ebe_tileILi([012])E(?:Li(\d)E)?\w+):", lines[i])
+    m = re.match(r"^(_ZN3fem(?:10k_ebe_tile|12k_ebe_tile_x)ILi([012])E(?:Li(\d)E)?\w+):", lines[i])
     if not m or (m.group(3) and m.group(3) != "0"):   # (the stress passes <0,1>, <0,2> are not products)
         i += 1
         continue
@@ -90,11 +90,10 @@ while i < len(lines):
     while not lines[j].startswith(".Lfunc_end"):
         j += 1
     body = lines[i:j]
-    # the step loop: the loop that holds the LDS adds (depth 1; depth 2 in the persistent kernel, whose outer loop walks the
-    # tiles) -- every block the compiler marks "in Loop: Header=<that one>"; loops inside it (the Gauss pairs of the general
+    # the step loop: the loop that holds the LDS adds -- every block the compiler marks "in Loop: Header=<that one>"; loops inside it (the Gauss pairs of the general
     # path) four times
     first_add = next(k for k, l in enumerate(body) if "ds_add_f64" in l)
-    depth = 2 if xk else 1
+    depth = 1
     hdr = None
     for k in range(first_add, -1, -1):
         mm = re.search(r"Header=(BB\d+_\d+) Depth=%d" % depth, body[k])
@@ -121,5 +120,3 @@ while i < len(lines):
     report("%s<%s> per element visit" % ("k_ebe_tile_x" if xk else "k_ebe_tile", {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)]),
            count(body, weight))
     i = j
-print("k_ebe_tile_x<cartesian>: the arithmetic of k_ebe_tile<cartesian> (hex_forces_cart); its rounds, the stage-in and the write-out "
-      "are one loop to the compiler, so the other vector instructions of a round are not counted separately")

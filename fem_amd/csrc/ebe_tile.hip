@@ -372,8 +372,8 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 // of every wavefront (v_readlane: nothing waits for a scalar load).  The LDS adds of a step are issued BEHIND the barrier
 // that closes the previous colour and the next step's corner values are read ahead of it (x is read-only), so the adds run
 // under the next step's arithmetic; contributions to rim nodes are not added at all (their sums belong to other tiles).
-template <int KIND>   // 2: axis-aligned bricks
-__global__ void __launch_bounds__(256, 3) k_ebe_tile_x(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+template <int KIND>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two)
+__global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
                                                        const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                        const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
                                                        const double* __restrict__ x, const int* __restrict__ bc_node,
@@ -383,8 +383,8 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_x(int nlist, const int* __r
                                                        const int* __restrict__ done)
 {
     if (done && *done) return;
-    static_assert(KIND == 2, "stored diagonal of adj(J)");
-    constexpr int NG = 5;
+    static_assert(KIND == 1 || KIND == 2, "stored geometry only");
+    constexpr int NG = KIND == 2 ? 5 : 11;
     constexpr int NPT = TILE_X_MAX_NODES / 256, NPO = TILE_X_MAX_OWN / 256;   // nodes / owned nodes per thread
     extern __shared__ double lds[];
     __shared__ double sh[4];
@@ -468,8 +468,17 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_x(int nlist, const int* __r
         // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
         tile_complete<3>(u, q0.fl);
         double fe[8][3], dot;
-        const double a[3] = {q0.geo[0], q0.geo[1], q0.geo[2]};
-        hex_forces_cart(a, q0.geo[3], q0.geo[4], u, g, fe, dot);
+        if constexpr (KIND == 2) {
+            const double a[3] = {q0.geo[0], q0.geo[1], q0.geo[2]};
+            hex_forces_cart(a, q0.geo[3], q0.geo[4], u, g, fe, dot);
+        } else {
+            double A[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) A[i][j] = q0.geo[3 * i + j];
+            hex_forces_geom(A, q0.geo[9], q0.geo[10], u, g, fe, dot);
+        }
         {   // +x face forces of a linked lane go to the next lane's -x face nodes
             const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
 #pragma unroll
@@ -768,13 +777,16 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     // grid of the mean element size over the bounding box of the nodes; node -> box of NB nodes per direction
     std::vector<unsigned char> aff((size_t)nel);
     std::vector<std::array<double, 9>> part((size_t)NT, std::array<double, 9>{1e300, 1e300, 1e300, -1e300, -1e300, -1e300, 0, 0, 0});
+    std::vector<std::array<double, 12>> edges((size_t)NT, std::array<double, 12>{});   // sums of the signed mean edge vectors [k][d], of their lengths [9 + k]
     parallel_ranges(nn, NT, [&](int th, long long v0, long long v1) {
-        auto& p = part[th];
+        std::array<double, 9> p = part[th];
         for (long long v = v0; v < v1; v++)
             for (int d = 0; d < pd; d++) { p[d] = std::min(p[d], xyz[(size_t)v * pd + d]); p[3 + d] = std::max(p[3 + d], xyz[(size_t)v * pd + d]); }
+        part[th] = p;
     });
     parallel_ranges(nel, NT, [&](int th, long long e0, long long e1) {
-        auto& p = part[th];
+        std::array<double, 9> p = part[th];      // (sums in locals: the workers' records share cache lines)
+        std::array<double, 12> eg{};
         for (long long e = e0; e < e1; e++) {
             double X[8][3] = {};
             for (int a = 0; a < npe; a++)
@@ -793,6 +805,24 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                     p[6 + d] += std::max(ex, ey);
                 }
             }
+            {   // the element's mean edge vectors along xi, eta, zeta (signed): the lattice the mesh sits on, if it is one
+                double ev[3][3] = {};
+                for (int d = 0; d < pd; d++) {
+                    if (hex) {
+                        ev[0][d] = 0.25 * ((X[1][d] + X[2][d] + X[5][d] + X[6][d]) - (X[0][d] + X[3][d] + X[4][d] + X[7][d]));
+                        ev[1][d] = 0.25 * ((X[3][d] + X[2][d] + X[7][d] + X[6][d]) - (X[0][d] + X[1][d] + X[4][d] + X[5][d]));
+                        ev[2][d] = 0.25 * ((X[4][d] + X[5][d] + X[6][d] + X[7][d]) - (X[0][d] + X[1][d] + X[2][d] + X[3][d]));
+                    } else {
+                        ev[0][d] = 0.5 * ((X[1][d] + X[2][d]) - (X[0][d] + X[3][d]));
+                        ev[1][d] = 0.5 * ((X[3][d] + X[2][d]) - (X[0][d] + X[1][d]));
+                    }
+                }
+                for (int k = 0; k < pd; k++) {
+                    double n2 = 0.0;
+                    for (int d = 0; d < pd; d++) { eg[3 * k + d] += ev[k][d]; n2 += ev[k][d] * ev[k][d]; }
+                    eg[9 + k] += std::sqrt(n2);
+                }
+            }
             unsigned char cls = (hex && host_hex_affine(X)) ? 1 : 0;
             if (cls) {   // an axis-aligned brick: the three edges at node 0 run along x, y, z exactly
                 const bool cart = X[1][1] == X[0][1] && X[1][2] == X[0][2] && X[3][0] == X[0][0] && X[3][2] == X[0][2] &&
@@ -801,6 +831,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             }
             aff[(size_t)e] = cls;
         }
+        part[th] = p; edges[th] = eg;
     });
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, hsum[3] = {0, 0, 0};
     for (auto& p : part)
@@ -808,10 +839,11 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: element pass %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
     // FEM_AMD_TILE_NB="nx,ny,nz": box size (experiments; 15,15,7 won the sweep at config 3)
     int NB[3] = {hex ? 15 : 31, hex ? 15 : 31, hex ? 7 : 1};   // quad4: 32 x 32 elements, 1,089 nodes of 20 B
-    if (hex) {   // a mesh of axis-aligned bricks: small tiles (16 x 8 x 8 elements), x of a tile in LDS, three tiles per CU (k_ebe_tile_x)
-        long long ncart = 0;
-        for (int e = 0; e < nel; e++) ncart += aff[(size_t)e] == 2;
-        if (ncart * 10 >= (long long)nel * 9) { NB[1] = 7; NB[2] = 7; }
+    if (hex) {   // a mesh of parallelepipeds (stored geometry): small tiles (16 x 8 x 8 elements), x of a tile in LDS, three (bricks) or
+                 // two tiles per CU (k_ebe_tile_x)
+        long long npar = 0;
+        for (int e = 0; e < nel; e++) npar += aff[(size_t)e] != 0;
+        if (npar * 10 >= (long long)nel * 9) { NB[1] = 7; NB[2] = 7; }
     }
     if (const char* ps = std::getenv("FEM_AMD_TILE_NB")) {
         int q[3] = {0, 0, 0};
@@ -821,6 +853,52 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     const int max_nodes = TILE_MAX_NODES;
     long long nbox[3] = {1, 1, 1};
     double h[3] = {1.0, 1.0, 1.0};
+    // A mesh whose elements all point the same way (a structured grid, sheared or rotated as it may be) is binned in the
+    // coordinates of its own lattice -- L = mean edge vectors, xi = L^-1 x, unit spacing: boxes follow the grid lines, the
+    // chains of x-neighbours run along the first box direction whatever the orientation in space.  Otherwise (the signed
+    // edge vectors of an unstructured mesh cancel) the boxes are axis-aligned in space.
+    bool lattice = false;
+    {
+        double Lm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, len[3] = {1, 1, 1};
+        bool ok = true;
+        for (int k = 0; k < pd; k++) {
+            double sk[3] = {0, 0, 0}, nk = 0.0, n2 = 0.0;
+            for (auto& eg : edges) { for (int d = 0; d < pd; d++) sk[d] += eg[3 * k + d]; nk += eg[9 + k]; }
+            for (int d = 0; d < pd; d++) { Lm[d][k] = sk[d] / nel; n2 += Lm[d][k] * Lm[d][k]; }
+            len[k] = std::sqrt(n2);
+            ok = ok && nk > 0.0 && len[k] >= 0.9 * nk / nel;
+        }
+        const double det = Lm[0][0] * (Lm[1][1] * Lm[2][2] - Lm[1][2] * Lm[2][1]) - Lm[0][1] * (Lm[1][0] * Lm[2][2] - Lm[1][2] * Lm[2][0]) +
+                           Lm[0][2] * (Lm[1][0] * Lm[2][1] - Lm[1][1] * Lm[2][0]);
+        ok = ok && std::fabs(det) >= 0.1 * len[0] * len[1] * len[2];
+        static const bool lattice_env = !(std::getenv("FEM_AMD_TILE_LATTICE") && std::atoi(std::getenv("FEM_AMD_TILE_LATTICE")) == 0);
+        if (ok && lattice_env) {
+            double Li[3][3];
+            Li[0][0] = (Lm[1][1] * Lm[2][2] - Lm[1][2] * Lm[2][1]) / det; Li[0][1] = (Lm[0][2] * Lm[2][1] - Lm[0][1] * Lm[2][2]) / det;
+            Li[0][2] = (Lm[0][1] * Lm[1][2] - Lm[0][2] * Lm[1][1]) / det; Li[1][0] = (Lm[1][2] * Lm[2][0] - Lm[1][0] * Lm[2][2]) / det;
+            Li[1][1] = (Lm[0][0] * Lm[2][2] - Lm[0][2] * Lm[2][0]) / det; Li[1][2] = (Lm[0][2] * Lm[1][0] - Lm[0][0] * Lm[1][2]) / det;
+            Li[2][0] = (Lm[1][0] * Lm[2][1] - Lm[1][1] * Lm[2][0]) / det; Li[2][1] = (Lm[0][1] * Lm[2][0] - Lm[0][0] * Lm[2][1]) / det;
+            Li[2][2] = (Lm[0][0] * Lm[1][1] - Lm[0][1] * Lm[1][0]) / det;
+            // the node coordinates become lattice coordinates (the copy on the host only serves the boxes from here on; the
+            // element classes above were taken from the real coordinates)
+            std::vector<std::array<double, 6>> bb((size_t)NT, std::array<double, 6>{1e300, 1e300, 1e300, -1e300, -1e300, -1e300});
+            parallel_ranges(nn, NT, [&](int th, long long v0, long long v1) {
+                std::array<double, 6> b = bb[th];
+                for (long long v = v0; v < v1; v++) {
+                    double X[3] = {0, 0, 0}, q[3];
+                    for (int d = 0; d < pd; d++) X[d] = xyz[(size_t)v * pd + d];
+                    for (int d = 0; d < pd; d++) q[d] = Li[d][0] * X[0] + Li[d][1] * X[1] + Li[d][2] * X[2];
+                    for (int d = 0; d < pd; d++) { xyz[(size_t)v * pd + d] = q[d]; b[d] = std::min(b[d], q[d]); b[3 + d] = std::max(b[3 + d], q[d]); }
+                }
+                bb[th] = b;
+            });
+            for (int d = 0; d < 3; d++) { lo[d] = 1e300; hi[d] = -1e300; }
+            for (auto& b : bb)
+                for (int d = 0; d < pd; d++) { lo[d] = std::min(lo[d], b[d]); hi[d] = std::max(hi[d], b[3 + d]); }
+            for (int d = 0; d < pd; d++) hsum[d] = (double)nel;   // unit spacing
+            lattice = true;
+        }
+    }
     for (int d = 0; d < pd; d++) {
         h[d] = hsum[d] / nel;
         if (!(h[d] > 0.0)) return refuse("flat mesh");
@@ -857,7 +935,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             bsplit[i] = b;
         }
     }
-    if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: node boxes %.0f ms\n", std::chrono::duration<double, std::milli>(tn - tl).count()); tl = tn; }
+    if (verbose) { const auto tn = std::chrono::steady_clock::now(); std::fprintf(stderr, "[fem_amd] ebe tiles set-up: node boxes %.0f ms (%s, %d x %d x %d nodes per box)\n", std::chrono::duration<double, std::milli>(tn - tl).count(), lattice ? "in the coordinates of the mesh's lattice" : "axis-aligned in space", NB[0], NB[1], NB[2]); tl = tn; }
     // nodes shared with other domains (a partitioned mesh): tiles that own one are computed first, so that the halo exchange
     // of their rows can run beside the others (ksp.hip)
     std::vector<unsigned char> shared_node;
@@ -1166,18 +1244,24 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     static const bool x_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
     const size_t shx = ((size_t)P.max_nnode + (size_t)P.max_nown) * 3 * sizeof(double);
     constexpr size_t shx_max = 54 * 1024;
-    if (x_env && c1 > c0 && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_MAX_NODES && P.max_nown <= TILE_X_MAX_OWN && shx <= shx_max) {
+    if (x_env && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_MAX_NODES && P.max_nown <= TILE_X_MAX_OWN && shx <= shx_max) {
         static bool xattr = false;
         if (!xattr) {
-            FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
+            for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>)})
+                FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
             xattr = true;
         }
-        const int n = c1 - c0;
-        hipLaunchKernelGGL(k_ebe_tile_x<2>, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, P.list_cart.p + c0, P.hdr.p, P.steps.p, P.nodes.p,
-                           P.conn16.p, P.flags.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode,
-                           P.max_nown, y, part, done);
-    } else go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
-    go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
+        auto gox = [&](auto kern, int n, const int* list) {
+            if (!n) return;
+            hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.conn16.p, P.flags.p,
+                               x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done);
+        };
+        gox(k_ebe_tile_x<2>, c1 - c0, P.list_cart.p + c0);
+        gox(k_ebe_tile_x<1>, a1 - a0, P.list_aff.p + a0);
+    } else {
+        go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
+        go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
+    }
     go(k_ebe_tile<0>, g1 - g0, P.list_gen.p + g0);
 }
 // stress_node(nnds, 6) of a hex8 mesh over the tiles of the product (RecoverNodalStress per element, the sum over the

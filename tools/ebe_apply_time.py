@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/ebe_apply_time.py [n] [reps] -- per-kernel time of the element-by-element product (event pairs around
-k_ebe_apply and k_ebe_gather) on the n^3 hex8 cube."""
+"""tools/ebe_apply_time.py [n] [reps] [sheared] -- per-kernel time of the element-by-element product (event pairs around
+the element kernel and the gather) on the n^3 hex8 cube; `sheared`: the cube mapped to a parallelepiped (stored adj(J))."""
 import os
 import sys
 
@@ -14,6 +14,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 149
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 ctx = capi.Context(0)
 m = structured_hex(n)
+if len(sys.argv) > 3 and sys.argv[3] == "sheared":
+    M = np.array([[1.1, 0.3, -0.2], [0.05, 0.9, 0.4], [-0.15, 0.2, 1.3]])
+    m.coords = np.ascontiguousarray(m.coords @ M.T + np.array([0.3, -1.7, 2.9]))
 prob = driver.Problem(ctx, m, "-mat_mult_type ebe")
 prob.assemble(); prob.ksp.set_up()
 X, Y = capi.Vec(ctx, m.ndof), capi.Vec(ctx, m.ndof)

@@ -267,15 +267,17 @@ def main():
 
     # stress recovery (RecoverStress + RecoverNodalStress + nodal average, src/main.F90:252-292), reported beside the
     # metric as SURVEY 8(d) asks: outside the timed region, displacements of the last solve, result left on the device
-    S = capi.Vec(ctx, mesh.nnds * (3 if mesh.pdim == 2 else 6))
-    prob.dmesh.recover_nodal_stress_vec(prob.U, S)
-    ctx.synchronize()
-    ts = time.perf_counter()
-    for _ in range(5):
+    stress_ms = None
+    if world == 1:       # (N > 1: the nodal sums cross the domains; that exchange is covered by the multi-domain tests, not timed here)
+        S = capi.Vec(ctx, mesh.nnds * (3 if mesh.pdim == 2 else 6))
         prob.dmesh.recover_nodal_stress_vec(prob.U, S)
-    ctx.synchronize()
-    stress_ms = (time.perf_counter() - ts) / 5 * 1e3
-    S.destroy()
+        ctx.synchronize()
+        ts = time.perf_counter()
+        for _ in range(5):
+            prob.dmesh.recover_nodal_stress_vec(prob.U, S)
+        ctx.synchronize()
+        stress_ms = (time.perf_counter() - ts) / 5 * 1e3
+        S.destroy()
     npe = len(mesh.conn) // max(mesh.nels, 1)
     stress_bytes = mesh.nels * npe * 4.0 + 2.0 * mesh.nnds * mesh.pdim * 8.0 + mesh.nnds * (3 if mesh.pdim == 2 else 6) * 8.0
 
@@ -403,11 +405,12 @@ def main():
             "roofline": roof,
         }
         out.update(side)
-        out["stress_recovery"] = {"ms": stress_ms, "bound": "hbm", "algorithmic_bytes": stress_bytes,
-                                  "achieved": stress_bytes / (stress_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": stress_bytes / (stress_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                  "note": "not part of the metric (assemble + solve); nodal stress of the last solution, "
-                                          "left on the device"}
+        if stress_ms is not None:
+            out["stress_recovery"] = {"ms": stress_ms, "bound": "hbm", "algorithmic_bytes": stress_bytes,
+                                      "achieved": stress_bytes / (stress_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": stress_bytes / (stress_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "not part of the metric (assemble + solve); nodal stress of the last solution, "
+                                              "left on the device"}
         if args.mult == "ebe" and hex_case and args.pc == "jacobi":
             # the CG iteration as a whole against the HBM roof: bytes of the product kernel (PMC where taken, else its
             # algorithmic bytes) + the two vector kernels (x += a p, r -= a w, z, dots: 7 passes; p = z + b p: 4 passes)

@@ -37,7 +37,9 @@ using namespace fem;
 namespace fem {
 
 constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
-constexpr int TILE_X_MAX_NODES = 1536, TILE_X_MAX_OWN = 768;   // tiles of the brick kernel with x in LDS (k_ebe_tile_x): 6 / 3 per thread
+constexpr int TILE_X_MAX_NODES = 1536, TILE_X_MAX_OWN = 768;   // tiles of the kernels with x in LDS (k_ebe_tile_x): 6 / 3 slots per thread
+constexpr int TILE_X_LDS_NODES = 1408;   // their LDS image, fixed (the component offsets become immediates of the LDS instructions):
+                                         // (1408 + 768) * 24 B = 51 KiB, three workgroups per CU; the 16 x 8 x 8-element tile has 1,377 nodes
 constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB); <= 12 * 256
 
 struct EbeTilePlan {
@@ -393,7 +395,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     const int t = list[lb];
     const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
     const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
-    const size_t MN = (size_t)max_nnode, MO = (size_t)max_nown;
+    constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
     double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
     double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
     int nv[NPT];
@@ -1242,9 +1244,8 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     const int g0 = phase == 1 ? P.n_gen_if : 0, g1 = phase == 0 ? P.n_gen_if : P.n_gen;
     // bricks: x of the tile in LDS where the plan's tiles are small enough for three workgroups per CU (FEM_AMD_TILE_X=0: never)
     static const bool x_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
-    const size_t shx = ((size_t)P.max_nnode + (size_t)P.max_nown) * 3 * sizeof(double);
-    constexpr size_t shx_max = 54 * 1024;
-    if (x_env && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_MAX_NODES && P.max_nown <= TILE_X_MAX_OWN && shx <= shx_max) {
+    constexpr size_t shx = (size_t)(TILE_X_LDS_NODES + TILE_X_MAX_OWN) * 3 * sizeof(double), shx_max = shx;
+    if (x_env && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_LDS_NODES && P.max_nown <= TILE_X_MAX_OWN) {
         static bool xattr = false;
         if (!xattr) {
             for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>)})

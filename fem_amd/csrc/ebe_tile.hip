@@ -88,17 +88,18 @@ __device__ __forceinline__ int tile_loc(const uint4& c, int a)
     const unsigned w = a < 2 ? c.x : a < 4 ? c.y : a < 6 ? c.z : c.w;
     return (a & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
 }
-// value of the next / the previous lane of the 16-lane row (DPP row_shl:1 / row_shr:1; lanes without a source keep 0)
+// value of the next / the previous lane of the 16-lane row (DPP row_shl:1 / row_shr:1 with bound_ctrl: a lane without a source
+// reads 0 and no register has to be zeroed for it beforehand -- those lanes never use the value)
 __device__ __forceinline__ double row_next(double x)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x101, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x101, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x101, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double row_prev(double x)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x111, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x111, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 // stage 1 (three steps ahead): the lane's slot from the tile lists -- plain global loads, nothing depends on them yet
@@ -298,7 +299,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         }
         // +x face forces of a linked lane go to the next lane's -x face nodes
         {
-            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(i0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(i0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -482,7 +483,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
             hex_forces_geom(A, q0.geo[9], q0.geo[10], u, g, fe, dot);
         }
         {   // +x face forces of a linked lane go to the next lane's -x face nodes
-            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
 #pragma unroll
             for (int i = 0; i < 4; i++)
 #pragma unroll
@@ -605,7 +606,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
         const DCoef D = dmat_coef(valid ? e0.E : 1.0, valid ? e0.nu : 0.25);
         quad4_forces(e0.X, e0.u, g, w, D.d12, D.d44, fe, dot);
         {   // +x edge forces of a linked lane go to the next lane's -x edge nodes
-            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(e0.fl & 1u), 0x111, 0xf, 0xf, false) != 0;
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(e0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
 #pragma unroll
             for (int d = 0; d < 2; d++) {
                 const double p1 = row_prev(fe[1][d]), p2 = row_prev(fe[2][d]);

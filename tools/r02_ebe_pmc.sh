@@ -1,8 +1,8 @@
 #!/bin/bash
-# SQ / TCC counters of k_ebe_apply and k_ebe_gather at config 3 (separate rocprofv3 --pmc passes)
+# SQ / LDS / TCC / TD counters of the element-by-element kernels at config 3 (separate rocprofv3 --pmc passes)
 set -eo pipefail
 export TMPDIR=/tmp
-O=gpurun_out/r02f
+O=gpurun_out/pmc_brick
 mkdir -p $O
 run() { # name counters...
   local name=$1; shift

@@ -955,6 +955,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         TileOut& o = outs[th];
         std::vector<unsigned> cmask;
         std::vector<int> el, nd, col, chain_start, lconn;   // lconn: tile-local node numbers of el's nodes
+        std::vector<std::pair<unsigned long long, int>> ekey;
         SmallMap emap(1u << 15), nmap(1u << 15);            // elements / nodes of the tile in hand (far below 32 K each)
         std::vector<std::vector<int>> todo;   // owned-node sets still to be turned into tiles (a box, or the halves of one)
         std::vector<unsigned char> todo_force;   // per set: halve it before anything else
@@ -1012,7 +1013,21 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 }
                 huge = el.size() > 16000;
             }
-            std::sort(el.begin(), el.end());
+            // the tile's elements in the order of the grid (z, y, x of their first node, in the box coordinates), whatever the
+            // numbering of the mesh: x-neighbours become consecutive, so the chains and a handful of colours are found on a
+            // mesh with shuffled element ids as on one numbered along the grid (where this is the ascending order of the ids)
+            ekey.resize(el.size());
+            for (size_t i = 0; i < el.size(); i++) {
+                const size_t v = (size_t)conn[(size_t)el[i] * npe];
+                unsigned long long k = 0;
+                for (int d = pd - 1; d >= 0; d--) {
+                    const long long gcoord = std::llround((xyz[v * pd + d] - lo[d]) / h[d]) + 4;
+                    k = (k << 21) | (unsigned long long)(std::min(std::max(gcoord, 0LL), (1LL << 21) - 1));
+                }
+                ekey[i] = {k, el[i]};
+            }
+            std::sort(ekey.begin(), ekey.end());
+            for (size_t i = 0; i < el.size(); i++) el[i] = ekey[i].second;
             nd.assign(own.begin(), own.end());
             for (int k = 0; k < nown && !huge; k++) { bool fresh; *nmap.slot(own[k], fresh) = k; }
             for (size_t i = 0; i < el.size() && !huge; i++) {
@@ -1038,7 +1053,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             lconn.resize(el.size() * (size_t)npe);
             for (size_t i = 0; i < el.size(); i++)
                 for (int a = 0; a < npe; a++) lconn[i * npe + a] = local_of(conn[(size_t)el[i] * npe + a]);
-            // chains: runs of elements (ascending ids) whose +x face is the next one's -x face, at most 16 long -- a chain
+            // chains: runs of elements (in that order) whose +x face is the next one's -x face, at most 16 long -- a chain
             // sits in consecutive lanes of one 16-lane row and passes its shared-face values along the row (k_ebe_tile)
             chain_start.clear();
             for (size_t i = 0; i < el.size(); i++) {

@@ -36,8 +36,9 @@ def _half_jitter(m):
 
 
 def _shuffled(m, seed=3):
-    """the same hex8 mesh with the elements in random order and the nodes renumbered at random: no x-neighbours in
-    consecutive lanes (chains of one element), colours as the greedy pass finds them"""
+    """the same hex8 mesh with the elements in random order and the nodes renumbered at random: the tile plan orders a
+    tile's elements along the grid itself (chains and colours as on the mesh numbered along the grid), the gathers of a
+    tile's x are scattered"""
     rng = np.random.default_rng(seed)
     pe = rng.permutation(m.nels)
     pn = rng.permutation(m.nnds).astype(np.int32)     # new id of old node i

@@ -303,3 +303,30 @@ def test_deck_writer_round_trips(tmp_path):
         fval[:, m.pdim:] = np.minimum(fval[:, m.pdim:], m.t)     # the reader clamps t1, t2 to t (src/m_io.F90:357-358)
         assert np.array_equal(fval, r.fval), seed
         assert (r.t, r.dt, r.pdim) == (m.t, m.dt, m.pdim)
+
+
+def test_bench_work_table_matches_the_compiled_kernels():
+    """bench.py prices the element-by-element kernels with the fp64 work per element visit AS COMPILED (EBE_WORK): the table
+    has to follow the code.  tools/count_ebe_flops.py compiles the device code for gfx950 (no GPU needed) and counts."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "count_ebe_flops.py")], cwd=root, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = {}
+    for line in out.stdout.splitlines():
+        m = re.match(r"^(k_ebe_\w+<[^>]+>)[^:]*: .*fp64 instr (\d+), flops (\d+), all vector instr (\d+)", line)
+        if m:
+            got[m.group(1)] = tuple(int(v) for v in m.group(2, 3, 4))
+    sys.path.insert(0, root)
+    import bench
+    for name in ("k_ebe_tile_x<cartesian>", "k_ebe_tile<cartesian>", "k_ebe_tile<affine>", "k_ebe_apply<3,8,8,3>"):
+        assert got[name] == tuple(bench.EBE_WORK[name]), (name, got[name], bench.EBE_WORK[name])
+    # distorted elements: the arithmetic of the general path alone (the tool's count of k_ebe_tile<general> includes the
+    # parallelepiped shortcut that a wavefront of distorted elements never takes)
+    assert got["k_ebe_apply<3,8,8,2>"][:2] == tuple(bench.EBE_WORK["k_ebe_tile<general>"][:2])

@@ -160,13 +160,15 @@ def test_cg_with_ebe_operator_matches_oracle(gpu_ctx, oracle, name, pc):
     assert abs(res.its[-1] - ref.its[-1]) <= max(2, ref.its[-1] // 50)
 
 
-def test_ebe_on_a_partitioned_mesh(oracle):
-    """Element-by-element product + halo sums on four brick domains against the serial oracle."""
+@pytest.mark.parametrize("jitter,npr", [(0.15, (4, 3, 4)), (0.0, (17, 9, 8))])
+def test_ebe_on_a_partitioned_mesh(oracle, jitter, npr):
+    """Element-by-element product + halo sums on four brick domains against the serial oracle: distorted elements (the
+    gathering tile kernel) and straight bricks (small tiles with x in LDS, several tiles per domain, shared nodes)."""
     from tests.test_gpu_multidomain import _run_domains
-    world, npr = 4, (4, 3, 4)
-    grid, out = _run_domains(world, npr, 0.15, "-mat_mult_type ebe -ksp_rtol 1e-13")
+    world = 4
+    grid, out = _run_domains(world, npr, jitter, "-mat_mult_type ebe -ksp_rtol 1e-13")
     gn = tuple(grid[d] * npr[d] for d in range(3))
-    g = structured_hex(*gn, jitter=0.15)
+    g = structured_hex(*gn, jitter=jitter)
     ug, sg, gits = oracle.run(g, "cg", rtol=1e-13)
     rp, ci = oracle.csr_pattern(g)
     val = oracle.assemble(g, rp, ci, apply_bc=True)

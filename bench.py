@@ -334,7 +334,7 @@ def main():
             model = (f"tile lists {slot_bytes:.0f} B/lane slot + node lists 4 B/entry + " +
                      ("stored geometry 40 B/element visit" if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
                      " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
-            traffic = traffic_of("ebe_traffic.json") if affine else None   # (the PMC passes were taken on the regular brick)
+            traffic = traffic_of("ebe_traffic.json") if (affine and x_in_lds) else None   # (the PMC passes were taken on the regular brick, default kernel)
         else:
             kname = "k_ebe_apply<3,8,8,3>" if affine else "k_ebe_apply<3,8,8,1>"
             visits = nel

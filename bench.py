@@ -265,6 +265,21 @@ def main():
     prob.K.set_mult_type(args.mult)
     X.destroy(); Y.destroy()
 
+    # what a plain streaming kernel reaches on this GPU ("a measured triad ceiling too"): y += a x, 3 passes, over
+    # vectors large enough (2 x 4 N x 8 B = 0.65 GB at config 3) that the 256 MB Infinity Cache cannot hold them from one
+    # launch to the next; 10 launches back to back
+    ns = max(4 * nrows, 1 << 25)
+    Xs, Ys = capi.Vec(ctx, ns), capi.Vec(ctx, ns)
+    Xs.set(1.0); Ys.set(2.0)
+    Ys.axpy(1e-3, Xs)
+    ctx.synchronize()
+    ts = time.perf_counter()
+    for _ in range(10):
+        Ys.axpy(1e-3, Xs)
+    ctx.synchronize()
+    stream_gbs = 10 * 3.0 * ns * 8.0 / (time.perf_counter() - ts) / 1e9
+    Xs.destroy(); Ys.destroy()
+
     # stress recovery (RecoverStress + RecoverNodalStress + nodal average, src/main.F90:252-292), reported beside the
     # metric as SURVEY 8(d) asks: outside the timed region, displacements of the last solve, result left on the device
     stress_ms = None
@@ -405,6 +420,8 @@ def main():
             "roofline": roof,
         }
         out.update(side)
+        out["hbm_stream_measured"] = {"GBs": stream_gbs, "kernel": "y += a x over two vectors of 4 N doubles (3 passes; beyond the Infinity Cache; 10 launches "
+                                                                      "back to back, launch gaps included)", "frac_of_spec": stream_gbs / HBM_PEAK_GBS}
         if stress_ms is not None:
             out["stress_recovery"] = {"ms": stress_ms, "bound": "hbm", "algorithmic_bytes": stress_bytes,
                                       "achieved": stress_bytes / (stress_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -419,7 +436,8 @@ def main():
             it_s = t_sol / args.steps / max(its, 1)
             out["cg_iteration_roofline"] = {"bound": "hbm", "bytes": it_bytes, "product_bytes": prod,
                                             "vector_bytes": 11.0 * nrows * 8.0, "achieved": it_bytes / it_s / 1e9,
-                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_bytes / it_s / 1e9 / HBM_PEAK_GBS}
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_bytes / it_s / 1e9 / HBM_PEAK_GBS,
+                                            "frac_of_measured_stream": it_bytes / it_s / 1e9 / stream_gbs}
         if world > 1 and args.n == 149 and args.jitter == 0.0 and hex_case:
             # weak scaling of a non-optimal-order solver: the global problem needs more iterations (measured on
             # one GPU holding the whole problem, DESIGN.md section 5: 724 / 1102 / 1048 / 1412 at N = 1 / 2 / 4 / 8)

@@ -853,7 +853,10 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         if (std::sscanf(ps, "%d,%d,%d", &q[0], &q[1], &q[2]) == 3 && q[0] > 0 && q[1] > 0 && q[2] > 0)
             for (int d = 0; d < pd; d++) NB[d] = q[d];
     }
-    const int max_nodes = TILE_MAX_NODES;
+    // node limits of a tile: the LDS image of the kernels it is meant for (small tiles: k_ebe_tile_x); a box that holds more (a
+    // graded or distorted mesh) is halved
+    const bool small_tiles = hex && NB[1] <= 7 && NB[2] <= 7;
+    const int max_nodes = small_tiles ? TILE_X_LDS_NODES : TILE_MAX_NODES, max_own = small_tiles ? TILE_X_MAX_OWN : 0x7fffffff;
     long long nbox[3] = {1, 1, 1};
     double h[3] = {1.0, 1.0, 1.0};
     // A mesh whose elements all point the same way (a structured grid, sheared or rotated as it may be) is binned in the
@@ -1042,7 +1045,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             std::sort(nd.begin() + nown, nd.end());
             for (size_t i = (size_t)nown; i < nd.size() && !huge; i++) { bool fresh; *nmap.slot(nd[i], fresh) = (int)i; }
             auto local_of = [&](int v) { return nmap.get(v); };
-            if (huge || (int)nd.size() > max_nodes) {
+            if (huge || (int)nd.size() > max_nodes || nown > max_own) {
                 // too many nodes for the LDS image (a box of a distorted mesh may hold more than its share): halve the set
                 // of owned nodes and try again
                 if (nown < 2) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }

@@ -27,6 +27,16 @@ def _rotated(m):
     return m
 
 
+def _graded(m):
+    """axis-aligned bricks of growing size (geometric grading along x and z): boxes of the mean spacing hold very different
+    numbers of nodes -- the crowded ones are halved until they fit the LDS image of the brick kernel"""
+    c = m.coords.copy()
+    c[:, 0] = 40.0 * (np.expm1(c[:, 0] / c[:, 0].max() * 2.0) / np.expm1(2.0))
+    c[:, 2] = 9.0 * (c[:, 2] / c[:, 2].max()) ** 2
+    m.coords = np.ascontiguousarray(c)
+    return m
+
+
 def _half_jitter(m):
     """distorted in one half, parallelepipeds in the other: wavefronts that hold both kinds take the general path"""
     j = structured_hex(9, 8, 7, jitter=0.2)
@@ -67,6 +77,7 @@ def _meshes():
         "hex_uniform": structured_hex(7, 6, 5),                      # every element a cube: affine path
         "hex_sheared": _sheared(structured_hex(9, 8, 7)),
         "hex_rotated": _rotated(structured_hex(18, 9, 17)),
+        "hex_graded": _graded(structured_hex(40, 18, 16)),
         "hex_half_jitter": _half_jitter(structured_hex(9, 8, 7)),
         "hex5_jitter": structured_hex(5, 4, 3, jitter=0.2),
         "hex_67nodes_x": structured_hex(66, 2, 2, jitter=0.1),
@@ -119,7 +130,7 @@ def test_ebe_product_matches_assembled_product_and_oracle(gpu_ctx, oracle, name)
 
 
 @pytest.mark.parametrize("name", ["hex_isolated_nodes", "hex_shuffled", "hex_uniform", "hex_sheared", "hex_half_jitter",
-                                  "hex_67nodes_x", "hex_tiles", "hex_tiles_flat"])
+                                  "hex_67nodes_x", "hex_tiles", "hex_tiles_flat", "hex_graded"])
 def test_nodal_stress_over_the_tiles_matches_the_element_buffer_path(gpu_ctx, oracle, name):
     """Once a hex8 mesh carries the tile plan of the one-pass product, RecoverNodalStress + the nodal average
     (src/main.F90:253-279) run over the same tiles (sums in LDS, strains in the monomial basis, two passes of three

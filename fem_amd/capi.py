@@ -71,6 +71,7 @@ _SIGS = {
     "fem_mat_get_profile": [_h, C.c_int, _ip, _dp, _dp, _dp],
     "fem_mat_get_mult_info": [_h, _ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                               C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _dp],
+    "fem_mesh_tile_plan_digest": [_h, C.c_char_p, C.POINTER(C.c_ulonglong), _dp],
     "fem_mat_get_diagonal": [_h, _h],
     "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
     "fem_vec_create": [_h, C.c_longlong, C.POINTER(_h)],
@@ -349,6 +350,18 @@ class DeviceMesh:
     def set_halo(self, comm: Comm, neigh_rank, neigh_ptr, neigh_nodes):
         nr, npx, nn = _i32(neigh_rank), _i32(neigh_ptr), _i32(neigh_nodes)
         _ck(_lib.fem_mesh_set_halo(self.h, comm.h, len(nr), _i(nr), _i(npx), _i(nn)))
+
+    def tile_plan_digest(self, builder: str = "device") -> dict:
+        """Digest of the tile plan of `-mat_mult_type ebe` built afresh by "device" (the product's builder) or "host" (the
+        cross-check); a Mat must have been created from this mesh."""
+        d = (C.c_ulonglong * 12)()
+        ms = C.c_double(0)
+        _ck(_lib.fem_mesh_tile_plan_digest(self.h, builder.encode(), d, C.byref(ms)))
+        names = ("tiles", "lane_slots", "tile_nodes", "element_visits", "hdr", "steps", "nodes", "elems", "conn16", "flags",
+                 "lists", "geometry")
+        out = {k: int(v) for k, v in zip(names, d)}
+        out["setup_ms"] = ms.value
+        return out
 
     def form_rhs(self, F: "Vec", t_init: float, dt: float, mesh=None):
         """FormRHS(t_init, dt) (src/m_global.F90:373)."""

@@ -1,0 +1,54 @@
+// fem_amd/csrc/ebe_tile.h -- the tile plan of the one-pass element-by-element product (ebe_tile.hip: kernels and the host
+// builder kept for cross-checks; ebe_plan.hip: the builder that runs on the device).
+#pragma once
+#include <memory>
+
+#include "objects.h"
+
+namespace fem {
+
+constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
+constexpr int TILE_X_MAX_NODES = 1536, TILE_X_MAX_OWN = 768;   // tiles of the kernels with x in LDS (k_ebe_tile_x): 6 / 3 slots per thread
+constexpr int TILE_X_LDS_NODES = 1408;   // their LDS image, fixed (the component offsets become immediates of the LDS instructions):
+                                         // (1408 + 768) * 24 B = 51 KiB, three workgroups per CU; the 16 x 8 x 8-element tile has 1,377 nodes
+constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB); <= 12 * 256
+
+struct EbeTilePlan {
+    int ntiles = 0, n_aff = 0, n_gen = 0, max_nnode = 0, max_nsteps = 0, max_nown = 0;
+    long long tile_elements = 0;         // elements computed per product (rim elements counted once per tile)
+    long long slots = 0;                 // lanes of all steps (elements + the padding of 16-lane rows)
+    long long tile_nodes = 0;            // entries of all node lists
+    DBuf<int> hdr;                       // [ntiles*6] node_off, nown, nnode, elem_off, step_off, nsteps
+    DBuf<int2> steps;                    // rounds of <= 256 elements of one colour: {first (relative), count | barrier << 31}
+    DBuf<int> nodes;                     // global node ids of every tile, owned ones first
+    DBuf<int> elems;                     // [slots] global element id of every lane slot, colour by colour; -1 = padding
+    DBuf<uint4> conn16;                  // the same elements' eight tile-local node numbers (16 bit each)
+    DBuf<unsigned char> flags;           // [slots] bit 0: the element's +x face is the -x face of the next lane's element
+    DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others; in both lists the tiles
+                                         // that own a node shared with another domain come first
+    int n_aff_if = 0, n_gen_if = 0;      // how many of each list those are
+    DBuf<int> list_cart;                 // tiles of axis-aligned bricks (a third list, same order rule); not in list_aff
+    int n_cart = 0, n_cart_if = 0;
+    const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
+    DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
+    double t_setup_ms = 0.0;
+};
+
+
+// Grid coordinate of a node (in spacings h from the origin lo), rounded to the nearest grid point.  The millionth of a spacing
+// added before the rounding settles the nodes that sit half-way between two grid points (a graded mesh measured in its mean
+// spacing has whole planes of them): without it the last bit of lo or h -- sums whose order differs between the builders --
+// would decide their box.
+#define FEM_PLAN_GRID(c, lo, h) llround(((c) - (lo)) / (h) + 1.0e-6)
+
+// limits of the builders (both build the same plan): elements of one tile (a set of owned nodes that touches more is halved)
+constexpr int PLAN_MAX_ELEMS = 2048;
+
+}  // namespace fem
+
+std::shared_ptr<fem::EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);          // dispatcher (ebe_tile.hip)
+std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s);     // host worker threads (cross-check: FEM_AMD_TILE_PLAN=host)
+std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s);   // ebe_plan.hip
+// geometry records of the stored-geometry tiles' elements (taff: class per lane slot), ebe_tile.hip
+void ebe_tile_store_geometry(fem_mesh m, fem::EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s);
+

@@ -21,6 +21,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <sched.h>
 
 #include <array>
@@ -28,6 +30,7 @@
 #include <thread>
 
 #include "comm.h"
+#include "ebe_tile.h"
 #include "hex8_ebe.h"
 #include "quad4_ebe.h"
 #include "objects.h"
@@ -35,33 +38,6 @@
 using namespace fem;
 
 namespace fem {
-
-constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
-constexpr int TILE_X_MAX_NODES = 1536, TILE_X_MAX_OWN = 768;   // tiles of the kernels with x in LDS (k_ebe_tile_x): 6 / 3 slots per thread
-constexpr int TILE_X_LDS_NODES = 1408;   // their LDS image, fixed (the component offsets become immediates of the LDS instructions):
-                                         // (1408 + 768) * 24 B = 51 KiB, three workgroups per CU; the 16 x 8 x 8-element tile has 1,377 nodes
-constexpr int TILE_MAX_NODES = 2900;     // nodes of a tile: 28 B of LDS each, two workgroups per CU (160 KiB); <= 12 * 256
-
-struct EbeTilePlan {
-    int ntiles = 0, n_aff = 0, n_gen = 0, max_nnode = 0, max_nsteps = 0, max_nown = 0;
-    long long tile_elements = 0;         // elements computed per product (rim elements counted once per tile)
-    long long slots = 0;                 // lanes of all steps (elements + the padding of 16-lane rows)
-    long long tile_nodes = 0;            // entries of all node lists
-    DBuf<int> hdr;                       // [ntiles*6] node_off, nown, nnode, elem_off, step_off, nsteps
-    DBuf<int2> steps;                    // rounds of <= 256 elements of one colour: {first (relative), count | barrier << 31}
-    DBuf<int> nodes;                     // global node ids of every tile, owned ones first
-    DBuf<int> elems;                     // [slots] global element id of every lane slot, colour by colour; -1 = padding
-    DBuf<uint4> conn16;                  // the same elements' eight tile-local node numbers (16 bit each)
-    DBuf<unsigned char> flags;           // [slots] bit 0: the element's +x face is the -x face of the next lane's element
-    DBuf<int> list_aff, list_gen;        // tiles whose elements are all parallelepipeds / the others; in both lists the tiles
-                                         // that own a node shared with another domain come first
-    int n_aff_if = 0, n_gen_if = 0;      // how many of each list those are
-    DBuf<int> list_cart;                 // tiles of axis-aligned bricks (a third list, same order rule); not in list_aff
-    int n_cart = 0, n_cart_if = 0;
-    const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
-    DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
-    double t_setup_ms = 0.0;
-};
 
 // What a lane needs of its coming elements is fetched ahead of the arithmetic (two waves per SIMD is all the LDS image of a
 // tile allows, so the latencies have to be covered inside the lane): the index chain -- local numbers, global ids from
@@ -747,9 +723,30 @@ void parallel_ranges(long long n, int nthreads, F f)   // f(thread, first, last)
 
 }  // namespace
 
-// Builds the plan (host, a few worker threads; once per mesh).  Returns nullptr when the mesh is not one group of hex8
-// elements or a tile would not fit (nodes, colours): the caller keeps the two-kernel product.
+// geometry records of the elements of the stored-geometry tiles (taff: 0 / 1 / 2 per lane slot), written once per mesh
+void ebe_tile_store_geometry(fem_mesh m, EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s)
+{
+    auto& grp = m->groups[0];
+    P.geo.alloc((size_t)P.slots * (P.n_aff ? 11 : 5));   // (axis-aligned bricks alone: the diagonal of adj(J) and the two factors)
+    const ElemTable& tab = host_elem_tables()[FEM_HEX];   // (only hex8 tiles are ever in those lists)
+    hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((P.slots + 255) / 256)), dim3(256), 0, s, (size_t)P.slots, P.elems.p, d_taff,
+                       grp.conn.p, m->coords.p, grp.E.p, grp.nu.p, tab.w[0], P.geo.p);
+    FEM_HIP(hipGetLastError());
+}
+
+// Builds the plan.  Returns nullptr when the mesh is not one group of hex8 (or quad4) elements or a tile would not fit
+// (nodes, colours): the caller keeps the two-kernel product.  The plan is built on the device (ebe_plan.hip: no copy of the
+// mesh to the host, a few milliseconds at config 3); FEM_AMD_TILE_PLAN=host selects the host builder below, which produces
+// the same plan with worker threads (hundreds of milliseconds) and is kept as the cross-check of the device one.
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
+{
+    const char* how = std::getenv("FEM_AMD_TILE_PLAN");
+    if (how && std::string(how) == "host") return ebe_tile_build_host(m, s);
+    return ebe_tile_build_device(m, s);
+}
+
+// The host builder (worker threads over contiguous ranges of boxes; the mesh is copied to the host first).
+std::shared_ptr<EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s)
 {
     if (m->groups.size() != 1 || !m->pattern) return nullptr;
     const bool hex = m->groups[0].type == FEM_HEX && m->pdim == 3;
@@ -915,7 +912,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
     auto box_of = [&](long long v) {
         long long b[3] = {0, 0, 0};
         for (int d = 0; d < pd; d++) {
-            long long i = std::llround((xyz[(size_t)v * pd + d] - lo[d]) / h[d]);
+            long long i = FEM_PLAN_GRID(xyz[(size_t)v * pd + d], lo[d], h[d]);
             b[d] = std::min(std::max(i / NB[d], 0LL), nbox[d] - 1);
         }
         return b[0] + nbox[0] * (b[1] + nbox[1] * b[2]);
@@ -973,32 +970,28 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             todo.pop_back();
             const bool force = todo_force.back();
             todo_force.pop_back();
-            // halves of a set of owned nodes, across its longest extent and along a plane of the node grid where there is one
-            // (the later half is pushed first: tiles stay in box order)
-            auto split_own = [&] {
+            // halves of a set of owned nodes: across its longest extent (in grid spacings), at the middle of that extent moved
+            // down by a millionth of a spacing -- the middle of a symmetric set is a plane of nodes, whose (lattice) coordinates
+            // differ in the last bits -- so that a plane of the node grid stays in one half.  Any partition of the owned nodes is
+            // a valid plan; this one needs a minimum, a maximum and one comparison per node (ebe_plan.hip does the same on the
+            // device).  The later half is pushed first: tiles stay in box order.  false: the nodes (all but) coincide.
+            auto split_own = [&]() -> bool {
                 double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
                 for (int v : own)
                     for (int d = 0; d < pd; d++) { mn[d] = std::min(mn[d], xyz[(size_t)v * pd + d]); mx[d] = std::max(mx[d], xyz[(size_t)v * pd + d]); }
                 int dl = 0;
                 for (int d = 1; d < pd; d++)
                     if ((mx[d] - mn[d]) / h[d] > (mx[dl] - mn[dl]) / h[dl]) dl = d;
-                std::vector<int> byc(own);
-                auto before = [&](int a, int c) {
-                    const double xa = xyz[(size_t)a * pd + dl], xc = xyz[(size_t)c * pd + dl];
-                    return xa < xc || (xa == xc && a < c);
-                };
-                std::nth_element(byc.begin(), byc.begin() + byc.size() / 2, byc.end(), before);
-                const double cut = xyz[(size_t)byc[byc.size() / 2] * pd + dl] - 0.25 * h[dl];   // below the median node's grid plane
+                const double eps = 1e-6 * h[dl];
+                if (!(mx[dl] - mn[dl] > 2.0 * eps)) return false;
+                const double cut = 0.5 * (mn[dl] + mx[dl]) - eps;
                 std::vector<int> lo_half, hi_half;
                 for (int v : own) (xyz[(size_t)v * pd + dl] < cut ? lo_half : hi_half).push_back(v);
-                if (lo_half.empty() || hi_half.empty()) {   // no plane to cut along: by rank
-                    lo_half.assign(byc.begin(), byc.begin() + byc.size() / 2); hi_half.assign(byc.begin() + byc.size() / 2, byc.end());
-                    std::sort(lo_half.begin(), lo_half.end()); std::sort(hi_half.begin(), hi_half.end());
-                }
                 todo.push_back(std::move(hi_half)); todo_force.push_back(0);
                 todo.push_back(std::move(lo_half)); todo_force.push_back(0);
+                return true;
             };
-            if (force && own.size() >= 2) { split_own(); continue; }
+            if (force && own.size() >= 2 && split_own()) continue;
             const int t = o.ntiles++;
             // the elements that touch an owned node, then the tile's nodes: owned ones first, the others of those elements
             // behind them, each part ascending -- tile-sized tables only, nothing of the size of the mesh
@@ -1006,6 +999,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
             el.clear();
             const int nown = (int)own.size();
             bool huge = nown > 16000;   // (a box of a mesh the grid fits badly: split before the tables fill up)
+            const size_t max_elems = (size_t)PLAN_MAX_ELEMS;   // (the device builder sorts a tile's elements in LDS)
             for (int k = 0; k < nown && !huge; k++) {
                 const int v = own[k];
                 for (int q = nptr[v]; q < nptr[v + 1]; q++) {
@@ -1014,7 +1008,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                     emap.slot(e, fresh);
                     if (fresh) el.push_back(e);
                 }
-                huge = el.size() > 16000;
+                huge = el.size() > max_elems;
             }
             // the tile's elements in the order of the grid (z, y, x of their first node, in the box coordinates), whatever the
             // numbering of the mesh: x-neighbours become consecutive, so the chains and a handful of colours are found on a
@@ -1024,7 +1018,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 const size_t v = (size_t)conn[(size_t)el[i] * npe];
                 unsigned long long k = 0;
                 for (int d = pd - 1; d >= 0; d--) {
-                    const long long gcoord = std::llround((xyz[v * pd + d] - lo[d]) / h[d]) + 4;
+                    const long long gcoord = FEM_PLAN_GRID(xyz[v * pd + d], lo[d], h[d]) + 4;
                     k = (k << 21) | (unsigned long long)(std::min(std::max(gcoord, 0LL), (1LL << 21) - 1));
                 }
                 ekey[i] = {k, el[i]};
@@ -1050,7 +1044,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
                 // of owned nodes and try again
                 if (nown < 2) { o.why = "tile with too many nodes"; o.why_a = (long long)nd.size(); o.why_b = nown; return; }
                 o.ntiles--;
-                split_own();
+                if (!split_own()) { o.why = "coincident nodes"; o.why_a = nown; return; }
                 continue;
             }
             lconn.resize(el.size() * (size_t)npe);
@@ -1193,13 +1187,8 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
         piece(plan->conn16.p, o.tconn, eoff[i]); piece(plan->flags.p, o.tflags, eoff[i]); piece(d_taff.p, o.taff, eoff[i]);
     }
     FEM_HIP(hipStreamSynchronize(s));
-    if (!laff.empty() || !lcart.empty()) {   // geometry records of the affine / Cartesian tiles' elements
-        plan->geo.alloc(eoff[NT] * 11);
-        const ElemTable& tab = host_elem_tables()[FEM_HEX];   // (only hex8 tiles are ever in this list)
-        hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((eoff[NT] + 255) / 256)), dim3(256), 0, s, eoff[NT], plan->elems.p,
-                           d_taff.p, grp.conn.p, m->coords.p, grp.E.p, grp.nu.p, tab.w[0], plan->geo.p);
-        FEM_HIP(hipStreamSynchronize(s));
-    }
+    if (!laff.empty() || !lcart.empty()) ebe_tile_store_geometry(m, *plan, d_taff.p, s);
+    FEM_HIP(hipStreamSynchronize(s));   // (d_taff goes out of scope)
     plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (verbose)
         std::fprintf(stderr, "[fem_amd] ebe tiles: %d (%d affine, %d Cartesian), <= %d nodes, %lld element visits in %lld lane slots for %d elements, %zu steps, set-up %.0f ms (%d threads)\n",
@@ -1313,3 +1302,73 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
     return true;
 }
 bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P) { return P.halo_seen == (const void*)A->mesh->halo.get(); }
+
+// fem_mesh_tile_plan_digest: the plan built afresh by the named builder, hashed array by array (cross-check of the builders)
+void mesh_tile_plan_digest_impl(fem_mesh m, const char* builder, unsigned long long* digest, double* setup_ms)
+{
+    m->ctx->bind();
+    hipStream_t s = m->ctx->stream;
+    FEM_CHECK(m->pattern, 5, "fem_mesh_tile_plan_digest: no Mat was created from this mesh yet (the symbolic phase supplies the node lists)");
+    const std::string b = builder;
+    FEM_CHECK(b == "device" || b == "host", 6, "fem_mesh_tile_plan_digest: builder must be device|host");
+    std::shared_ptr<EbeTilePlan> P = b == "host" ? ebe_tile_build_host(m, s) : ebe_tile_build_device(m, s);
+    for (int i = 0; i < 12; i++) digest[i] = 0;
+    if (setup_ms) *setup_ms = P ? P->t_setup_ms : 0.0;
+    if (!P) return;
+    auto fnv = [&](const void* dptr, size_t bytes, unsigned long long h = 1469598103934665603ULL) {
+        std::vector<unsigned char> buf(bytes);
+        if (bytes) FEM_HIP(hipMemcpy(buf.data(), dptr, bytes, hipMemcpyDeviceToHost));
+        for (unsigned char c : buf) { h ^= c; h *= 1099511628211ULL; }
+        return h;
+    };
+    FEM_HIP(hipStreamSynchronize(s));
+    digest[0] = (unsigned long long)P->ntiles; digest[1] = (unsigned long long)P->slots;
+    digest[2] = (unsigned long long)P->tile_nodes; digest[3] = (unsigned long long)P->tile_elements;
+    digest[4] = fnv(P->hdr.p, (size_t)P->ntiles * 6 * sizeof(int));
+    // (the number of steps is the sum of the headers' sixth entries: take it from there)
+    std::vector<int> hdr((size_t)P->ntiles * 6);
+    if (P->ntiles) FEM_HIP(hipMemcpy(hdr.data(), P->hdr.p, hdr.size() * sizeof(int), hipMemcpyDeviceToHost));
+    size_t nsteps = 0;
+    for (int t = 0; t < P->ntiles; t++) nsteps += (size_t)hdr[(size_t)6 * t + 5];
+    digest[5] = fnv(P->steps.p, nsteps * sizeof(int2));
+    digest[6] = fnv(P->nodes.p, (size_t)P->tile_nodes * sizeof(int));
+    digest[7] = fnv(P->elems.p, (size_t)P->slots * sizeof(int));
+    digest[8] = fnv(P->conn16.p, (size_t)P->slots * sizeof(uint4));
+    digest[9] = fnv(P->flags.p, (size_t)P->slots);
+    const int counts[9] = {P->n_cart, P->n_cart_if, P->n_aff, P->n_aff_if, P->n_gen, P->n_gen_if, P->max_nnode, P->max_nsteps, P->max_nown};
+    unsigned long long h = 1469598103934665603ULL;
+    for (int c : counts) { h ^= (unsigned long long)(unsigned)c; h *= 1099511628211ULL; }
+    h = fnv(P->list_cart.p, (size_t)P->n_cart * sizeof(int), h);
+    h = fnv(P->list_aff.p, (size_t)P->n_aff * sizeof(int), h);
+    digest[10] = fnv(P->list_gen.p, (size_t)P->n_gen * sizeof(int), h);
+    // stored geometry: only the entries of real elements in stored-geometry tiles are ever written
+    if (P->geo.p && (P->n_aff || P->n_cart)) {
+        std::vector<double> geo((size_t)P->slots * (P->n_aff ? 11 : 5));
+        std::vector<int> el((size_t)P->slots);
+        FEM_HIP(hipMemcpy(geo.data(), P->geo.p, geo.size() * sizeof(double), hipMemcpyDeviceToHost));
+        FEM_HIP(hipMemcpy(el.data(), P->elems.p, el.size() * sizeof(int), hipMemcpyDeviceToHost));
+        std::vector<int> lists;
+        std::vector<unsigned char> cls((size_t)P->ntiles, 0);
+        auto mark = [&](const DBuf<int>& l, int n, unsigned char c) {
+            std::vector<int> hl((size_t)n);
+            if (n) FEM_HIP(hipMemcpy(hl.data(), l.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+            for (int t : hl) cls[(size_t)t] = c;
+        };
+        mark(P->list_aff, P->n_aff, 1); mark(P->list_cart, P->n_cart, 2);
+        unsigned long long g = 1469598103934665603ULL;
+        for (int t = 0; t < P->ntiles; t++) {
+            if (!cls[(size_t)t]) continue;
+            const int e0 = hdr[(size_t)6 * t + 3], e1 = (t + 1 < P->ntiles) ? hdr[(size_t)6 * (t + 1) + 3] : (int)P->slots;
+            const int ng = cls[(size_t)t] == 2 ? 5 : 11;
+            for (int k = e0; k < e1; k++) {
+                if (el[(size_t)k] < 0) continue;
+                for (int j = 0; j < ng; j++) {
+                    unsigned long long bits;
+                    std::memcpy(&bits, &geo[(size_t)j * (size_t)P->slots + (size_t)k], 8);
+                    g ^= bits; g *= 1099511628211ULL;
+                }
+            }
+        }
+        digest[11] = g;
+    }
+}

@@ -372,6 +372,14 @@ module fem_amd_capi
       real(c_double), intent(out) :: setup_ms
       integer(c_int) :: ierr
     end function
+    function fem_mesh_tile_plan_digest(mesh, builder, digest, setup_ms) bind(C, name="fem_mesh_tile_plan_digest") result(ierr)
+      import :: c_int, c_ptr, c_double, c_long_long, c_char
+      type(c_ptr), value :: mesh
+      character(kind=c_char), intent(in) :: builder(*)
+      integer(c_long_long), intent(out) :: digest(12)
+      real(c_double), intent(out) :: setup_ms
+      integer(c_int) :: ierr
+    end function
     function fem_mat_get_diagonal(mat, d) bind(C, name="fem_mat_get_diagonal") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: mat, d

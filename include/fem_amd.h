@@ -188,6 +188,13 @@ int fem_mat_get_profile(fem_mat mat, int max_products, int *n, double *element_m
  * node lists, host set-up time). */
 int fem_mat_get_mult_info(fem_mat mat, int *kind, long long *tiles, long long *affine_tiles, long long *element_visits,
                           long long *lane_slots, long long *tile_nodes, double *setup_ms);
+/* Cross-check of the tile plan behind `-mat_mult_type ebe` (hex8 / quad4 meshes): builds the plan afresh with the named
+ * builder -- "device" (the one the product uses: integer kernels, nothing leaves HBM) or "host" (worker threads over a host
+ * copy of the mesh, kept as the check) -- without caching it, and returns a digest of every array: [0] tiles, [1] lane
+ * slots, [2] node-list entries, [3] element visits, [4..11] FNV-1a of hdr, steps, nodes, elems, conn16, flags, the three
+ * tile lists, the stored geometry.  A Mat must have been created from the mesh (its symbolic phase supplies the node ->
+ * element lists).  digest[0] = 0 when the mesh gets no tile plan (other element types, more than 16 colours). */
+int fem_mesh_tile_plan_digest(fem_mesh mesh, const char *builder, unsigned long long digest[12], double *setup_ms);
 /* MatMult: y = K x (sub-assembled product + halo sum when a halo is attached). */
 int fem_mat_mult(fem_mat mat, fem_vec x, fem_vec y);
 int fem_mat_get_diagonal(fem_mat mat, fem_vec d);

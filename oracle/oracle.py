@@ -314,19 +314,22 @@ class Oracle:
         return J, R
 
     # ---- bench.py's cpu_baseline leg (oracle/cpu_baseline.c) ----
-    def cpu_baseline(self, m, nthreads, ncg, rtol=DEFAULT_RTOL, nprod=0, want_arrays=False):
-        """Timed all-core run of the path; returns a dict of timings (and the matrix / iterate when asked)."""
+    def cpu_baseline(self, m, nthreads, ncg, rtol=DEFAULT_RTOL, nprod=0, want_arrays=False, want_x=False):
+        """Timed all-core run of the path; returns a dict of timings (and the matrix / iterate when asked; want_x: the
+        iterate alone -- the full-size parity tests, where a second copy of the 10 GB matrix would be wasted)."""
         p, keep = make_problem(m)
         t = np.zeros(6); info = np.zeros(3, dtype=np.int64)
         N = p.nnds * p.pdim
         x = rp = ci = val = None
+        if want_x and not want_arrays:
+            x = np.zeros(N)
         if want_arrays:
             nnz = len(self.csr_pattern(m)[1])
             x = np.zeros(N); rp = np.zeros(N + 1, dtype=np.int32); ci = np.zeros(nnz, dtype=np.int32); val = np.zeros(nnz)
         self.L.dm_cpu_baseline.restype = C.c_int
         rc = self.L.dm_cpu_baseline(C.byref(p), int(nthreads), int(ncg), C.c_double(rtol), int(nprod), _d(t),
                                     info.ctypes.data_as(C.POINTER(C.c_longlong)),
-                                    _d(x) if want_arrays else None, _i(rp) if want_arrays else None,
+                                    _d(x) if (want_arrays or want_x) else None, _i(rp) if want_arrays else None,
                                     _i(ci) if want_arrays else None, _d(val) if want_arrays else None)
         if rc != 0:
             raise RuntimeError(f"dm_cpu_baseline failed: {rc}")
@@ -334,6 +337,8 @@ class Oracle:
                "t_spmv": t[5], "nnz": int(info[0]), "its": int(info[1]), "reason": int(info[2])}
         if want_arrays:
             out.update(x=x, rowptr=rp, colind=ci, val=val)
+        elif want_x:
+            out.update(x=x)
         return out
 
     def cpu_ebe_mult(self, m, x, nthreads=1):

@@ -161,7 +161,7 @@ def test_solve_and_stress_match_oracle(gpu_ctx, oracle, name):
     u, s, its = oracle.run(m, "cg", rtol=1e-13)
     assert res.reasons[-1] > 0
     assert np.abs(res.aggregate_u - u).max() <= 1e-10 * np.abs(u).max()
-    assert np.abs(res.aggregate_stress - s).max() <= 1e-9 * np.abs(s).max()
+    assert np.abs(res.aggregate_stress - s).max() <= 1e-10 * np.abs(s).max()
     # same algorithm, same semantics: iteration counts agree up to rounding noise
     assert abs(res.its[-1] - its[-1]) <= max(2, its[-1] // 50)
 
@@ -169,11 +169,11 @@ def test_solve_and_stress_match_oracle(gpu_ctx, oracle, name):
 @pytest.mark.parametrize("n,jitter", [(40, 0.0), (56, 0.2)])
 def test_medium_cube_solution_matches_oracle(gpu_ctx, oracle, n, jitter):
     """Config-3 setup at a size the oracle still solves in seconds (56^3 = 555k DOF): same CG
-    semantics on both sides, rtol 1e-13 -> displacements within 1e-10, nodal stress within 1e-9."""
+    semantics on both sides, rtol 1e-13 -> displacements within 1e-10, nodal stress within 1e-10."""
     m = structured_hex(n, jitter=jitter)
     res = driver.run(m, "-ksp_rtol 1e-13", ctx=gpu_ctx)
     u, s, its = oracle.run(m, "cg", rtol=1e-13, nthreads=8)
     assert res.reasons[-1] == 2
     assert np.abs(res.aggregate_u - u).max() <= 1e-10 * np.abs(u).max()
-    assert np.abs(res.aggregate_stress - s).max() <= 1e-9 * np.abs(s).max()
+    assert np.abs(res.aggregate_stress - s).max() <= 1e-10 * np.abs(s).max()
     assert abs(res.its[-1] - its[-1]) <= max(3, its[-1] // 50)

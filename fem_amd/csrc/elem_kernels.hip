@@ -991,7 +991,17 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
                                             "product (solid elements only) does not know: -mat_mult_type assembled");
     fem_mesh m = A->mesh;
     MatPattern& P = *A->pat;
-    if (ebe && !P.ebe_ready) {   // once per mesh: hand-over flags, workgroup classes, gather lists
+    // `ebe` on a mesh of hex8 (or of quad4) elements alone: the one-pass product by tiles (ebe_tile.hip); `ebe_gather` and
+    // every other mesh: element buffer + node gather.  FEM_AMD_EBE_TILE=0 keeps `ebe` on the latter as well (measurement).
+    static const bool tile_env = !(std::getenv("FEM_AMD_EBE_TILE") && std::atoi(std::getenv("FEM_AMD_EBE_TILE")) == 0);
+    if (t == "ebe" && tile_env && !P.ebe_tile_tried) {
+        P.ebe_tile = ebe_tile_build(m, s);
+        P.ebe_tile_tried = true;
+    }
+    A->ebe_use_tile = (t == "ebe") && tile_env && P.ebe_tile != nullptr;
+    // the two-kernel product (element buffer + node gather), where that is the one in use: once per mesh its hand-over flags,
+    // workgroup classes and gather lists
+    if (ebe && !A->ebe_use_tile && !P.ebe_ready) {
         FEM_CHECK(A->n2e_ptr.p && A->n2e.p, 5, "fem_mat_set_mult_type: matrix was not created from a mesh");
         P.ebe_plan.clear();
         P.ebe_plan.resize(m->groups.size());
@@ -1046,15 +1056,7 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
         FEM_HIP(hipStreamSynchronize(s));
         P.ebe_ready = true;
     }
-    // `ebe` on a mesh of hex8 (or of quad4) elements alone: the one-pass product by tiles (ebe_tile.hip); `ebe_gather` and
-    // every other mesh: element buffer + node gather.  FEM_AMD_EBE_TILE=0 keeps `ebe` on the latter as well (measurement).
-    static const bool tile_env = !(std::getenv("FEM_AMD_EBE_TILE") && std::atoi(std::getenv("FEM_AMD_EBE_TILE")) == 0);
-    if (t == "ebe" && tile_env && !P.ebe_tile_tried) {
-        P.ebe_tile = ebe_tile_build(m, s);
-        P.ebe_tile_tried = true;
-    }
-    A->ebe_use_tile = (t == "ebe") && tile_env && P.ebe_tile != nullptr;
-    if (ebe) A->ebe_grid = P.ebe_grid;
+    if (ebe) A->ebe_grid = A->ebe_use_tile ? 0 : P.ebe_grid;
     if (ebe && !A->ebe_use_tile && A->ebe_f.empty()) {   // this Mat's element-force buffers
         A->ebe_f.resize(m->groups.size());
         for (size_t g = 0; g < m->groups.size(); g++)

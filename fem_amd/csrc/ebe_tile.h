@@ -28,6 +28,7 @@ struct EbeTilePlan {
                                          // that own a node shared with another domain come first
     int n_aff_if = 0, n_gen_if = 0;      // how many of each list those are
     DBuf<int> list_cart;                 // tiles of axis-aligned bricks (a third list, same order rule); not in list_aff
+    DBuf<int> lhdr_cart, lhdr_aff, lhdr_gen;   // [n * 8] the listed tiles' hdr records + tile id, in list order (what the kernels read)
     int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
@@ -50,5 +51,6 @@ std::shared_ptr<fem::EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);    
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s);     // host worker threads (cross-check: FEM_AMD_TILE_PLAN=host)
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s);   // ebe_plan.hip
 // geometry records of the stored-geometry tiles' elements (taff: class per lane slot), ebe_tile.hip
+void ebe_tile_list_headers(fem::EbeTilePlan& P, hipStream_t s);   // lhdr_* from list_* and hdr (ebe_tile.hip)
 void ebe_tile_store_geometry(fem_mesh m, fem::EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s);
 

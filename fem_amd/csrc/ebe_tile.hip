@@ -144,6 +144,39 @@ __device__ __forceinline__ void tile_complete(double (&u)[8][N], unsigned fl)
         }
 }
 
+// End of a tile's workgroup: its p.Kp partial, and -- where the caller wants the sum (the CG) -- the workgroup that finishes
+// last adds all the tiles' partials in a fixed order (thread i: partials i, i + 256, ...; then the fixed tree of the waves), so
+// that no separate reduction kernel follows the product and the result does not depend on which workgroup that was.
+__device__ __forceinline__ void tile_finish(double dot, int t, double* sh, double* __restrict__ partial, unsigned* __restrict__ rcount,
+                                            int rtotal, double* __restrict__ red)
+{
+    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+    __syncthreads();
+    if (!rcount) {
+        if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        return;
+    }
+    // No fences (a release would write back this XCD's whole L2 -- the kernel's own y -- once per workgroup: measured 3x the
+    // kernel time): the partial is stored write-through (agent-scope store = sc1), the lane waits for it, then counts; the
+    // workgroup whose count came last reads every partial with agent-scope loads (sc1: past this CU's L1), nothing else.
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[t], (sh[0] + sh[1]) + (sh[2] + sh[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(rcount, 1u) == (unsigned)(rtotal - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double sum = 0.0;
+    for (int i = threadIdx.x; i < rtotal; i += 256) sum += __hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) { *red = (sh[0] + sh[1]) + (sh[2] + sh[3]); *rcount = 0u; }
+}
+
 // geometry records of the elements of the affine tiles (set-up): geo[j * stride + k], k = position in the tile lists
 __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __restrict__ telems, const unsigned char* __restrict__ taff,
                                                    const int* __restrict__ conn, const double* __restrict__ coords,
@@ -179,7 +212,7 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
 // OP 0: y = K x.  OP 1, 2: the nodal stress sums of RecoverNodalStress + src/main.F90:258-279 over the same tiles (x = the
 // displacements; y = component 0 / 3 of stress_node(nnds, 6), column-major; divided by the valence where one is given)
 template <int KIND, int OP = 0>   // 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal)
-__global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+__global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ lhdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
                                                      const unsigned char* __restrict__ tflags,
@@ -190,7 +223,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                                                      size_t geo_stride, double g, double w, int max_nnode,
                                                      double* __restrict__ y, double* __restrict__ partial,
                                                      const int* __restrict__ done, const double* __restrict__ valence,
-                                                     size_t nn)
+                                                     size_t nn, unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red)
 {
     if (done && *done) return;
     static_assert(OP == 0 || KIND == 0, "the stress passes read the coordinates");
@@ -200,9 +233,9 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     // workgroups b and b + 8 share an XCD (and its L2): neighbouring tiles, which read the same nodes, go to one XCD
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
     if (lb >= (unsigned)nlist) return;
-    const int t = list[lb];
-    const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
-    const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
+    // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     double* acc = lds;
     int* gl = reinterpret_cast<int*>(lds + 3 * (size_t)max_nnode);
     {   // node list -> LDS, sums zeroed (all loads of a lane in flight together: TILE_MAX_NODES <= 12 * 256)
@@ -336,10 +369,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         }
     }
     if constexpr (OP != 0) return;
-    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
 // Axis-aligned bricks with x of the tile in LDS.  On a mesh of bricks the plan uses small tiles (15 x 7 x 7 owned nodes: 1,024
@@ -352,14 +382,15 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 // that closes the previous colour and the next step's corner values are read ahead of it (x is read-only), so the adds run
 // under the next step's arithmetic; contributions to rim nodes are not added at all (their sums belong to other tiles).
 template <int KIND>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two)
-__global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+__global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist, const int* __restrict__ lhdr,
                                                        const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                        const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
                                                        const double* __restrict__ x, const int* __restrict__ bc_node,
                                                        const int* __restrict__ bc_dof, const double* __restrict__ bc_shift,
                                                        const double* __restrict__ geo, size_t geo_stride, double g, int max_nnode,
                                                        int max_nown, double* __restrict__ y, double* __restrict__ partial,
-                                                       const int* __restrict__ done)
+                                                       const int* __restrict__ done, unsigned* __restrict__ rcount, int rtotal,
+                                                       double* __restrict__ red)
 {
     if (done && *done) return;
     static_assert(KIND == 1 || KIND == 2, "stored geometry only");
@@ -369,9 +400,9 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     __shared__ double sh[4];
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // (XCD map as in k_ebe_tile)
     if (lb >= (unsigned)nlist) return;
-    const int t = list[lb];
-    const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
-    const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
+    // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
     double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
     double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
@@ -499,17 +530,14 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
             dot += xi * sum;
         }
     }
-    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
 // The tile product of a quad4 mesh (plane strain; config 2): the same plan in two dimensions -- 31 x 31 owned nodes per
 // tile, chains of 16 elements along x (two per element row, so the greedy pass needs four colours), LDS image 20 B per node
 // -- and the bilinear arithmetic of quad4_ebe.h.  At a million dofs the CG iteration is a handful of 10 microsecond
 // kernels: one kernel for the product instead of element forces + gather + a reduction of their partials.
-__global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __restrict__ list, const int* __restrict__ hdr,
+__global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __restrict__ lhdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
                                                      const unsigned char* __restrict__ tflags,
@@ -518,16 +546,17 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
                                                      const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
                                                      const double* __restrict__ bc_shift, double g, double w, int max_nnode,
                                                      double* __restrict__ y, double* __restrict__ partial,
-                                                     const int* __restrict__ done)
+                                                     const int* __restrict__ done, unsigned* __restrict__ rcount, int rtotal,
+                                                     double* __restrict__ red)
 {
     if (done && *done) return;
     extern __shared__ double lds[];
     __shared__ double sh[4];
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // XCD-wise, as k_ebe_tile
     if (lb >= (unsigned)nlist) return;
-    const int t = list[lb];
-    const int node_off = hdr[6 * t], nown = hdr[6 * t + 1], nnode = hdr[6 * t + 2], elem_off = hdr[6 * t + 3];
-    const int step_off = hdr[6 * t + 4], nsteps = hdr[6 * t + 5];
+    // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     double* acc = lds;
     int* gl = reinterpret_cast<int*>(lds + 2 * (size_t)max_nnode);
     {
@@ -629,10 +658,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) dot += __shfl_down(dot, o);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
-    __syncthreads();
-    if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
 // the parallelepiped test of hex_forces on the host (same tolerance)
@@ -722,6 +748,25 @@ void parallel_ranges(long long n, int nthreads, F f)   // f(thread, first, last)
 }
 
 }  // namespace
+
+// the tiles' records in the order of each list: [node_off, nown, nnode, elem_off, step_off, nsteps, tile, 0] per position
+__global__ void __launch_bounds__(256) k_tile_list_hdr(int n, const int* __restrict__ list, const int* __restrict__ hdr, int* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n) return;
+    const int t = list[i];
+    for (int j = 0; j < 6; j++) out[8 * i + j] = hdr[(size_t)6 * t + j];
+    out[8 * i + 6] = t; out[8 * i + 7] = 0;
+}
+void ebe_tile_list_headers(EbeTilePlan& P, hipStream_t s)
+{
+    auto go = [&](DBuf<int>& out, const DBuf<int>& list, int n) {
+        out.alloc((size_t)std::max(n, 1) * 8);
+        if (n) hipLaunchKernelGGL(k_tile_list_hdr, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, n, list.p, P.hdr.p, out.p);
+    };
+    go(P.lhdr_cart, P.list_cart, P.n_cart); go(P.lhdr_aff, P.list_aff, P.n_aff); go(P.lhdr_gen, P.list_gen, P.n_gen);
+    FEM_HIP(hipGetLastError());
+}
 
 // geometry records of the elements of the stored-geometry tiles (taff: 0 / 1 / 2 per lane slot), written once per mesh
 void ebe_tile_store_geometry(fem_mesh m, EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s)
@@ -1187,6 +1232,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s)
         piece(plan->conn16.p, o.tconn, eoff[i]); piece(plan->flags.p, o.tflags, eoff[i]); piece(d_taff.p, o.taff, eoff[i]);
     }
     FEM_HIP(hipStreamSynchronize(s));
+    ebe_tile_list_headers(*plan, s);
     if (!laff.empty() || !lcart.empty()) ebe_tile_store_geometry(m, *plan, d_taff.p, s);
     FEM_HIP(hipStreamSynchronize(s));   // (d_taff goes out of scope)
     plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1224,6 +1270,8 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     const ElemTable& tab = host_elem_tables()[grp.type];
     const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
     const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
+    // the caller wants the sum of the partials (A->red_out, set by the CG): the workgroup that finishes last delivers it
+    unsigned* rcount = A->red_out ? A->red_counter.p : nullptr;
     if (grp.type == FEM_QUA) {
         const size_t shq = (size_t)P.max_nnode * (2 * sizeof(double) + sizeof(int));
         static bool qattr = false;
@@ -1234,18 +1282,18 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         }
         const int n0 = phase == 1 ? P.n_gen_if : 0, n1 = phase == 0 ? P.n_gen_if : P.n_gen;
         if (n1 > n0)
-            hipLaunchKernelGGL(k_ebe_tile_q4, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shq, s, n1 - n0, P.list_gen.p + n0, P.hdr.p,
+            hipLaunchKernelGGL(k_ebe_tile_q4, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shq, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
                                P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn,
-                               A->bc_dof.p, A->bc_shift.p, g, w, P.max_nnode, y, part, done);
+                               A->bc_dof.p, A->bc_shift.p, g, w, P.max_nnode, y, part, done, rcount, P.ntiles, A->red_out);
         return;
     }
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
     hex_tile_kernel_attributes();
     auto go = [&](auto kern, int n, const int* list) {
         if (!n) return;
-        hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.elems.p,
+        hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.steps.p, P.nodes.p, P.elems.p,
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
-                           (size_t)P.slots, g, w, P.max_nnode, y, part, done, (const double*)nullptr, (size_t)0);
+                           (size_t)P.slots, g, w, P.max_nnode, y, part, done, (const double*)nullptr, (size_t)0, rcount, P.ntiles, A->red_out);
     };
     const int c0 = phase == 1 ? P.n_cart_if : 0, c1 = phase == 0 ? P.n_cart_if : P.n_cart;
     const int a0 = phase == 1 ? P.n_aff_if : 0, a1 = phase == 0 ? P.n_aff_if : P.n_aff;
@@ -1262,16 +1310,17 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         }
         auto gox = [&](auto kern, int n, const int* list) {
             if (!n) return;
-            hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.conn16.p, P.flags.p,
-                               x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done);
+            hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.steps.p, P.nodes.p, P.conn16.p, P.flags.p,
+                               x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done, rcount,
+                               P.ntiles, A->red_out);
         };
-        gox(k_ebe_tile_x<2>, c1 - c0, P.list_cart.p + c0);
-        gox(k_ebe_tile_x<1>, a1 - a0, P.list_aff.p + a0);
+        gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+        gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
     } else {
-        go(k_ebe_tile<2>, c1 - c0, P.list_cart.p + c0);
-        go(k_ebe_tile<1>, a1 - a0, P.list_aff.p + a0);
+        go(k_ebe_tile<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+        go(k_ebe_tile<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
     }
-    go(k_ebe_tile<0>, g1 - g0, P.list_gen.p + g0);
+    go(k_ebe_tile<0>, g1 - g0, P.lhdr_gen.p + 8 * (size_t)g0);
 }
 // stress_node(nnds, 6) of a hex8 mesh over the tiles of the product (RecoverNodalStress per element, the sum over the
 // elements of a node src/main.F90:258-268 in LDS, the division by the valence :277-279 on the way out): two passes of
@@ -1287,14 +1336,14 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
     hex_tile_kernel_attributes();
     auto go = [&](auto kern, int n, const int* list, double* out) {
         if (!n) return;
-        hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.hdr.p, P.steps.p, P.nodes.p, P.elems.p,
+        hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.steps.p, P.nodes.p, P.elems.p,
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, U, (const int*)nullptr, (const int*)nullptr,
                            (const double*)nullptr, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, out, (double*)nullptr,
-                           (const int*)nullptr, valence, nn);
+                           (const int*)nullptr, valence, nn, (unsigned*)nullptr, 0, (double*)nullptr);
     };
     for (int half = 0; half < 2; half++) {
         double* out = S + (size_t)(3 * half) * nn;
-        for (auto [n, list] : {std::pair<int, const int*>{P.n_cart, P.list_cart.p}, {P.n_aff, P.list_aff.p}, {P.n_gen, P.list_gen.p}}) {
+        for (auto [n, list] : {std::pair<int, const int*>{P.n_cart, P.lhdr_cart.p}, {P.n_aff, P.lhdr_aff.p}, {P.n_gen, P.lhdr_gen.p}}) {
             if (half == 0) go(k_ebe_tile<0, 1>, n, list, out);
             else go(k_ebe_tile<0, 2>, n, list, out);
         }

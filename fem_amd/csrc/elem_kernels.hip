@@ -1063,6 +1063,7 @@ void mat_set_mult_type_impl(fem_mat A, const char* type)
             A->ebe_f[g].alloc((size_t)m->groups[g].nel * m->groups[g].npe * m->pdim);
     }
     A->mult_ebe = ebe;
+    if (A->ebe_use_tile && !A->red_counter.p) { A->red_counter.alloc(1); A->red_counter.zero(s); }
     // the Krylov solver sums A->spmv_partial[0 .. spmv_grid): size it for the product in use
     A->spmv_grid = A->ebe_use_tile ? ebe_tile_partials(*P.ebe_tile) : ebe ? A->ebe_grid : (A->nslices + 3) / 4;
     A->spmv_partial.alloc((size_t)A->spmv_grid);

@@ -41,6 +41,7 @@ struct KspState {
     double dpi2[2];  // p.w of the last two iterations (ping-pong: see the field table below)
     double red[4];   // reduced scalars: [0] z.z  [1] z.r  [2] p.w
     int it, its, reason, done;
+    int stop;        // `done` as the x / r update saw it: what k_cg_update_p may end on (see there)
 };
 
 __device__ __forceinline__ double block_sum(double v, double* sh)
@@ -167,8 +168,10 @@ __global__ void __launch_bounds__(256) k_cg_init_ext(size_t n, const double* __r
 // from the same inputs (so all agree); workgroup 0 / thread 0 records the result
 // in the KspState.  Fields are arranged so that no field is both read and written
 // inside one kernel (except `done`, where every reader reaches the same verdict):
-//   k_cg_update_p  reads it, betaold, rnorm0, ttol      writes dp, rnorm0/ttol (it==0), its, b, beta, reason, done
+//   k_cg_update_p  reads it, betaold, rnorm0, ttol, a   writes dp, rnorm0/ttol (it==0), its, b, beta, reason, done
 //   k_cg_update_xr reads its, beta, dpi2[(i+1)&1]       writes a, betaold, dpi2[i&1], it, reason, done
+// x += a p of iteration i is applied by the k_cg_update_p that opens iteration i + 1 (or ends the solve): it reads p anyway,
+// so the x / r update does not have to (ten vector passes per iteration instead of eleven; same operations on x, same bits).
 // Scalars z.z, z.r (and p.w) arrive either as per-workgroup partials that each
 // workgroup sums in a fixed order, or already reduced in st->red (after k_reduce
 // and, multi-domain, the all-reduce).
@@ -180,9 +183,12 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
                                                      int npart, double rtol, double abstol, double dtol, int maxit,
                                                      double* __restrict__ hist, int hist_len,
                                                      const double* __restrict__ dinv, const double* __restrict__ r,
-                                                     double* __restrict__ p, const double* __restrict__ zext)
+                                                     double* __restrict__ p, const double* __restrict__ zext,
+                                                     double* __restrict__ x)
 {
-    if (st->done) return;
+    // (not st->done: this kernel's own verdict sets it while other workgroups are still starting, and every workgroup owes
+    // the last x += a p; `stop` is only ever written by the x / r update that follows)
+    if (st->stop) return;
     __shared__ double sh[4];
     double zz, zr;
     if (pzz) {
@@ -208,6 +214,7 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
         else if (i > 0 && zr * st->betaold < 0.0) reason = FEM_KSP_DIVERGED_INDEFINITE_PC;
     }
     const double b = (i == 0) ? 0.0 : zr / st->betaold;
+    const double aprev = st->a;   // alpha of the iteration just completed (x += a p is still owed; 0 before the first)
     if (writer) {
         st->dp = dp;
         if (hist && i < hist_len) hist[i] = dp;
@@ -216,22 +223,32 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
         if (reason) { st->reason = reason; st->done = 1; }
         else { st->b = b; st->beta = zr; }
     }
-    if (reason) return;
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t str = (size_t)gridDim.x * blockDim.x;
-    if (zext) { for (; q < n; q += str) p[q] = zext[q] + b * p[q]; }   // z = M^-1 r applied by a separate PC
-    else { for (; q < n; q += str) p[q] = dinv[q] * r[q] + b * p[q]; }
+    if (reason) {   // the solve ends here: the last iteration's x += a p
+        if (i > 0) for (; q < n; q += str) x[q] += aprev * p[q];
+        return;
+    }
+    if (i == 0) {   // (x = 0, p = 0)
+        if (zext) { for (; q < n; q += str) p[q] = zext[q]; }
+        else { for (; q < n; q += str) p[q] = dinv[q] * r[q]; }
+        return;
+    }
+    if (zext) { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = zext[q] + b * pq; } }   // z = M^-1 r applied by a separate PC
+    else { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = dinv[q] * r[q] + b * pq; } }
 }
 
-// alpha = beta / p.w, then x += a p ; r -= a w ; z = M^-1 r ; partials of z.z and z.r
+// alpha = beta / p.w, then r -= a w ; z = M^-1 r ; partials of z.z and z.r  (x += a p: see k_cg_update_p)
 __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState* __restrict__ st,
                                                       const double* __restrict__ ppw, int npart,
-                                                      const double* __restrict__ dinv, const double* __restrict__ p,
-                                                      const double* __restrict__ w, double* __restrict__ x,
+                                                      const double* __restrict__ dinv, const double* __restrict__ w,
                                                       double* __restrict__ r, const unsigned char* __restrict__ owned,
                                                       double* __restrict__ pzz, double* __restrict__ pzr)
 {
-    if (st->done) return;
+    if (st->done) {   // the solve ended in the k_cg_update_p before this kernel (or earlier): tell the ones that follow
+        if (blockIdx.x == 0 && threadIdx.x == 0) st->stop = 1;
+        return;
+    }
     __shared__ double sh[4];
     double dpi;
     if (ppw) {
@@ -245,7 +262,7 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState
     const double beta = st->beta;
     const double a = beta / dpi;
     if (writer) {
-        if (bad) { st->reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; st->done = 1; }
+        if (bad) { st->reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; st->done = 1; st->stop = 1; }
         else { st->a = a; st->betaold = beta; st->dpi2[i & 1] = dpi; st->it = i + 1; }
     }
     if (bad) return;
@@ -253,11 +270,10 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState
     const size_t str = (size_t)gridDim.x * blockDim.x;
     double zz = 0.0, zr = 0.0;
     if (!dinv) {   // external preconditioner: z and its dot products come from later kernels
-        for (; q < n; q += str) { x[q] += a * p[q]; r[q] -= a * w[q]; }
+        for (; q < n; q += str) r[q] -= a * w[q];
         return;
     }
     for (; q < n; q += str) {
-        x[q] += a * p[q];
         const double ri = r[q] - a * w[q];
         r[q] = ri;
         const double zi = dinv[q] * ri;
@@ -614,12 +630,19 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     reduce_zz_zr();
     // p.w partials of a large SpMV grid are summed by one small kernel first; small grids
     // (and z.z / z.r, at most 1024 partials) are summed inside the consuming kernel
-    const bool reduce_pw_first = comm || A->spmv_grid > 2048;
+    // FEM_AMD_SELF_REDUCE=1: the one-pass tile product adds its partials itself (its last workgroup) instead of the reduction
+    // kernel -- measured at config 3: the product grows by 6.8 us (every workgroup ends on a write-through store and an atomic)
+    // for the 5 us kernel it replaces, 0.2738 against 0.2679 ms per iteration: off by default
+    static const bool self_env = std::getenv("FEM_AMD_SELF_REDUCE") && std::atoi(std::getenv("FEM_AMD_SELF_REDUCE")) != 0;
+    const bool self_reduce = self_env && A->mult_ebe && A->ebe_use_tile;
+    A->red_out = self_reduce ? &st->red[2] : nullptr;
+    struct RedOutGuard { fem_mat A; ~RedOutGuard() { A->red_out = nullptr; } } red_guard{A};
+    const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > 2048;
     int queued = 0;   // iterations enqueued so far (the profile samples iteration j * period)
     auto one_iteration = [&] {
         hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
-                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr);
+                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr, x->d.p);
         const bool sample = k->profiling > 0 && (queued % k->profiling) == 0;
         queued++;
         if (sample) FEM_HIP(hipEventRecord(next_event(), s));
@@ -628,23 +651,23 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
             FEM_HIP(hipEventRecord(cx->ev_a, s));
             ebe_tile_phase(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done, 1);        // the rest
             if (sample) FEM_HIP(hipEventRecord(next_event(), s));
-            hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr,
-                               A->spmv_grid, &st->red[2], &st->done);
+            if (!self_reduce)
+                hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr,
+                                   A->spmv_grid, &st->red[2], &st->done);
             FEM_HIP(hipStreamWaitEvent(cs, cx->ev_a, 0));                             // second stream: halo sum of w
             halo_sum_on(A->mesh, k->w.p, pd, pd, 1, cs);
             FEM_HIP(hipEventRecord(cx->ev_c, cs));
             comm->allreduce_sum(&st->red[2], 1, s);                                   // p.Kp over the domains
             FEM_HIP(hipStreamWaitEvent(s, cx->ev_c, 0));
             hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, (const double*)nullptr, A->spmv_grid,
-                               mg ? (const double*)nullptr : k->dinv.p, k->p.p, k->w.p, x->d.p, k->r.p, owned, k->pzz.p,
-                               k->pzr.p);
+                               mg ? (const double*)nullptr : k->dinv.p, k->w.p, k->r.p, owned, k->pzz.p, k->pzr.p);
             if (mg) apply_pc_and_dots();
             reduce_zz_zr();
             return;
         }
         mat_mult_raw(A, k->p.p, k->w.p, A->spmv_partial.p, &st->done);
         if (sample) FEM_HIP(hipEventRecord(next_event(), s));
-        if (reduce_pw_first)
+        if (reduce_pw_first && !self_reduce)
             hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr,
                                A->spmv_grid, &st->red[2], &st->done);
         if (comm) {
@@ -654,8 +677,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
         }
         hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st,
                            reduce_pw_first ? nullptr : A->spmv_partial.p, A->spmv_grid,
-                           mg ? (const double*)nullptr : k->dinv.p, k->p.p, k->w.p, x->d.p, k->r.p, owned, k->pzz.p,
-                           k->pzr.p);
+                           mg ? (const double*)nullptr : k->dinv.p, k->w.p, k->r.p, owned, k->pzz.p, k->pzr.p);
         if (mg) apply_pc_and_dots();
         reduce_zz_zr();
     };

@@ -141,6 +141,10 @@ struct fem_mat_s {
     int ebe_grid = 0;
     bool sampling = false;                  // the product in flight is one the profile samples
     bool ebe_use_tile = false;              // `ebe`: one-pass tile product when the mesh allows it; `ebe_gather`: never
+    // the one-pass tile product can deliver the sum of its p.Kp partials itself (its last workgroup adds them): the Krylov
+    // solver points red_out at its scalar for the length of a solve
+    double* red_out = nullptr;
+    fem::DBuf<unsigned> red_counter;
     // penalty rows as INSERTed by ApplyKBC: dof index (or -1) and (value held here) - (assembled diagonal)
     fem::DBuf<int> bc_dof;
     fem::DBuf<double> bc_shift;

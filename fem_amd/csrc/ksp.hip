@@ -176,6 +176,36 @@ __global__ void __launch_bounds__(256) k_cg_init_ext(size_t n, const double* __r
 // workgroup sums in a fixed order, or already reduced in st->red (after k_reduce
 // and, multi-domain, the all-reduce).
 
+// What opens iteration i + 1 of KSPSolve_CG (i = iterations completed): KSPConvergedDefault on the preconditioned residual
+// norm sqrt(z.z), then beta = z.r and b = beta / beta_old.  Pure function of its arguments: every workgroup of a kernel
+// evaluates it from the same inputs.
+struct CgOpen { double dp, rnorm0, ttol, b; int reason, its; };
+__device__ __forceinline__ CgOpen cg_open_logic(int i, double zz, double zr, double betaold, double rnorm0_in, double ttol_in,
+                                                double rtol, double abstol, double dtol, int maxit)
+{
+    CgOpen o;
+    o.dp = sqrt(zz);
+    o.rnorm0 = (i == 0) ? o.dp : rnorm0_in;
+    o.ttol = (i == 0) ? fmax(rtol * o.dp, abstol) : ttol_in;
+    o.reason = 0;
+    if (isnan(o.dp) || isinf(o.dp)) o.reason = FEM_KSP_DIVERGED_NANORINF;
+    else if (o.dp <= o.ttol) o.reason = (o.dp < abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
+    else if (o.dp >= dtol * o.rnorm0) o.reason = FEM_KSP_DIVERGED_DTOL;
+    else if (i >= maxit) o.reason = FEM_KSP_DIVERGED_ITS;
+    o.its = -1;
+    if (!o.reason) {
+        o.its = i + 1;   // PETSc sets ksp->its = i+1 before the beta checks
+        if (zr == 0.0) o.reason = FEM_KSP_CONVERGED_ATOL;
+        else if (i > 0 && zr * betaold < 0.0) o.reason = FEM_KSP_DIVERGED_INDEFINITE_PC;
+    }
+    o.b = (i == 0) ? 0.0 : zr / betaold;
+    return o;
+}
+// z = M^-1 r and p = z + b p with one rounding each, written the same way in every kernel that forms them (the compiler is
+// free to contract a * b + c either way round; the kernels of one solve have to agree to the bit)
+__device__ __forceinline__ double cg_z(double dinv, double r) { return __dmul_rn(dinv, r); }
+__device__ __forceinline__ double cg_p(double z, double b, double p) { return __fma_rn(b, p, z); }
+
 // Convergence test (KSPConvergedDefault) + beta, then p = M^-1 r + b p.
 // `it` = iterations completed so far.
 __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restrict__ st,
@@ -199,27 +229,15 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
     } else { zz = st->red[0]; zr = st->red[1]; }
     const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
     const int i = st->it;
-    const double dp = sqrt(zz);
-    const double rnorm0 = (i == 0) ? dp : st->rnorm0;
-    const double ttol = (i == 0) ? fmax(rtol * dp, abstol) : st->ttol;
-    int reason = 0;
-    if (isnan(dp) || isinf(dp)) reason = FEM_KSP_DIVERGED_NANORINF;
-    else if (dp <= ttol) reason = (dp < abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
-    else if (dp >= dtol * rnorm0) reason = FEM_KSP_DIVERGED_DTOL;
-    else if (i >= maxit) reason = FEM_KSP_DIVERGED_ITS;
-    int its = -1;
-    if (!reason) {
-        its = i + 1;   // PETSc sets ksp->its = i+1 before the beta checks
-        if (zr == 0.0) reason = FEM_KSP_CONVERGED_ATOL;
-        else if (i > 0 && zr * st->betaold < 0.0) reason = FEM_KSP_DIVERGED_INDEFINITE_PC;
-    }
-    const double b = (i == 0) ? 0.0 : zr / st->betaold;
+    const CgOpen o = cg_open_logic(i, zz, zr, st->betaold, st->rnorm0, st->ttol, rtol, abstol, dtol, maxit);
+    const int reason = o.reason;
+    const double b = o.b;
     const double aprev = st->a;   // alpha of the iteration just completed (x += a p is still owed; 0 before the first)
     if (writer) {
-        st->dp = dp;
-        if (hist && i < hist_len) hist[i] = dp;
-        if (i == 0) { st->rnorm0 = rnorm0; st->ttol = ttol; }
-        if (its >= 0) st->its = its;
+        st->dp = o.dp;
+        if (hist && i < hist_len) hist[i] = o.dp;
+        if (i == 0) { st->rnorm0 = o.rnorm0; st->ttol = o.ttol; }
+        if (o.its >= 0) st->its = o.its;
         if (reason) { st->reason = reason; st->done = 1; }
         else { st->b = b; st->beta = zr; }
     }
@@ -231,11 +249,11 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
     }
     if (i == 0) {   // (x = 0, p = 0)
         if (zext) { for (; q < n; q += str) p[q] = zext[q]; }
-        else { for (; q < n; q += str) p[q] = dinv[q] * r[q]; }
+        else { for (; q < n; q += str) p[q] = cg_z(dinv[q], r[q]); }
         return;
     }
-    if (zext) { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = zext[q] + b * pq; } }   // z = M^-1 r applied by a separate PC
-    else { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = dinv[q] * r[q] + b * pq; } }
+    if (zext) { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = cg_p(zext[q], b, pq); } }   // z = M^-1 r applied by a separate PC
+    else { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = cg_p(cg_z(dinv[q], r[q]), b, pq); } }
 }
 
 // alpha = beta / p.w, then r -= a w ; z = M^-1 r ; partials of z.z and z.r  (x += a p: see k_cg_update_p)
@@ -276,7 +294,7 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState
     for (; q < n; q += str) {
         const double ri = r[q] - a * w[q];
         r[q] = ri;
-        const double zi = dinv[q] * ri;
+        const double zi = cg_z(dinv[q], ri);
         if (!owned || owned[q / pd]) { zz += zi * zi; zr += zi * ri; }
     }
     zz = block_sum(zz, sh);

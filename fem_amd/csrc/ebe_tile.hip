@@ -533,6 +533,180 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
+// Nodal stress of a mesh of parallelepipeds (KIND 2: axis-aligned bricks, 1: the others) in ONE pass over the small tiles (u of the tile and six sums per owned node in
+// LDS, 69 KB: two workgroups per CU).  On a parallelepiped the strains are (bi)linear along the element, i.e. inside the
+// trilinear space the N2^-1 extrapolation of RecoverNodalStress (src/m_global.F90:506-509) reproduces exactly: the value the
+// extrapolation gives at a node IS the strain of the trilinear displacement at that node, and along an element edge that
+// displacement is linear -- so the nodal strain is made of the differences of u along the three edges that meet at the node,
+// mapped to x by the stored adj(J) / det (axis-aligned bricks: divided by the edge lengths, 1 / h_i = a_i mw / (16 w mu) from the
+// stored diagonal and the Lame factor): no coordinate is read.  sigma = D eps (DMat, src/m_local.F90:204-228; Voigt order xx yy zz xy yz zx of BMat :160-168), summed
+// per node over the elements (src/main.F90:258-268) in LDS -- colour by colour, +x face values handed along the 16-lane rows
+// as in the product, so every sum has one writer and a fixed order -- and divided by the valence on the way out (:277-279).
+template <int KIND>
+__global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
+                                                          const int* __restrict__ tnodes, const int* __restrict__ telems,
+                                                          const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
+                                                          const double* __restrict__ U, const double* __restrict__ geo, size_t geo_stride,
+                                                          const double* __restrict__ Ev, const double* __restrict__ nuv, double w,
+                                                          double* __restrict__ S, const double* __restrict__ valence, size_t nn)
+{
+    constexpr int NPT = TILE_X_MAX_NODES / 256, NPO = TILE_X_MAX_OWN / 256;
+    constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
+    extern __shared__ double lds[];
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // (XCD map as in k_ebe_tile)
+    if (lb >= (unsigned)nlist) return;
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5];
+    double* xs = lds;              // xs[d * MN + i]: u of the tile's nodes
+    double* acc = lds + 3 * MN;    // acc[c * MO + i]: six stress sums of the owned nodes
+    int nv[NPT];
+    {
+        double xv[NPT][3];
+#pragma unroll
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const int i = threadIdx.x + 256 * j;
+#pragma unroll
+            for (int d = 0; d < 3; d++) xv[j][d] = (i < nnode) ? U[(size_t)nv[j] * 3 + d] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nnode) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) xs[d * MN + i] = xv[j][d];
+            }
+            if (i < nown) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[c * MO + i] = 0.0;
+            }
+        }
+    }
+    const int2 sv = ((int)(threadIdx.x & 63) < nsteps) ? steps[step_off + (threadIdx.x & 63)] : make_int2(0, 0);
+    constexpr int NA = KIND == 2 ? 3 : 9;   // stored adj(J): the diagonal / row by row
+    struct Slot { uint4 c16; unsigned fl; double a[NA], mw, E, nu; };
+    auto fetch = [&](Slot& q, int s) {
+        q.fl = 0;
+        if (s >= nsteps) return;
+        const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
+        if ((int)threadIdx.x >= cnt) return;
+        const size_t k = (size_t)elem_off + first + threadIdx.x;
+        q.c16 = tconn[k];
+        q.fl = tflags[k];
+        const int e = telems[k];
+#pragma unroll
+        for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + k];
+        q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + k];
+        q.E = (e >= 0) ? Ev[e] : 1.0; q.nu = (e >= 0) ? nuv[e] : 0.25;
+    };
+    auto read_u = [&](double (&u)[8][3], const Slot& q) {
+        const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int la = tile_loc(q.c16, c_tminus[i]);
+#pragma unroll
+            for (int d = 0; d < 3; d++) u[c_tminus[i]][d] = valid ? xs[d * MN + la] : 0.0;
+        }
+        if (valid && !linked) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int la = tile_loc(q.c16, c_tplus[i]);
+#pragma unroll
+                for (int d = 0; d < 3; d++) u[c_tplus[i]][d] = xs[d * MN + la];
+            }
+        }
+    };
+    Slot q0, q1;
+    fetch(q0, 0);
+    __syncthreads();
+    double u[8][3];
+    read_u(u, q0);
+    bool prev_bar = false;
+    for (int s = 0; s < nsteps; s++) {
+        const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
+        fetch(q1, s + 1);
+        const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
+        tile_complete<3>(u, q0.fl);
+        // differences of u along the four xi-, eta-, zeta-edges (node pairs in the order of their lower node: bottom CCW, top CCW)
+        constexpr int ex[4][2] = {{0, 1}, {3, 2}, {4, 5}, {7, 6}}, ey[4][2] = {{0, 3}, {1, 2}, {4, 7}, {5, 6}}, ez[4][2] = {{0, 4}, {1, 5}, {2, 6}, {3, 7}};
+        const DCoef D = dmat_coef(q0.E, q0.nu);
+        const double kinv = q0.mw / (16.0 * w * D.d44);          // 1 / (2 det J)
+        double sn[8][6];
+        {
+            double dx[4][3], dy[4][3], dz[4][3];   // differences of u_d along the edges (= 2 du_d / d xi_j at the edge's nodes)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    dx[k][d] = u[ex[k][1]][d] - u[ex[k][0]][d];
+                    dy[k][d] = u[ey[k][1]][d] - u[ey[k][0]][d];
+                    dz[k][d] = u[ez[k][1]][d] - u[ez[k][0]][d];
+                }
+            // node a sits on x-edge kx[a], y-edge ky[a], z-edge kz[a]
+            constexpr int kx[8] = {0, 0, 1, 1, 2, 2, 3, 3}, ky[8] = {0, 1, 1, 0, 2, 3, 3, 2}, kz[8] = {0, 1, 2, 3, 0, 1, 2, 3};
+            const double two_mu = 2.0 * D.d44;
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                double H[3][3];   // H[l][i] = du_l / dx_i = sum_j adj(J)[i][j] du_l/dxi_j / det
+#pragma unroll
+                for (int l = 0; l < 3; l++) {
+                    const double g0 = dx[kx[a]][l], g1 = dy[ky[a]][l], g2 = dz[kz[a]][l];
+                    if constexpr (KIND == 2) {
+                        H[l][0] = q0.a[0] * kinv * g0; H[l][1] = q0.a[1] * kinv * g1; H[l][2] = q0.a[2] * kinv * g2;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 3; i++) H[l][i] = kinv * (q0.a[3 * i] * g0 + q0.a[3 * i + 1] * g1 + q0.a[3 * i + 2] * g2);
+                    }
+                }
+                const double exx = H[0][0], eyy = H[1][1], ezz = H[2][2];
+                const double tr = D.d12 * ((exx + eyy) + ezz);
+                sn[a][0] = fma(two_mu, exx, tr); sn[a][1] = fma(two_mu, eyy, tr); sn[a][2] = fma(two_mu, ezz, tr);
+                sn[a][3] = D.d44 * (H[0][1] + H[1][0]);
+                sn[a][4] = D.d44 * (H[1][2] + H[2][1]);
+                sn[a][5] = D.d44 * (H[2][0] + H[0][2]);
+            }
+        }
+        {   // +x face values of a linked lane go to the next lane's -x face nodes
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const double pv = row_prev(sn[c_tplus[i]][c]);
+                    if (recv) sn[c_tminus[i]][c] += pv;
+                }
+        }
+        read_u(u, q1);
+        if (prev_bar) __syncthreads();
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                if (linked && (a == 1 || a == 2 || a == 5 || a == 6)) continue;   // handed over
+                const int la = tile_loc(q0.c16, a);
+                if (la >= nown) continue;     // a rim node: its sums belong to another tile
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    __hip_atomic_fetch_add(&acc[c * MO + la], sn[a][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        prev_bar = bar;
+        q0 = q1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPO; j++) {
+        const int i = threadIdx.x + 256 * j;
+        if (i >= nown) continue;
+        const double rv = valence ? valence[nv[j]] : 1.0;   // stress_node(i,:) / global_count_node (no solid element: 0)
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double sum = acc[c * MO + i];
+            S[(size_t)c * nn + nv[j]] = (valence && rv != 0.0) ? sum / rv : sum;
+        }
+    }
+}
+
 // The tile product of a quad4 mesh (plane strain; config 2): the same plan in two dimensions -- 31 x 31 owned nodes per
 // tile, chains of 16 elements along x (two per element row, so the greedy pass needs four colours), LDS image 20 B per node
 // -- and the bilinear arithmetic of quad4_ebe.h.  At a million dofs the CG iteration is a handful of 10 microsecond
@@ -1341,9 +1515,28 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
                            (const double*)nullptr, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, out, (double*)nullptr,
                            (const int*)nullptr, valence, nn, (unsigned*)nullptr, 0, (double*)nullptr);
     };
+    // tiles of parallelepipeds: one pass, from the stored geometry (FEM_AMD_STRESS_CART=0: the two passes below for them too)
+    static const bool cart_env = !(std::getenv("FEM_AMD_STRESS_CART") && std::atoi(std::getenv("FEM_AMD_STRESS_CART")) == 0);
+    const bool cart_one_pass = cart_env && (P.n_cart > 0 || P.n_aff > 0) && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_LDS_NODES &&
+                               P.max_nown <= TILE_X_MAX_OWN;
+    if (cart_one_pass) {
+        constexpr size_t shs = (size_t)(3 * TILE_X_LDS_NODES + 6 * TILE_X_MAX_OWN) * sizeof(double);
+        static bool sattr = false;
+        if (!sattr) {
+            for (const void* f : {reinterpret_cast<const void*>(k_tile_stress_cart<1>), reinterpret_cast<const void*>(k_tile_stress_cart<2>)})
+                FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs));
+            sattr = true;
+        }
+        if (P.n_cart)
+            hipLaunchKernelGGL(k_tile_stress_cart<2>, dim3((P.n_cart + 7) / 8 * 8), dim3(256), shs, s, P.n_cart, P.lhdr_cart.p, P.steps.p,
+                               P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U, P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);
+        if (P.n_aff)
+            hipLaunchKernelGGL(k_tile_stress_cart<1>, dim3((P.n_aff + 7) / 8 * 8), dim3(256), shs, s, P.n_aff, P.lhdr_aff.p, P.steps.p,
+                               P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U, P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);
+    }
     for (int half = 0; half < 2; half++) {
         double* out = S + (size_t)(3 * half) * nn;
-        for (auto [n, list] : {std::pair<int, const int*>{P.n_cart, P.lhdr_cart.p}, {P.n_aff, P.lhdr_aff.p}, {P.n_gen, P.lhdr_gen.p}}) {
+        for (auto [n, list] : {std::pair<int, const int*>{cart_one_pass ? 0 : P.n_cart, P.lhdr_cart.p}, {cart_one_pass ? 0 : P.n_aff, P.lhdr_aff.p}, {P.n_gen, P.lhdr_gen.p}}) {
             if (half == 0) go(k_ebe_tile<0, 1>, n, list, out);
             else go(k_ebe_tile<0, 2>, n, list, out);
         }

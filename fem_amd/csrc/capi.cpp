@@ -699,8 +699,20 @@ int fem_mat_copy(fem_mat src, fem_mat dst)
     FEM_HIP(hipMemcpyAsync(dst->val.p, src->values(), src->val.bytes(), hipMemcpyDeviceToDevice, src->ctx->stream));
     dst->lazy_zero = false;
     dst->unsymmetric = src->unsymmetric;
-    // the copy holds the same penalty rows; a later ApplyKBC on it starts from what it finds
-    dst->bc_saved = false;
+    // the copy holds the same penalty rows: with the values goes what ApplyKBC recorded about them (the constraint list, the
+    // assembled diagonal under it, the shift of the element-by-element product), so that a later ApplyKBC with another list
+    // restores the assembled diagonal and `-mat_mult_type ebe` on the copy keeps its penalty rows
+    hipStream_t s = src->ctx->stream;
+    auto dup = [&](auto& d, const auto& a) {
+        using T = std::remove_reference_t<decltype(*a.p)>;
+        if (!a.p || !a.n) { d.release(); return; }
+        if (d.n != a.n) d.alloc(a.n);
+        FEM_HIP(hipMemcpyAsync(d.p, a.p, a.n * sizeof(T), hipMemcpyDeviceToDevice, s));
+    };
+    dup(dst->bc_dof, src->bc_dof); dup(dst->bc_shift, src->bc_shift); dup(dst->bc_diag, src->bc_diag); dup(dst->bc_node, src->bc_node);
+    dst->h_bc = src->h_bc;
+    dst->nbc_dof = src->nbc_dof;
+    dst->bc_saved = src->bc_saved;
     FEM_CATCH
 }
 

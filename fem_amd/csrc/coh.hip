@@ -139,16 +139,17 @@ struct RelsNodes {
 // src/m_global.F90:200-203: ApplyNodalForce(Residual, ..., .true.)); STIFF = true: Jacobian += appliedStiff, 64
 // MatSetValue(ADD_VALUES) per element (:140-146).  getCohRels reads local_u(2(k-1)+i), k = 1..4 -- four fixed nodes of
 // the rank (rels_mode 0: `rn`, by default the first four), not the element's (src/m_elems.F90:697-704); rels_mode 1
-// hands it the element's own nodes.  fp64 atomics: a node may sit in several cohesive elements.
+// hands it the element's own nodes.  One launch per colour of the cohesive elements (no two elements of a colour share a
+// node: fem_mesh_set_cohesive): plain adds, the sums into a node in the fixed order of the colours -- bitwise reproducible.
 template <bool STIFF>
-__global__ void __launch_bounds__(128) k_coh_mesh(int ncoh, const int* __restrict__ conn, const double* __restrict__ props,
+__global__ void __launch_bounds__(128) k_coh_mesh(int first, int ncoh, const int* __restrict__ conn, const double* __restrict__ props,
                                                   const double* __restrict__ coords, const double* __restrict__ utot, double dt,
                                                   int rels_mode, RelsNodes rn, double* __restrict__ R,
                                                   const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                   const int* __restrict__ bcol, double* __restrict__ val)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ncoh) return;
+    const int e = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (e >= first + ncoh) return;
     const int* nd = conn + (size_t)e * 4;
     double ec[8], u[8], res[8], K[64];
     for (int a = 0; a < 4; a++) {
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(128) k_coh_mesh(int ncoh, const int* __restric
     coh_element(ec, u, props + (size_t)e * 6, dt, res, K, nullptr);
     if constexpr (!STIFF) {
         for (int j = 0; j < 4; j++)
-            for (int d = 0; d < 2; d++) unsafeAtomicAdd(R + (size_t)nd[j] * 2 + d, res[2 * j + d]);
+            for (int d = 0; d < 2; d++) R[(size_t)nd[j] * 2 + d] += res[2 * j + d];
     } else {
         for (int n1 = 0; n1 < 4; n1++) {
             const int row = nd[n1];
@@ -174,7 +175,7 @@ __global__ void __launch_bounds__(128) k_coh_mesh(int ncoh, const int* __restric
                 double* blk = val + (size_t)(o0 + lo) * 4 * 64 + lane;
                 for (int d1 = 0; d1 < 2; d1++)
                     for (int d2 = 0; d2 < 2; d2++)
-                        unsafeAtomicAdd(blk + (size_t)(d1 * 2 + d2) * 64, K[(n1 * 2 + d1) + 8 * (n2 * 2 + d2)]);
+                        blk[(size_t)(d1 * 2 + d2) * 64] += K[(n1 * 2 + d1) + 8 * (n2 * 2 + d2)];
             }
         }
     }
@@ -226,6 +227,33 @@ void mesh_set_cohesive_impl(fem_mesh m, const int* nlmat, int ncohmats, const do
         for (int q = 0; q < 6; q++) pr.push_back(props[(size_t)(nlmat[e] - 1) * 6 + q]);
     }
     m->ncoh = (int)(conn.size() / 4);
+    {   // colours: greedily, in the order of the deck, the lowest colour none of the element's nodes carries yet; the elements are
+        // then kept colour by colour (deck order inside a colour) and every colour is one launch of the element kernels
+        const int nc = m->ncoh;
+        std::vector<unsigned long long> used((size_t)m->nnds, 0ULL);
+        std::vector<int> col((size_t)nc, 0);
+        int ncol = 0;
+        for (int e = 0; e < nc; e++) {
+            unsigned long long u = 0;
+            for (int a = 0; a < 4; a++) u |= used[(size_t)conn[(size_t)4 * e + a]];
+            int c = 0;
+            while (c < 64 && ((u >> c) & 1ULL)) c++;
+            FEM_CHECK(c < 64, 3, "fem_mesh_set_cohesive: a node sits in more than 64 cohesive elements");
+            col[(size_t)e] = c; ncol = std::max(ncol, c + 1);
+            for (int a = 0; a < 4; a++) used[(size_t)conn[(size_t)4 * e + a]] |= 1ULL << c;
+        }
+        std::vector<int> conn2; std::vector<double> pr2;
+        m->coh_colour_ptr.assign(1, 0);
+        for (int c = 0; c < ncol; c++) {
+            for (int e = 0; e < nc; e++) {
+                if (col[(size_t)e] != c) continue;
+                conn2.insert(conn2.end(), conn.begin() + (size_t)4 * e, conn.begin() + (size_t)4 * e + 4);
+                pr2.insert(pr2.end(), pr.begin() + (size_t)6 * e, pr.begin() + (size_t)6 * e + 6);
+            }
+            m->coh_colour_ptr.push_back((int)(conn2.size() / 4));
+        }
+        conn.swap(conn2); pr.swap(pr2);
+    }
     m->h_coh_conn = conn;
     if (m->ncoh) {
         m->coh_conn.alloc(conn.size()); m->coh_conn.upload(conn.data(), conn.size(), s);
@@ -254,8 +282,12 @@ void mat_add_cohesive_impl(fem_mat J, const double* utot, double dt, int rels_mo
     J->ctx->bind();
     hipStream_t s = J->ctx->stream;
     const RelsNodes rn = rels_of(m, rels_mode, rels_nodes);
-    hipLaunchKernelGGL(k_coh_mesh<true>, dim3(cdiv((size_t)m->ncoh, 128)), dim3(128), 0, s, m->ncoh, m->coh_conn.p, m->coh_props.p,
-                       m->coords.p, utot, dt, rels_mode, rn, (double*)nullptr, J->rowlen.p, J->boff.p, J->bcol.p, J->values());
+    double* jval = J->values();
+    for (size_t c = 0; c + 1 < m->coh_colour_ptr.size(); c++) {
+        const int first = m->coh_colour_ptr[c], cnt = m->coh_colour_ptr[c + 1] - first;
+        hipLaunchKernelGGL(k_coh_mesh<true>, dim3(cdiv((size_t)cnt, 128)), dim3(128), 0, s, first, cnt, m->coh_conn.p, m->coh_props.p,
+                           m->coords.p, utot, dt, rels_mode, rn, (double*)nullptr, J->rowlen.p, J->boff.p, J->bcol.p, jval);
+    }
     J->unsymmetric = true;
     J->bc_saved = false;   // ApplyKBC comes next and sees a new diagonal
     FEM_HIP(hipGetLastError());
@@ -269,8 +301,11 @@ void vec_add_cohesive_traction_impl(fem_mesh m, const double* utot, double dt, i
     m->ctx->bind();
     hipStream_t s = m->ctx->stream;
     const RelsNodes rn = rels_of(m, rels_mode, rels_nodes);
-    hipLaunchKernelGGL(k_coh_mesh<false>, dim3(cdiv((size_t)m->ncoh, 128)), dim3(128), 0, s, m->ncoh, m->coh_conn.p, m->coh_props.p,
-                       m->coords.p, utot, dt, rels_mode, rn, R, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
-                       (double*)nullptr);
+    for (size_t c = 0; c + 1 < m->coh_colour_ptr.size(); c++) {
+        const int first = m->coh_colour_ptr[c], cnt = m->coh_colour_ptr[c + 1] - first;
+        hipLaunchKernelGGL(k_coh_mesh<false>, dim3(cdiv((size_t)cnt, 128)), dim3(128), 0, s, first, cnt, m->coh_conn.p, m->coh_props.p,
+                           m->coords.p, utot, dt, rels_mode, rn, R, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr,
+                           (double*)nullptr);
+    }
     FEM_HIP(hipGetLastError());
 }

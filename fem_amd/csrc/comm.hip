@@ -134,15 +134,19 @@ struct LocalComm : Comm {
         if (last) delete sh;
     }
     void allreduce_sum(double* dbuf, int n, hipStream_t s) override {
+        // (as in exchange below: a failing domain still arrives at both barriers and throws afterwards)
+        std::string err;
         std::vector<double>& mine = sh->slots[rank];
-        mine.resize(n);
-        FEM_HIP(hipMemcpyAsync(mine.data(), dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-        FEM_HIP(hipStreamSynchronize(s));
+        mine.assign((size_t)n, 0.0);
+        if (hipMemcpyAsync(mine.data(), dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess)
+            err = "local all-reduce: copy to the host failed";
         sh->barrier();
         std::vector<double> sum(n, 0.0);
         for (int r = 0; r < size; r++)
-            for (int k = 0; k < n; k++) sum[k] += sh->slots[r][k];
+            for (int k = 0; k < n && k < (int)sh->slots[r].size(); k++) sum[k] += sh->slots[r][k];
         sh->barrier();  // everybody has read before anybody overwrites its slot
+        FEM_CHECK(err.empty(), 62, err);
         FEM_HIP(hipMemcpyAsync(dbuf, sum.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
         FEM_HIP(hipStreamSynchronize(s));
     }

@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -90,6 +91,20 @@ struct DBuf {
 };
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// One-shot set-up that the HIP runtime keeps per device (a kernel's raised dynamic-LDS limit): first(dev) is true exactly once
+// per device, also when several domain threads of one process arrive together.
+struct OncePerDevice {
+    std::mutex mu;
+    unsigned long long done = 0;
+    bool first(int dev) {
+        std::lock_guard<std::mutex> lk(mu);
+        const unsigned long long bit = 1ULL << (dev & 63);
+        if (done & bit) return false;
+        done |= bit;
+        return true;
+    }
+};
 
 }  // namespace fem
 

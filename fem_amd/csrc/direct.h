@@ -50,7 +50,8 @@ struct BandLU {
     long long n = 0;
     int kl = 0;                 // half bandwidth in dofs after renumbering (kl = ku)
     int wb = 0;                 // stored row width: 3 kl + 1
-    bool failed = false;
+    bool failed = false;        // a NaN reached a pivot column
+    int null_pivots = 0;        // pivots below 1e-6 of the largest entry, fixed to zero
     DBuf<int> perm_dof;         // [n] new position of every dof
     DBuf<double> ab;            // [n*wb] row i holds columns i-kl .. i+2kl
     DBuf<int> ipiv;             // [n]

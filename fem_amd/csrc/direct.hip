@@ -546,8 +546,9 @@ __global__ void __launch_bounds__(256) k_band_lu(long long n, int kl, int wb, do
         }
         __syncthreads();
         const int p = s_p;
-        if (s_piv <= tiny) {   // null pivot: the unknown is fixed to zero (row and column dropped)
-            if (threadIdx.x == 0) { ipiv[k] = -1 - (int)k; atomicAdd(flag, 0); }
+        if (!(s_piv > tiny)) {   // null pivot (flag[0] counts them): the unknown is fixed to zero (row and column dropped);
+                                 // a NaN in the column (flag[1]) is treated the same way and reported as a failed factorisation
+            if (threadIdx.x == 0) { ipiv[k] = -1 - (int)k; atomicAdd(flag, 1); if (isnan(s_piv)) atomicExch(flag + 1, 1); }
             for (int r = threadIdx.x + 1; r <= km; r += 256) ab[(k + r) * wb + (kl - r)] = 0.0;
             for (int c = threadIdx.x + 1; c <= nc; c += 256) ab[k * wb + kl + c] = 0.0;
             if (threadIdx.x == 0) ab[k * wb + kl] = 1.0;
@@ -649,13 +650,16 @@ void BandLU::setup(fem_mat A_)
     else
         hipLaunchKernelGGL(k_bandfull_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
                            A->rowlen.p, dperm.p, kl, wb, ab.p);
-    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 1); flag.alloc(1);
+    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 1); flag.alloc(2);
     flag.zero(s);
     hipLaunchKernelGGL(k_band_amax, dim3(1), dim3(256), 0, s, (size_t)n * wb, ab.p, v0.p + n);
     hipLaunchKernelGGL(k_band_lu, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p + n, flag.p);
     FEM_HIP(hipGetLastError());
+    int hflag[2] = {0, 0};
+    flag.download(hflag, 2, s);
     FEM_HIP(hipStreamSynchronize(s));
-    failed = false;
+    null_pivots = hflag[0];      // (MUMPS ICNTL(24) = 1 fixes them the same way, src/main.F90:368)
+    failed = hflag[1] != 0;      // a NaN reached a pivot column: KSP_DIVERGED_PC_FAILED
 }
 
 void BandLU::solve(const double* b, double* x)

@@ -796,14 +796,11 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s)
         hipLaunchKernelGGL(k_plan_mark, dim3(cdiv((size_t)hl->ninodes, 256)), dim3(256), 0, s, hl->ninodes, hl->inodes.p, shared_node.p);
     }
     // 3. first pass: counts; sets that exceed a tile are halved until none is left
-    static bool attr_set[4] = {false, false, false, false};
-    auto set_attr = [&](int which, const void* f) {
-        if (attr_set[which]) return;
-        FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_tile_lds()));
-        attr_set[which] = true;
-    };
-    set_attr(0, reinterpret_cast<const void*>(k_plan_tile<true, false>)); set_attr(1, reinterpret_cast<const void*>(k_plan_tile<true, true>));
-    set_attr(2, reinterpret_cast<const void*>(k_plan_tile<false, false>)); set_attr(3, reinterpret_cast<const void*>(k_plan_tile<false, true>));
+    static OncePerDevice once;
+    if (once.first(m->ctx->device))
+        for (const void* f : {reinterpret_cast<const void*>(k_plan_tile<true, false>), reinterpret_cast<const void*>(k_plan_tile<true, true>),
+                              reinterpret_cast<const void*>(k_plan_tile<false, false>), reinterpret_cast<const void*>(k_plan_tile<false, true>)})
+            FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_tile_lds()));
     DBuf<PlanCounters> ctr(1);
     ctr.zero(s);
     DBuf<int> border_tmp;

@@ -1423,15 +1423,14 @@ void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_til
     *tiles = P.ntiles; *affine_tiles = P.n_aff + P.n_cart; *visits = P.tile_elements; *slots = P.slots; *nodes = P.tile_nodes; *ms = P.t_setup_ms;
 }
 
-static void hex_tile_kernel_attributes()
+static void hex_tile_kernel_attributes(int device)
 {
-    static bool attr_set = false;
-    if (attr_set) return;
+    static OncePerDevice once;
+    if (!once.first(device)) return;
     for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<0>), reinterpret_cast<const void*>(k_ebe_tile<1>),
                           reinterpret_cast<const void*>(k_ebe_tile<2>), reinterpret_cast<const void*>(k_ebe_tile<0, 1>),
                           reinterpret_cast<const void*>(k_ebe_tile<0, 2>)})
         FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
-    attr_set = true;
 }
 
 // y = K x, p.Kp partials into part[0 .. ntiles)
@@ -1448,12 +1447,10 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     unsigned* rcount = A->red_out ? A->red_counter.p : nullptr;
     if (grp.type == FEM_QUA) {
         const size_t shq = (size_t)P.max_nnode * (2 * sizeof(double) + sizeof(int));
-        static bool qattr = false;
-        if (!qattr) {
+        static OncePerDevice qonce;
+        if (qonce.first(A->ctx->device))
             FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_q4), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         TILE_MAX_NODES * 20));
-            qattr = true;
-        }
         const int n0 = phase == 1 ? P.n_gen_if : 0, n1 = phase == 0 ? P.n_gen_if : P.n_gen;
         if (n1 > n0)
             hipLaunchKernelGGL(k_ebe_tile_q4, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shq, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
@@ -1462,7 +1459,7 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         return;
     }
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
-    hex_tile_kernel_attributes();
+    hex_tile_kernel_attributes(m->ctx->device);
     auto go = [&](auto kern, int n, const int* list) {
         if (!n) return;
         hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.steps.p, P.nodes.p, P.elems.p,
@@ -1476,12 +1473,10 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     static const bool x_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
     constexpr size_t shx = (size_t)(TILE_X_LDS_NODES + TILE_X_MAX_OWN) * 3 * sizeof(double), shx_max = shx;
     if (x_env && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_LDS_NODES && P.max_nown <= TILE_X_MAX_OWN) {
-        static bool xattr = false;
-        if (!xattr) {
+        static OncePerDevice xonce;
+        if (xonce.first(A->ctx->device))
             for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
-            xattr = true;
-        }
         auto gox = [&](auto kern, int n, const int* list) {
             if (!n) return;
             hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.steps.p, P.nodes.p, P.conn16.p, P.flags.p,
@@ -1507,7 +1502,7 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
     const ElemTable& tab = host_elem_tables()[grp.type];
     const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int)), nn = (size_t)m->nnds;
-    hex_tile_kernel_attributes();
+    hex_tile_kernel_attributes(m->ctx->device);
     auto go = [&](auto kern, int n, const int* list, double* out) {
         if (!n) return;
         hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.steps.p, P.nodes.p, P.elems.p,
@@ -1521,12 +1516,10 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
                                P.max_nown <= TILE_X_MAX_OWN;
     if (cart_one_pass) {
         constexpr size_t shs = (size_t)(3 * TILE_X_LDS_NODES + 6 * TILE_X_MAX_OWN) * sizeof(double);
-        static bool sattr = false;
-        if (!sattr) {
+        static OncePerDevice sonce;
+        if (sonce.first(m->ctx->device))
             for (const void* f : {reinterpret_cast<const void*>(k_tile_stress_cart<1>), reinterpret_cast<const void*>(k_tile_stress_cart<2>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs));
-            sattr = true;
-        }
         if (P.n_cart)
             hipLaunchKernelGGL(k_tile_stress_cart<2>, dim3((P.n_cart + 7) / 8 * 8), dim3(256), shs, s, P.n_cart, P.lhdr_cart.p, P.steps.p,
                                P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U, P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);

@@ -325,9 +325,14 @@ __global__ void __launch_bounds__(256) k_bcgs_p(size_t n, double beta, double om
     const size_t st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) P[i] = R[i] + beta * (P[i] - omega * V[i]);
 }
-// w = y + a x
-__global__ void __launch_bounds__(256) k_waxpy(size_t n, double a, const double* __restrict__ x, const double* __restrict__ y,
-                                               double* __restrict__ w)
+__global__ void __launch_bounds__(256) k_scale(size_t n, double a, double* __restrict__ v)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t st = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += st) v[i] *= a;
+}
+// w = y + a x (w may be x or y: no __restrict__)
+__global__ void __launch_bounds__(256) k_waxpy(size_t n, double a, const double* x, const double* y, double* w)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t st = (size_t)gridDim.x * blockDim.x;
@@ -504,7 +509,8 @@ static void ksp_bcgs_solve(fem_ksp k, fem_vec b, fem_vec x)
     const size_t n = (size_t)k->n;
     const unsigned g = vgrid(n);
     double *R = k->bcgs_work.p, *RP = R + n, *V = RP + n, *T = V + n, *S = T + n, *P = S + n;
-    DBuf<double> part(g + 1);
+    if (k->pzz.n < (size_t)g + 1) k->pzz.alloc((size_t)VGRID + 1);   // (the partials of the dot products: the CG's buffer, kept by the KSP)
+    struct { double* p; } part{k->pzz.p};
     auto dot = [&](const double* a, const double* c) {
         hipLaunchKernelGGL(k_dot_partial, dim3(g), dim3(256), 0, s, a, c, n, 1, (const unsigned char*)nullptr, part.p);
         hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, part.p, (const double*)nullptr, (int)g, part.p + g,
@@ -540,9 +546,10 @@ static void ksp_bcgs_solve(fem_ksp k, fem_vec b, fem_vec x)
         mult(S, T);
         const double st_ = dot(S, T), tt = dot(T, T);
         it++;
-        if (tt == 0.0) {   // t = 0: s is the residual of x + alpha p
+        if (tt == 0.0) {   // t = 0 (bcgs.c): if s = 0 as well, alpha v = r and x + alpha p is the solution; otherwise a breakdown
+            if (dot(S, S) != 0.0) { reason = -5; break; }   // KSP_DIVERGED_BREAKDOWN
             hipLaunchKernelGGL(k_axpy, dim3(g), dim3(256), 0, s, x->d.p, alpha, P, n);
-            dp = std::sqrt(dot(S, S));
+            dp = 0.0;
             hist.push_back(dp);
             reason = FEM_KSP_CONVERGED_RTOL;
             break;
@@ -574,7 +581,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     if (k->direct_lu) {
         k->direct_lu->solve(b->d.p, x->d.p);
         FEM_HIP(hipStreamSynchronize(s));
-        k->its = 1; k->rnorm = 0.0; k->reason = 4;
+        k->its = 1; k->rnorm = 0.0; k->reason = k->direct_lu->failed ? -11 : 4;
         k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
         return;
     }
@@ -770,11 +777,10 @@ void vec_axpy(fem_vec y, double a, fem_vec x)
     hipLaunchKernelGGL(k_axpy, dim3(vgrid((size_t)y->n)), dim3(256), 0, y->ctx->stream, y->d.p, a, x->d.p, (size_t)y->n);
     FEM_HIP(hipGetLastError());
 }
-void vec_scale(fem_vec v, double a)
+void vec_scale(fem_vec v, double a)   // VecScale: v = a v, one rounding per entry
 {
     v->ctx->bind();
-    // y = a*y + 0: k_waxpy with x = y
-    hipLaunchKernelGGL(k_waxpy, dim3(vgrid((size_t)v->n)), dim3(256), 0, v->ctx->stream, (size_t)v->n, a - 1.0, v->d.p, v->d.p, v->d.p);
+    hipLaunchKernelGGL(k_scale, dim3(vgrid((size_t)v->n)), dim3(256), 0, v->ctx->stream, (size_t)v->n, a, v->d.p);
     FEM_HIP(hipGetLastError());
 }
 // w = y + a x (w may alias y or x)

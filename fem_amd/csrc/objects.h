@@ -56,6 +56,7 @@ struct fem_mesh_s {
     fem::DBuf<int> coh_conn;        // [ncoh*4]
     fem::DBuf<double> coh_props;    // [ncoh*6] the element's cohMats(nlMat) row
     std::vector<int> h_coh_conn;
+    std::vector<int> coh_colour_ptr;   // the cohesive elements are kept colour by colour (no shared node inside a colour): [ncolours + 1]
     std::shared_ptr<fem::MatPattern> pattern;   // symbolic phase result, built by the first fem_mat_create_aij
 };
 

@@ -228,3 +228,42 @@ def tile_deck(m: Mesh, copies: int, shift=None) -> Mesh:
                 fval=np.tile(m.fval, (copies, 1)), telsd=telsd, tval=np.tile(m.tval, (copies, 1)), t=m.t, dt=m.dt,
                 stype=m.stype, nodal_bw=m.nodal_bw, nlmat=None if m.nlmat is None else np.tile(m.nlmat, copies),
                 cohmats=m.cohmats)
+
+
+def tile_deck_connected(m: Mesh, copies: int) -> Mesh:
+    """`copies` copies of a 2-D deck side by side along x as ONE connected strip (BASELINE config 5 as SURVEY 8(d) words it:
+    examples/cohesive_test_2.inp "tiled x1000 along x"): the nodes on the right edge (x = max) of a copy are the nodes on
+    the left edge (x = min) of the next one, matched by their y in the order of their numbers (the deck's duplicated
+    interface nodes pair up in that order), so that the strip holds `copies` cohesive elements on one continuous interface.
+    Constraints and loads of every copy are kept (records that land on one node are merged by ApplyKBC as the reference's
+    sequential INSERT does)."""
+    assert m.pdim == 2
+    x = m.coords[:, 0]
+    ext = x.max() - x.min()
+    left = np.nonzero(x == x.min())[0]
+    right = np.nonzero(x == x.max())[0]
+    left = left[np.lexsort((left, m.coords[left, 1]))]
+    right = right[np.lexsort((right, m.coords[right, 1]))]
+    assert len(left) == len(right) and np.array_equal(m.coords[left, 1], m.coords[right, 1]), "edges of the deck do not match"
+    nn = m.nnds
+    inner = np.setdiff1d(np.arange(nn), left)               # nodes a later copy adds (its left edge is the previous right edge)
+    newid = np.empty((copies, nn), dtype=np.int64)
+    newid[0] = np.arange(nn)
+    coords = [m.coords]
+    for c in range(1, copies):
+        base = nn + (c - 1) * len(inner)
+        newid[c, inner] = base + np.arange(len(inner))
+        newid[c, left] = newid[c - 1, right]
+        coords.append(m.coords[inner] + np.array([c * ext, 0.0]))
+    conn = np.concatenate([newid[c][m.conn] for c in range(copies)]).astype(np.int32)
+    eptr = np.concatenate([[0]] + [m.eptr[1:] + c * m.eptr[-1] for c in range(copies)])
+    bcnode = m.bcnode
+    if len(m.bcnode):
+        bcnode = np.concatenate([np.column_stack([newid[c][m.bcnode[:, 0]], m.bcnode[:, 1:]]) for c in range(copies)]).astype(np.int32)
+    telsd = np.concatenate([m.telsd + np.array([c * m.nels, 0]) for c in range(copies)]) if len(m.telsd) else m.telsd
+    return Mesh(pdim=m.pdim, eltype=np.tile(m.eltype, copies), eptr=eptr, conn=conn, mat_id=np.tile(m.mat_id, copies),
+                coords=np.ascontiguousarray(np.concatenate(coords)), mats=m.mats, bcnode=bcnode, bcval=np.tile(m.bcval, (copies, 1)),
+                fnode=np.concatenate([newid[c][m.fnode] for c in range(copies)]).astype(np.int32) if len(m.fnode) else m.fnode,
+                fval=np.tile(m.fval, (copies, 1)), telsd=telsd, tval=np.tile(m.tval, (copies, 1)), t=m.t, dt=m.dt,
+                stype=m.stype, nodal_bw=m.nodal_bw, nlmat=None if m.nlmat is None else np.tile(m.nlmat, copies),
+                cohmats=m.cohmats)

@@ -124,3 +124,29 @@ def test_config5_tiling(gpu_ctx, oracle):
     # gives on a direction made of round-off differs between the two factorizations; the increments do not)
     assert a.snes_its[0] == b["its"][0] == 1 and a.snes_reasons[0] == b["reasons"][0] == 3 and min(a.snes_reasons) > 0
     assert np.abs(a.aggregate_u - b["u"]).max() <= 1e-9 * np.abs(b["u"]).max()
+
+
+@pytest.mark.parametrize("rels_mode", [0, 1])
+def test_config5_connected_strip(gpu_ctx, oracle, rels_mode):
+    """Config 5 as SURVEY 8(d) words it -- the deck tiled along x with SHARED edge nodes: one connected strip, `copies`
+    cohesive elements on one interface (a node sits in two of them: the coloured, atomic-free adds of the tangent and the
+    traction).  40 copies against the oracle's Newton loop (first increment; the later ones end in a line-search verdict on
+    both sides, see above), the callbacks' Jacobian twice for bitwise equality, and the x1000 strip (8,008 dofs) must run."""
+    from fem_amd.mesh import tile_deck_connected
+    m1 = read_inp(DECK)
+    m40 = tile_deck_connected(m1, 40)
+    a = driver.run_nonlinear(m40, "", ctx=gpu_ctx, rels_mode=rels_mode, recover_stress=False)
+    b = oracle.snes_run(m40, rels_mode=rels_mode)
+    assert a.snes_its[0] == b["its"][0] and a.snes_reasons[0] == b["reasons"][0] == 3
+    assert np.abs(a.U_hist[0] - b["U_hist"][0]).max() <= 1e-9 * np.abs(b["U_hist"][0]).max()
+    # the Jacobian of a state with open gaps, assembled twice: no atomics, same bits
+    prob = driver.NonlinearProblem(gpu_ctx, m40, "", rels_mode, None)
+    rng = np.random.default_rng(2)
+    X = capi.Vec(gpu_ctx, m40.ndof); X.set_array(1e-3 * rng.standard_normal(m40.ndof))
+    prob.calc_jacobian(X, prob.J)
+    v1 = prob.J.get_csr()[2].copy()
+    prob.calc_jacobian(X, prob.J)
+    assert np.array_equal(v1, prob.J.get_csr()[2])
+    X.destroy(); prob.destroy()
+    big = driver.run_nonlinear(tile_deck_connected(m1, 1000), "", ctx=gpu_ctx, rels_mode=rels_mode, recover_stress=False)
+    assert big.snes_reasons[0] == 3 and np.isfinite(big.aggregate_u).all()

@@ -452,12 +452,12 @@ def main():
                                               "left on the device"}
         if args.mult == "ebe" and hex_case and args.pc == "jacobi":
             # the CG iteration as a whole against the HBM roof: bytes of the product kernel (PMC where taken, else its
-            # algorithmic bytes) + the two vector kernels (x += a p, r -= a w, z, dots: 7 passes; p = z + b p: 4 passes)
+            # algorithmic bytes) + the two vector kernels (r -= a w, z, dots: 4 passes; x += a p, p = z + b p: 6 passes)
             prod = roof.get("traffic") or roof.get("algorithmic_bytes") or 0.0
-            it_bytes = prod + 11.0 * nrows * 8.0
+            it_bytes = prod + 10.0 * nrows * 8.0
             it_s = t_sol / args.steps / max(its, 1)
             out["cg_iteration_roofline"] = {"bound": "hbm", "bytes": it_bytes, "product_bytes": prod,
-                                            "vector_bytes": 11.0 * nrows * 8.0, "achieved": it_bytes / it_s / 1e9,
+                                            "vector_bytes": 10.0 * nrows * 8.0, "achieved": it_bytes / it_s / 1e9,
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": it_bytes / it_s / 1e9 / HBM_PEAK_GBS,
                                             "frac_of_measured_stream": it_bytes / it_s / 1e9 / stream_gbs}
         if world > 1 and args.n == 149 and args.jitter == 0.0 and hex_case:

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from fem_amd import capi, driver  # noqa: E402
 from fem_amd.inp import read_inp  # noqa: E402
-from fem_amd.mesh import tile_deck  # noqa: E402
+from fem_amd.mesh import tile_deck, tile_deck_connected  # noqa: E402
 
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 m1 = read_inp(os.path.join(ROOT, "tests", "golden", "decks", "cohesive_test_2.inp"))
@@ -27,6 +27,16 @@ for opts in ("-ksp_type preonly -pc_type lu", "-ksp_type bcgs -pc_type jacobi -k
         dt = time.perf_counter() - t0
     print(f"  [{opts}] {dt * 1e3:.1f} ms for {len(r.snes_its)} increments (second run); SNES iterations {list(r.snes_its)}, "
           f"reasons {list(r.snes_reasons)}, linear iterations {list(r.its)}, {m.ndof * len(r.snes_its) / dt:.3e} DOF-increments/s")
+# the same deck as ONE connected strip (shared edge nodes: `copies` cohesive elements on one interface)
+mc = tile_deck_connected(m1, copies)
+print(f"config 5, connected strip: {mc.nels} elements, {mc.nnds} nodes, {mc.ndof} dofs")
+for opts in ("-ksp_type preonly -pc_type lu",):
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r = driver.run_nonlinear(mc, opts, ctx=ctx, rels_mode=1, recover_stress=True)
+        dt = time.perf_counter() - t0
+    print(f"  [{opts}, rels_mode 1] {dt * 1e3:.1f} ms for {len(r.snes_its)} increments (second run); SNES iterations {list(r.snes_its)}, "
+          f"reasons {list(r.snes_reasons)}, linear iterations {list(r.its)}")
 try:
     from oracle.oracle import Oracle
     o = Oracle()

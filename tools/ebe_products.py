@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/ebe_products.py [n] [reps] -- assembles config 3 once and runs `reps` element-by-element
-products (for rocprofv3 --pmc passes over k_ebe_apply / k_ebe_gather)."""
+products and three nodal stress recoveries (for rocprofv3 --pmc passes over the tile kernels)."""
 import os
 import sys
 
@@ -19,4 +19,9 @@ prob.assemble(); prob.ksp.set_up()
 X, Y = capi.Vec(ctx, m.ndof), capi.Vec(ctx, m.ndof)
 X.set_array(np.sin(0.001 * np.arange(m.ndof)))
 print("avg product ms", prob.K.mult_timed(X, Y, reps), flush=True)
+S = capi.Vec(ctx, m.nnds * 6)
+for _ in range(3):                      # nodal stress over the tiles (k_tile_stress_cart on this mesh of bricks)
+    prob.dmesh.recover_nodal_stress_vec(X, S)
+ctx.synchronize()
+S.destroy()
 prob.destroy(); ctx.destroy()

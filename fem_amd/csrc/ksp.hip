@@ -665,7 +665,9 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     const bool self_reduce = self_env && A->mult_ebe && A->ebe_use_tile;
     A->red_out = self_reduce ? &st->red[2] : nullptr;
     struct RedOutGuard { fem_mat A; ~RedOutGuard() { A->red_out = nullptr; } } red_guard{A};
-    const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > 2048;
+    // (FEM_AMD_REDUCE_PW_MIN: from how many partials on the separate reduction kernel is used; measurement)
+    static const int pw_min = std::getenv("FEM_AMD_REDUCE_PW_MIN") ? std::atoi(std::getenv("FEM_AMD_REDUCE_PW_MIN")) : 2048;
+    const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > pw_min;
     int queued = 0;   // iterations enqueued so far (the profile samples iteration j * period)
     auto one_iteration = [&] {
         hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,

@@ -52,5 +52,6 @@ std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s)
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s);   // ebe_plan.hip
 // geometry records of the stored-geometry tiles' elements (taff: class per lane slot), ebe_tile.hip
 void ebe_tile_list_headers(fem::EbeTilePlan& P, hipStream_t s);   // lhdr_* from list_* and hdr (ebe_tile.hip)
+void ebe_tile_quad_factors(fem_mesh m, fem::EbeTilePlan& P, hipStream_t s);   // quad4 plans: D factors per lane slot
 void ebe_tile_store_geometry(fem_mesh m, fem::EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s);
 

@@ -835,6 +835,160 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
     tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
+// The same product with x AND the coordinates of the tile's nodes staged in LDS (the quad4 counterpart of k_ebe_tile_x): at a
+// million dofs every tile of the mesh is resident at once and the kernel lasts as long as one tile's chain of latencies, which
+// the gathering kernel above runs through once per step (slot -> node ids in LDS -> coordinates and x from global memory).  Here
+// the chain is: tile record -> node ids -> x, X (one wave of loads) and from then on LDS only; the slot records (local numbers,
+// flags, the element's two D factors: stored at set-up, no E / nu gather behind the element id) stream in one step ahead.
+// LDS: x and X of the tile's nodes (32 B each) + the sums of its owned nodes (16 B each): 50 KB for the 33 x 33-node tile.
+constexpr int TILE_Q4X_MAX_NODES = 1280, TILE_Q4X_MAX_OWN = 1024;   // 5 / 4 slots per thread
+constexpr int TILE_Q4X_LDS_NODES = 1104, TILE_Q4X_LDS_OWN = 976;    // the LDS image (33 x 33 nodes, 31 x 31 owned): 50 KB, three workgroups per CU
+__global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
+                                                      const int* __restrict__ tnodes, const uint4* __restrict__ tconn,
+                                                      const unsigned char* __restrict__ tflags, const double* __restrict__ geo,
+                                                      size_t geo_stride, const double* __restrict__ coords, const double* __restrict__ x,
+                                                      const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
+                                                      const double* __restrict__ bc_shift, double g, double w,
+                                                      double* __restrict__ y, double* __restrict__ partial, const int* __restrict__ done,
+                                                      unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red)
+{
+    if (done && *done) return;
+    constexpr int NPT = TILE_Q4X_MAX_NODES / 256, NPO = TILE_Q4X_MAX_OWN / 256, MN = TILE_Q4X_LDS_NODES, MO = TILE_Q4X_LDS_OWN;
+    extern __shared__ double lds[];
+    __shared__ double sh[4];
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // XCD-wise, as k_ebe_tile
+    if (lb >= (unsigned)nlist) return;
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
+    double* xs = lds;               // xs[d * MN + i]: x of the tile's nodes
+    double* Xs = lds + 2 * MN;      // Xs[d * MN + i]: their coordinates
+    double* acc = lds + 4 * MN;     // acc[d * MO + i]: sums of the owned nodes
+    int nv[NPT];
+    {
+        double xv[NPT][2], cv[NPT][2];
+#pragma unroll
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const int i = threadIdx.x + 256 * j;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                xv[j][d] = (i < nnode) ? x[(size_t)nv[j] * 2 + d] : 0.0;
+                cv[j][d] = (i < nnode) ? coords[(size_t)nv[j] * 2 + d] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nnode) {
+#pragma unroll
+                for (int d = 0; d < 2; d++) { xs[d * MN + i] = xv[j][d]; Xs[d * MN + i] = cv[j][d]; }
+            }
+            if (j < NPO && i < nown) { acc[i] = 0.0; acc[MO + i] = 0.0; }
+        }
+    }
+    int kb[NPO];
+#pragma unroll
+    for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 256 * j < nown) ? bc_node[nv[j]] : -1;
+    const int2 sv = ((int)(threadIdx.x & 63) < nsteps) ? steps[step_off + (threadIdx.x & 63)] : make_int2(0, 0);
+    struct Slot { uint4 c16; unsigned fl; double lam, mu; };
+    auto fetch = [&](Slot& q, int s) {
+        q.fl = 0; q.lam = 1.0; q.mu = 1.0;
+        if (s >= nsteps) return;
+        const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
+        if ((int)threadIdx.x >= cnt) return;
+        const size_t k = (size_t)elem_off + first + threadIdx.x;
+        q.c16 = tconn[k];
+        q.fl = tflags[k];
+        q.lam = geo[k]; q.mu = geo[geo_stride + k];
+    };
+    auto read_corners = [&](double (&X)[4][2], double (&u)[4][2], const Slot& q) {
+        const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            if (a == 1 || a == 2) continue;
+            const int la = tile_loc(q.c16, a);
+#pragma unroll
+            for (int d = 0; d < 2; d++) { X[a][d] = valid ? Xs[d * MN + la] : 0.0; u[a][d] = valid ? xs[d * MN + la] : 0.0; }
+        }
+        if (valid && !linked) {
+#pragma unroll
+            for (int a = 1; a < 3; a++) {
+                const int la = tile_loc(q.c16, a);
+#pragma unroll
+                for (int d = 0; d < 2; d++) { X[a][d] = Xs[d * MN + la]; u[a][d] = xs[d * MN + la]; }
+            }
+        }
+    };
+    Slot q0, q1;
+    fetch(q0, 0);
+    __syncthreads();
+    double X[4][2], u[4][2];
+    read_corners(X, u, q0);
+    bool prev_bar = false;
+    for (int s = 0; s < nsteps; s++) {
+        const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
+        fetch(q1, s + 1);
+        const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {   // the +x edge (nodes 1, 2) of a linked lane: the next lane's -x edge (nodes 0, 3)
+            const double x1 = row_next(X[0][d]), x2 = row_next(X[3][d]), u1 = row_next(u[0][d]), u2 = row_next(u[3][d]);
+            if (linked) { X[1][d] = x1; X[2][d] = x2; u[1][d] = u1; u[2][d] = u2; }
+        }
+        double fe[4][2], dote;
+        quad4_forces(X, u, g, w, q0.lam, q0.mu, fe, dote);
+        {
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const double p1 = row_prev(fe[1][d]), p2 = row_prev(fe[2][d]);
+                if (recv) { fe[0][d] += p1; fe[3][d] += p2; }
+            }
+        }
+        read_corners(X, u, q1);
+        if (prev_bar) __syncthreads();
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (linked && (a == 1 || a == 2)) continue;   // handed over
+                const int la = tile_loc(q0.c16, a);
+                if (la >= nown) continue;     // a rim node: its sum belongs to another tile
+#pragma unroll
+                for (int d = 0; d < 2; d++)   // one writer per node and colour
+                    __hip_atomic_fetch_add(&acc[d * MO + la], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        prev_bar = bar;
+        q0 = q1;
+    }
+    __syncthreads();
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPO; j++) {
+        const int i = threadIdx.x + 256 * j;
+        if (i >= nown) continue;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            double sum = acc[d * MO + i];
+            const double xi = xs[d * MN + i];
+            if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
+            y[(size_t)nv[j] * 2 + d] = sum;
+            dot += xi * sum;
+        }
+    }
+    tile_finish(dot, t, sh, partial, rcount, rtotal, red);
+}
+// the two factors of DMat2d per lane slot of a quad4 plan (k_ebe_tile_q4x): geo[k] = d12, geo[slots + k] = d44
+__global__ void __launch_bounds__(256) k_tile_geom_q4(size_t ntel, const int* __restrict__ telems, const double* __restrict__ Ev,
+                                                      const double* __restrict__ nuv, double* __restrict__ geo)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ntel) return;
+    const int e = telems[k];
+    const DCoef D = dmat_coef(e >= 0 ? Ev[e] : 1.0, e >= 0 ? nuv[e] : 0.25);
+    geo[k] = D.d12; geo[ntel + k] = D.d44;
+}
+
 // the parallelepiped test of hex_forces on the host (same tolerance)
 static bool host_hex_affine(const double (&X)[8][3])
 {
@@ -939,6 +1093,16 @@ void ebe_tile_list_headers(EbeTilePlan& P, hipStream_t s)
         if (n) hipLaunchKernelGGL(k_tile_list_hdr, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, n, list.p, P.hdr.p, out.p);
     };
     go(P.lhdr_cart, P.list_cart, P.n_cart); go(P.lhdr_aff, P.list_aff, P.n_aff); go(P.lhdr_gen, P.list_gen, P.n_gen);
+    FEM_HIP(hipGetLastError());
+}
+// quad4 plans: the D factors of every lane slot's element (k_ebe_tile_q4x reads them with the slot record)
+void ebe_tile_quad_factors(fem_mesh m, EbeTilePlan& P, hipStream_t s)
+{
+    auto& grp = m->groups[0];
+    if (grp.type != FEM_QUA || P.slots < 1) return;
+    P.geo.alloc((size_t)P.slots * 2);
+    hipLaunchKernelGGL(k_tile_geom_q4, dim3((unsigned)((P.slots + 255) / 256)), dim3(256), 0, s, (size_t)P.slots, P.elems.p, grp.E.p,
+                       grp.nu.p, P.geo.p);
     FEM_HIP(hipGetLastError());
 }
 
@@ -1408,6 +1572,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s)
     FEM_HIP(hipStreamSynchronize(s));
     ebe_tile_list_headers(*plan, s);
     if (!laff.empty() || !lcart.empty()) ebe_tile_store_geometry(m, *plan, d_taff.p, s);
+    if (!hex) ebe_tile_quad_factors(m, *plan, s);
     FEM_HIP(hipStreamSynchronize(s));   // (d_taff goes out of scope)
     plan->t_setup_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (verbose)
@@ -1452,6 +1617,19 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
             FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_q4), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         TILE_MAX_NODES * 20));
         const int n0 = phase == 1 ? P.n_gen_if : 0, n1 = phase == 0 ? P.n_gen_if : P.n_gen;
+        // x and the coordinates of a tile in LDS where its nodes fit (FEM_AMD_TILE_X=0: the gathering kernel)
+        static const bool qx_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
+        if (qx_env && P.geo.p && P.max_nsteps <= 64 && P.max_nnode <= TILE_Q4X_LDS_NODES && P.max_nown <= TILE_Q4X_LDS_OWN) {
+            constexpr size_t shqx = (size_t)(4 * TILE_Q4X_LDS_NODES + 2 * TILE_Q4X_LDS_OWN) * sizeof(double);
+            static OncePerDevice qxonce;
+            if (qxonce.first(A->ctx->device))
+                FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_q4x), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shqx));
+            if (n1 > n0)
+                hipLaunchKernelGGL(k_ebe_tile_q4x, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shqx, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
+                                   P.steps.p, P.nodes.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn, A->bc_dof.p,
+                                   A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out);
+            return;
+        }
         if (n1 > n0)
             hipLaunchKernelGGL(k_ebe_tile_q4, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shq, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
                                P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn,

@@ -515,6 +515,35 @@ def main():
         pr = run_once(mesh, f"{pc_opts} -mat_mult_type {args.mult}", rtol=1e-12)
         out["config"]["parity_run"] = {"rtol": 1e-12, "cg_iterations": pr["its"], "converged_reason": pr["reason"],
                                        "ms_per_step": pr["t_setup_assemble_ms"] + pr["t_solve_ms"], "t_solve_ms": pr["t_solve_ms"]}
+        if args.mult == "ebe":
+            # the same step with the assembled SpMV inside the CG (SURVEY 8(d)'s "CSR SpMV inside CG/Jacobi"): the headline applies
+            # Mat_K element by element, so this is where the SpMV of the metric's second half runs inside a timed solve --
+            # every 8th launch bracketed by HIP events on the library's stream
+            pa = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type assembled")
+            pa.ksp.set_profiling(period)
+            pa.assemble(); pa.ksp.set_up()
+            pa.dmesh.form_rhs(pa.F, 0.0, mesh.dt)
+            pa.ksp.solve(pa.F, pa.U)                      # warm-up
+            ctx.synchronize()
+            ta_ = time.perf_counter()
+            pa.K.destroy(); pa.K = None
+            pa.assemble(); pa.ksp.set_up()
+            pa.dmesh.form_rhs(pa.F, 0.0, mesh.dt)
+            pa.ksp.solve(pa.F, pa.U)
+            ctx.synchronize()
+            ta_ = time.perf_counter() - ta_
+            ka, msa, sola = pa.ksp.get_profile()
+            ita = pa.ksp.get_iteration_number()
+            _, nnz_a, dev_a = pa.K.info()
+            sp_ms = msa / max(ka, 1)
+            fmt_a = dev_a + nrows * 16.0
+            out["config"]["assembled_spmv_run"] = {
+                "what": "one step with -mat_mult_type assembled: k_spmv_sell inside KSPCG", "value": ndof_global / ta_, "unit": "DOF/s",
+                "ms_per_step": ta_ * 1e3, "cg_iterations": ita, "converged_reason": pa.ksp.get_converged_reason(),
+                "ms_per_cg_iteration": sola / max(ita, 1), "spmv_ms_in_cg": sp_ms, "sampled_launches": ka,
+                "spmv_GBs_csr_bytes": spmv_algorithmic_bytes(nnz_a, nrows) / (sp_ms * 1e-3) / 1e9 if sp_ms > 0 else None,
+                "spmv_frac_of_spec_format": fmt_a / (sp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if sp_ms > 0 else None}
+            pa.destroy()
         if hex_case and not args.no_c2:
             # config 2 of BASELINE.json (707^2 quad4 plate, 1.0 M DOF) in the same line: steady-state steps as above
             m2 = structured_quad(707)

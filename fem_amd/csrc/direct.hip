@@ -633,9 +633,12 @@ void BandLU::setup(fem_mat A_)
     kl = (int)std::min<long long>(bwn * bs + bs - 1, std::max<long long>(n - 1, 0));
     wb = 3 * kl + 1;
     size_t free_b = 0, total_b = 0;
-    pool_trim();
-    FEM_HIP(hipMemGetInfo(&free_b, &total_b));
     const double need = (double)n * wb * sizeof(double);
+    FEM_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (!(need < 0.8 * ((double)free_b + (double)pool_cached_bytes()))) {   // (only a factor that may not fit empties the pool)
+        pool_trim();
+        FEM_HIP(hipMemGetInfo(&free_b, &total_b));
+    } else free_b += pool_cached_bytes();
     FEM_CHECK(need < 0.8 * (double)free_b, 9, "pc lu: the band of the unsymmetric factor needs " +
                                                   std::to_string((long long)(need / 1048576.0)) + " MiB: use -ksp_type bcgs");
     DBuf<int> dperm((size_t)nn);

@@ -392,6 +392,9 @@ def main():
         if traffic:
             r["pmc_GBs"] = traffic / secs / 1e9
             r["frac_of_spec_pmc"] = r["pmc_GBs"] / HBM_PEAK_GBS
+        # the part of the byte model no MatMult can avoid -- x read once, y written once -- on its own: the rest (tile lists, node
+        # lists, stored geometry) is this design's metadata, which the product trades for the 7 GB of matrix it does not stream
+        r["frac_x_and_y_only"] = nrows * 16.0 / secs / 1e9 / HBM_PEAK_GBS
         if info["kind"] == 2:
             r["tiles"] = {k: info[k] for k in ("tiles", "affine_tiles", "element_visits", "lane_slots", "tile_nodes", "setup_ms")}
         r.update(extra)

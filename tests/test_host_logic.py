@@ -330,3 +330,29 @@ def test_bench_work_table_matches_the_compiled_kernels():
     # distorted elements: the arithmetic of the general path alone (the tool's count of k_ebe_tile<general> includes the
     # parallelepiped shortcut that a wavefront of distorted elements never takes)
     assert got["k_ebe_apply<3,8,8,2>"][:2] == tuple(bench.EBE_WORK["k_ebe_tile<general>"][:2])
+
+
+def test_connected_tiling_of_the_cohesive_deck_shares_its_edge_nodes():
+    """Config 5 as one strip: `copies` copies of examples/cohesive_test_2.inp joined at their x = 0 / x = 1 edges (four nodes
+    each, the duplicated interface nodes pairing up in the order of their numbers): 4 + 4 copies nodes, every cohesive element
+    still spans its own interface pair, and the oracle's Newton loop runs on it."""
+    from fem_amd.inp import read_inp
+    from fem_amd.mesh import tile_deck, tile_deck_connected
+    deck = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decks", "cohesive_test_2.inp")
+    m1 = read_inp(deck)
+    for copies in (1, 2, 7):
+        m = tile_deck_connected(m1, copies)
+        assert m.nnds == 4 + 4 * copies and m.nels == 3 * copies
+        assert m.conn.min() == 0 and m.conn.max() == m.nnds - 1
+        d = tile_deck(m1, copies)                     # the disjoint tiling: same elements, copy c shifted by 2 (extent 1 + 1)
+        conn_c, conn_d = m.conn.reshape(-1, 4), d.conn.reshape(-1, 4)
+        for e in range(m.nels):
+            c = e // 3
+            assert np.allclose(m.coords[conn_c[e]], d.coords[conn_d[e]] - np.array([c * 1.0, 0.0]))
+        if copies > 1:   # the right edge of copy 0 is the left edge of copy 1
+            e0, e1 = conn_c[0], conn_c[3]             # upper quads of copies 0 and 1: (1 2 5 4) -> nodes 4, 5 are copy 1's 1, 2
+            assert e0[3] == e1[0] and e0[2] == e1[1]
+    from oracle.oracle import Oracle, build
+    build(ref=False)
+    r = Oracle().snes_run(tile_deck_connected(m1, 5), rels_mode=1)
+    assert r["its"][0] == 1 and r["reasons"][0] == 3 and np.isfinite(r["u"]).all()

@@ -626,14 +626,15 @@ def main():
                 print(json.dumps(out), flush=True)
             os._exit(3)
         if world > 1 and args.mult == "ebe" and hex_case and mg_line is not None:
-            # the exchange beside the interior tiles (second stream), measured against the one-stream schedule on real peers:
-            # two steps each with CG/Jacobi; reported, the headline keeps the one-stream schedule it was timed with
+            # the exchange beside the interior tiles (second stream) and the p.Kp all-reduce inside the RCCL group of the halo
+            # exchange, each measured against the plain one-stream schedule on real peers: two steps each with CG/Jacobi;
+            # reported, the headline keeps the schedule it was timed with
             if out is not None:
                 out["config"]["pc_mg"] = mg_line            # (should the probe hang, the watchdog prints what is complete)
             try:
                 probe = {}
-                for flag in (0, 1):
-                    prob.ksp.set_from_options(f"-pc_type jacobi -ksp_halo_overlap {flag} -mat_mult_type {args.mult}")
+                for flag, fuse in ((0, 0), (1, 0), (0, 1)):
+                    prob.ksp.set_from_options(f"-pc_type jacobi -ksp_halo_overlap {flag} -ksp_fuse_allreduce {fuse} -mat_mult_type {args.mult}")
                     one_step()
                     barrier()
                     tp = time.perf_counter()
@@ -646,8 +647,8 @@ def main():
                     tt = torch.tensor([tp, sp], dtype=torch.float64, device="cuda")
                     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                     pits = max(prob.ksp.get_iteration_number(), 1)
-                    probe[f"overlap_{flag}"] = {"ms_per_step": float(tt[0]) / 2 * 1e3, "ms_per_cg_iteration": float(tt[1]) / 2 * 1e3 / pits,
-                                                "cg_iterations": pits}
+                    probe[f"overlap_{flag}_fused_allreduce_{fuse}"] = {"ms_per_step": float(tt[0]) / 2 * 1e3,
+                                                                     "ms_per_cg_iteration": float(tt[1]) / 2 * 1e3 / pits, "cg_iterations": pits}
                 if out is not None:
                     out["config"]["halo_overlap_probe"] = probe
             except Exception as e:  # noqa: BLE001

@@ -23,6 +23,13 @@ struct Comm {
     // neighbour i sends sendbuf[off[i]..off[i+1]) and receives the same range of recvbuf
     virtual void exchange(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf,
                           double* recvbuf, hipStream_t s) = 0;
+    // both in one go: the all-reduce of `nred` doubles and the neighbour exchange (RCCL: one group, one launch instead of two;
+    // the other back ends: one after the other)
+    virtual void exchange_allreduce(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf, double* recvbuf,
+                                    double* red, int nred, hipStream_t s) {
+        allreduce_sum(red, nred, s);
+        exchange(nneigh, neigh_rank, off, sendbuf, recvbuf, s);
+    }
     virtual bool needs_reduce() const { return size > 1; }
 };
 
@@ -37,3 +44,5 @@ struct fem_comm_s {
 void halo_sum(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc);
 // the same on a given stream (the Krylov solver runs it beside the interior part of the product)
 void halo_sum_on(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, hipStream_t s);
+// the halo sum together with the all-reduce of red[0 .. nred) (Comm::exchange_allreduce), on the mesh's stream
+void halo_sum_allreduce(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, double* red, int nred);

@@ -103,6 +103,19 @@ struct RcclComm : Comm {
         }
         FEM_NCCL(rccl().GroupEnd());
     }
+    // the CG's p.Kp all-reduce inside the group of the halo exchange that follows it: one RCCL launch per iteration less
+    void exchange_allreduce(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf, double* recvbuf,
+                            double* red, int nred, hipStream_t s) override {
+        FEM_NCCL(rccl().GroupStart());
+        FEM_NCCL(rccl().AllReduce(red, red, (size_t)nred, NCCL_FLOAT64, NCCL_SUM, nc, s));
+        for (int i = 0; i < nneigh; i++) {
+            const size_t cnt = off[i + 1] - off[i];
+            if (!cnt) continue;
+            FEM_NCCL(rccl().Send(sendbuf + off[i], cnt, NCCL_FLOAT64, neigh_rank[i], nc, s));
+            FEM_NCCL(rccl().Recv(recvbuf + off[i], cnt, NCCL_FLOAT64, neigh_rank[i], nc, s));
+        }
+        FEM_NCCL(rccl().GroupEnd());
+    }
 };
 
 // ---------------------------------------------------------------- LocalGroup
@@ -223,6 +236,24 @@ void halo_sum_on(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, hi
     std::vector<size_t> off(h->nneigh + 1);
     for (int i = 0; i <= h->nneigh; i++) off[i] = (size_t)h->neigh_ptr[i] * ncomp;
     h->comm->exchange(h->nneigh, h->neigh_rank.data(), off.data(), h->sendbuf.p, h->recvbuf.p, s);
+    hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((size_t)h->ninodes * ncomp, 256)), dim3(256), 0, s, h->ninodes,
+                       h->inodes.p, h->contrib_ptr.p, h->contrib_src.p, ncomp, sn, sc, h->recvbuf.p, vec);
+    FEM_HIP(hipGetLastError());
+}
+
+void halo_sum_allreduce(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, double* red, int nred)
+{
+    Halo* h = mesh->halo.get();
+    hipStream_t s = mesh->ctx->stream;
+    if (!h) return;
+    const int nslots = h->neigh_ptr[h->nneigh];
+    if (h->comm->size == 1 || nslots == 0) { h->comm->allreduce_sum(red, nred, s); return; }
+    FEM_CHECK((size_t)ncomp <= 6, 63, "halo_sum: too many components");
+    hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((size_t)nslots * ncomp, 256)), dim3(256), 0, s, nslots, h->neigh_nodes.p,
+                       ncomp, sn, sc, vec, h->sendbuf.p);
+    std::vector<size_t> off(h->nneigh + 1);
+    for (int i = 0; i <= h->nneigh; i++) off[i] = (size_t)h->neigh_ptr[i] * ncomp;
+    h->comm->exchange_allreduce(h->nneigh, h->neigh_rank.data(), off.data(), h->sendbuf.p, h->recvbuf.p, red, nred, s);
     hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv((size_t)h->ninodes * ncomp, 256)), dim3(256), 0, s, h->ninodes,
                        h->inodes.p, h->contrib_ptr.p, h->contrib_src.p, ncomp, sn, sc, h->recvbuf.p, vec);
     FEM_HIP(hipGetLastError());

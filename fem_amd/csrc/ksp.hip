@@ -367,6 +367,7 @@ struct fem_ksp_s {
     DBuf<double> bcgs_work;                      // -ksp_type bcgs: r, r', v, t, s, p, A*in scratch
     bool mg_additive = false;
     int halo_overlap = -1;                   // -ksp_halo_overlap 0|1: the exchange beside the interior tiles; -1: FEM_AMD_OVERLAP
+    int fuse_allreduce = -1;                 // -ksp_fuse_allreduce 0|1: p.Kp all-reduce in the RCCL group of the halo exchange; -1: FEM_AMD_FUSE_ALLREDUCE
     double mg_box = 4.0;                     // level-1 box edge in mean node spacings
     int mg_slice_min = 32768;
     double mg_alpha = -1.0, mg_omega = 0.7;  // alpha < 0: default (1.5 over-correction for the additive form, 1 for the V-cycle)
@@ -425,6 +426,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-ksp_atol") { is >> k->abstol; }
         else if (key == "-ksp_divtol") { is >> k->dtol; }
         else if (key == "-ksp_max_it") { is >> k->maxit; }
+        else if (key == "-ksp_fuse_allreduce") { is >> k->fuse_allreduce; FEM_CHECK(k->fuse_allreduce == 0 || k->fuse_allreduce == 1, 6, "-ksp_fuse_allreduce 0|1"); }
         else if (key == "-ksp_halo_overlap") { is >> k->halo_overlap; FEM_CHECK(k->halo_overlap == 0 || k->halo_overlap == 1, 6, "-ksp_halo_overlap 0|1"); }
         else if (key == "-ksp_norm_type") { is >> val; FEM_CHECK(val == "preconditioned", 6, "only -ksp_norm_type preconditioned"); }
         else if (key == "-pc_factor_mat_solver_package" || key == "-pc_factor_mat_solver_type") { is >> val; }  // one built-in factorisation
@@ -645,6 +647,8 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // Off by default: on one GPU with a single-rank RCCL communicator the hand-overs cost more than a neighbour exchange
     // is expected to take and no second GPU was available to measure the other side.
     static const bool overlap_env = std::getenv("FEM_AMD_OVERLAP") && std::atoi(std::getenv("FEM_AMD_OVERLAP")) != 0;
+    static const bool fuse_env = std::getenv("FEM_AMD_FUSE_ALLREDUCE") && std::atoi(std::getenv("FEM_AMD_FUSE_ALLREDUCE")) != 0;
+    const bool fuse_ar = k->fuse_allreduce >= 0 ? k->fuse_allreduce != 0 : fuse_env;
     const bool overlap_on = k->halo_overlap >= 0 ? k->halo_overlap != 0 : overlap_env;
     const bool overlap = comm && overlap_on && ebe_tile_phase(A, nullptr, nullptr, nullptr, nullptr, -2);
     fem_ctx cx = A->ctx;
@@ -702,8 +706,11 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
                                A->spmv_grid, &st->red[2], &st->done);
         if (comm) {
             // p.(K p) = sum over domains of p_loc.(K_loc p_loc): the fused partials stay valid un-assembled
-            comm->allreduce_sum(&st->red[2], 1, s);
-            halo_sum(A->mesh, k->w.p, pd, pd, 1);
+            if (fuse_ar) halo_sum_allreduce(A->mesh, k->w.p, pd, pd, 1, &st->red[2], 1);   // (one RCCL group for both)
+            else {
+                comm->allreduce_sum(&st->red[2], 1, s);
+                halo_sum(A->mesh, k->w.p, pd, pd, 1);
+            }
         }
         hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st,
                            reduce_pw_first ? nullptr : A->spmv_partial.p, A->spmv_grid,

@@ -241,3 +241,14 @@ def test_general_partition_matches_serial_oracle(oracle, kind, world):
         c.destroy()
     for c in ctxs:
         c.destroy()
+
+
+def test_allreduce_inside_the_halo_group_gives_the_same_fields():
+    """-ksp_fuse_allreduce 1 (the CG's p.Kp all-reduce and the halo exchange of w through Comm::exchange_allreduce: one RCCL
+    group on real peers, one after the other in the in-process communicator) against the default schedule: same iteration
+    counts, bitwise the same fields."""
+    a = _run_domains(4, (5, 4, 3), 0.1, "-mat_mult_type ebe -ksp_rtol 1e-12")[1]
+    b = _run_domains(4, (5, 4, 3), 0.1, "-mat_mult_type ebe -ksp_rtol 1e-12 -ksp_fuse_allreduce 1")[1]
+    for (ua, sa, ia, ra, ya, ga), (ub, sb, ib, rb, yb, gb) in zip(a, b):
+        assert ia == ib and ra == rb > 0
+        assert np.array_equal(ua, ub) and np.array_equal(sa, sb)

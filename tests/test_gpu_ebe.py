@@ -70,8 +70,30 @@ def _with_isolated_nodes(m, k=70):
     return m
 
 
+def _annulus(m):
+    """the brick bent into half a ring (x -> angle, y -> radius): curved grid lines, no lattice (the signed mean edge vectors
+    cancel), so the tile plan bins the nodes in boxes of the mean spacing along x, y, z -- ragged tiles, chains that follow the
+    curved x-lines, every element distorted"""
+    c = m.coords.copy()
+    th = np.pi * (1.0 - c[:, 0] / c[:, 0].max())          # (clockwise: the elements keep their orientation)
+    rad = 2.0 + c[:, 1] / c[:, 1].max()
+    m.coords = np.ascontiguousarray(np.column_stack([8.0 * rad * np.cos(th), 8.0 * rad * np.sin(th), 0.6 * c[:, 2]]))
+    return m
+
+
+def _two_materials(m):
+    """a second, softer and less compressible material in every other layer of elements: the stored geometry of the tiles and
+    the one-pass nodal stress carry E and nu element by element"""
+    m.mats = np.vstack([m.mats, [7.0e9, 0.4, 1.0e18, 1.0, 2000.0]])
+    c = m.coords[m.conn.reshape(m.nels, 8)].mean(axis=1)
+    m.mat_id = np.ascontiguousarray((np.floor(c[:, 2]).astype(np.int64) % 2).astype(m.mat_id.dtype))
+    return m
+
+
 def _meshes():
     return {
+        "hex_two_materials": _two_materials(structured_hex(19, 9, 8)),
+        "hex_annulus": _annulus(structured_hex(48, 6, 5)),
         "hex_isolated_nodes": _with_isolated_nodes(structured_hex(6, 5, 4, jitter=0.1)),
         "hex_shuffled": _shuffled(structured_hex(13, 11, 9, jitter=0.1)),
         "hex_uniform": structured_hex(7, 6, 5),                      # every element a cube: affine path
@@ -130,7 +152,7 @@ def test_ebe_product_matches_assembled_product_and_oracle(gpu_ctx, oracle, name)
 
 
 @pytest.mark.parametrize("name", ["hex_isolated_nodes", "hex_shuffled", "hex_uniform", "hex_sheared", "hex_half_jitter",
-                                  "hex_67nodes_x", "hex_tiles", "hex_tiles_flat", "hex_graded"])
+                                  "hex_67nodes_x", "hex_tiles", "hex_tiles_flat", "hex_graded", "hex_annulus", "hex_two_materials"])
 def test_nodal_stress_over_the_tiles_matches_the_element_buffer_path(gpu_ctx, oracle, name):
     """Once a hex8 mesh carries the tile plan of the one-pass product, RecoverNodalStress + the nodal average
     (src/main.F90:253-279) run over the same tiles (sums in LDS, strains in the monomial basis, two passes of three

@@ -603,6 +603,113 @@ __global__ void __launch_bounds__(256) k_band_lu_solve(long long n, int kl, int 
     }
 }
 
+// ---- a matrix that falls apart into small independent blocks (BASELINE config 5: a thousand copies of the reference's
+// cohesive deck side by side share no node) is factorised block by block: one wavefront per connected component of the node
+// graph, dense LU with partial pivoting in LDS -- instead of one workgroup walking all 16,000 columns of the band one after the
+// other (28 ms per factorisation, most of a Newton step's time).  Same pivot rule as the band LU (a pivot below 1e-6 of
+// the largest non-penalty entry of the whole matrix is fixed to zero, a NaN is reported).
+constexpr int COMP_MAX = 64;   // dofs of a component (one lane per row)
+__global__ void __launch_bounds__(256) k_val_amax(size_t n, const double* __restrict__ v, unsigned long long* __restrict__ out)
+{
+    double m = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const double a = fabs(v[i]); if (a < 1e29 && a > m) m = a; }
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_down(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));   // (non-negative doubles order like their bits)
+}
+template <int BS>
+__global__ void __launch_bounds__(64) k_comp_lu(int ncomp, const int* __restrict__ comp_ptr, const int* __restrict__ comp_nodes,
+                                                const int* __restrict__ node_loc, const int* __restrict__ boff,
+                                                const int* __restrict__ bcol, const double* __restrict__ val,
+                                                const int* __restrict__ rowlen, const unsigned long long* __restrict__ amax_bits,
+                                                const long long* __restrict__ fac_off, double* __restrict__ fac, int* __restrict__ piv,
+                                                int* __restrict__ flag)
+{
+    __shared__ double a[COMP_MAX][COMP_MAX + 1];
+    __shared__ int s_p;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= ncomp) return;
+    const int p0 = comp_ptr[c], m = (comp_ptr[c + 1] - p0) * BS;
+    const double tiny = 1e-6 * __longlong_as_double((long long)*amax_bits);
+    for (int j = 0; j < m; j++) a[lane][j] = 0.0;
+    __syncthreads();
+    if (lane < m) {   // row `lane` of the block from the node's block row of the Mat
+        const int node = comp_nodes[p0 + lane / BS], r = lane % BS;
+        const int ln = node & 63, len = rowlen[node], o0 = boff[node >> 6];
+        for (int j = 0; j < len; j++) {
+            const int cl = node_loc[bcol[(size_t)(o0 + j) * 64 + ln]] * BS;
+            for (int cc = 0; cc < BS; cc++) a[lane][cl + cc] = val[((size_t)(o0 + j) * BS * BS + r * BS + cc) * 64 + ln];
+        }
+    }
+    __syncthreads();
+    const size_t dof0 = (size_t)p0 * BS;   // position of the block's first dof in the component-ordered numbering
+    for (int k = 0; k < m; k++) {
+        if (lane == 0) {
+            int p = k;
+            double best = fabs(a[k][k]);
+            for (int i = k + 1; i < m; i++) { const double v = fabs(a[i][k]); if (v > best) { best = v; p = i; } }
+            if (!(best > tiny)) {
+                p = -1;
+                atomicAdd(flag, 1);
+                if (isnan(best)) atomicExch(flag + 1, 1);
+            }
+            s_p = p;
+            piv[dof0 + k] = p;
+        }
+        __syncthreads();
+        const int p = s_p;
+        if (p < 0) {   // null pivot: the unknown is fixed to zero (row and column dropped)
+            if (lane < m && lane != k) { a[lane][k] = 0.0; a[k][lane] = 0.0; }
+            if (lane == 0) a[k][k] = 1.0;
+            __syncthreads();
+            continue;
+        }
+        if (p != k && lane < m) { const double t = a[k][lane]; a[k][lane] = a[p][lane]; a[p][lane] = t; }
+        __syncthreads();
+        if (lane > k && lane < m) {
+            const double l = a[lane][k] / a[k][k];
+            a[lane][k] = l;
+            for (int j = k + 1; j < m; j++) a[lane][j] -= l * a[k][j];
+        }
+        __syncthreads();
+    }
+    if (lane < m)
+        for (int j = 0; j < m; j++) fac[fac_off[c] + (size_t)lane * m + j] = a[lane][j];
+}
+// the solves of the same blocks: b and x in the Mat's dof numbering
+template <int BS>
+__global__ void __launch_bounds__(64) k_comp_solve(int ncomp, const int* __restrict__ comp_ptr, const int* __restrict__ comp_nodes,
+                                                   const long long* __restrict__ fac_off, const double* __restrict__ fac,
+                                                   const int* __restrict__ piv, const double* __restrict__ b, double* __restrict__ x)
+{
+    __shared__ double xs[COMP_MAX];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= ncomp) return;
+    const int p0 = comp_ptr[c], m = (comp_ptr[c + 1] - p0) * BS;
+    const size_t dof0 = (size_t)p0 * BS;
+    const double* f = fac + fac_off[c];
+    size_t gdof = 0;
+    if (lane < m) { gdof = (size_t)comp_nodes[p0 + lane / BS] * BS + lane % BS; xs[lane] = b[gdof]; }
+    __syncthreads();
+    for (int k = 0; k < m; k++) {   // row exchanges and L
+        const int p = piv[dof0 + k];
+        if (p < 0) { if (lane == 0) xs[k] = 0.0; __syncthreads(); continue; }
+        if (lane == 0 && p != k) { const double t = xs[k]; xs[k] = xs[p]; xs[p] = t; }
+        __syncthreads();
+        const double xk = xs[k];
+        if (lane > k && lane < m) xs[lane] -= f[(size_t)lane * m + k] * xk;
+        __syncthreads();
+    }
+    for (int k = m - 1; k >= 0; k--) {   // U
+        if (piv[dof0 + k] < 0) { __syncthreads(); continue; }
+        if (lane == 0) xs[k] /= f[(size_t)k * m + k];
+        __syncthreads();
+        const double xk = xs[k];
+        if (lane < k) xs[lane] -= f[(size_t)lane * m + k] * xk;
+        __syncthreads();
+    }
+    if (lane < m) x[gdof] = xs[lane];
+}
+
 void BandLU::setup(fem_mat A_)
 {
     A = A_; bs = A->bs;
@@ -621,6 +728,63 @@ void BandLU::setup(fem_mat A_)
     for (int v = 0; v < nn; v++) {
         const size_t o0 = (size_t)A->h_boff[v >> 6];
         for (int j = 0; j < A->h_rowlen[v]; j++) adj[(size_t)ptr[v] + j] = hc[(o0 + j) * 64 + (v & 63)];
+    }
+    // independent blocks?  connected components of the node graph (the pattern is symmetric), small ones only
+    batched = false;
+    {
+        static const bool comp_env = !(std::getenv("FEM_AMD_LU_COMPONENTS") && std::atoi(std::getenv("FEM_AMD_LU_COMPONENTS")) == 0);
+        std::vector<int> comp((size_t)nn, -1), stack, cptr{0}, cnodes;
+        int nc = 0, biggest = 0;
+        for (int v0_ = 0; v0_ < nn && comp_env; v0_++) {
+            if (comp[(size_t)v0_] >= 0) continue;
+            const size_t first = cnodes.size();
+            stack.assign(1, v0_); comp[(size_t)v0_] = nc;
+            while (!stack.empty()) {
+                const int v = stack.back(); stack.pop_back();
+                cnodes.push_back(v);
+                for (int e = ptr[v]; e < ptr[v + 1]; e++) {
+                    const int u = adj[(size_t)e];
+                    if (comp[(size_t)u] < 0) { comp[(size_t)u] = nc; stack.push_back(u); }
+                }
+            }
+            std::sort(cnodes.begin() + (long)first, cnodes.end());
+            biggest = std::max(biggest, (int)(cnodes.size() - first));
+            cptr.push_back((int)cnodes.size());
+            nc++;
+        }
+        if (comp_env && nc >= 1 && biggest * bs <= COMP_MAX) {   // (also a single small deck: the same arithmetic as its tilings)
+            batched = true;
+            ncomp = nc;
+            std::vector<int> loc((size_t)nn);
+            std::vector<long long> foff((size_t)nc + 1, 0);
+            for (int c = 0; c < nc; c++) {
+                for (int k = cptr[c]; k < cptr[c + 1]; k++) loc[(size_t)cnodes[(size_t)k]] = k - cptr[c];
+                const long long mm = (long long)(cptr[c + 1] - cptr[c]) * bs;
+                foff[(size_t)c + 1] = foff[(size_t)c] + mm * mm;
+            }
+            comp_ptr.alloc(cptr.size()); comp_ptr.upload(cptr.data(), cptr.size(), s);
+            comp_nodes.alloc(cnodes.size()); comp_nodes.upload(cnodes.data(), cnodes.size(), s);
+            node_loc.alloc(loc.size()); node_loc.upload(loc.data(), loc.size(), s);
+            fac_off.alloc(foff.size()); fac_off.upload(foff.data(), foff.size(), s);
+            fac.alloc((size_t)std::max<long long>(foff[(size_t)nc], 1));
+            ipiv.alloc((size_t)n); flag.alloc(2); flag.zero(s);
+            DBuf<unsigned long long> amax(1);
+            amax.zero(s);
+            hipLaunchKernelGGL(k_val_amax, dim3(std::min<unsigned>(cdiv(A->val.n, 256), 1024)), dim3(256), 0, s, A->val.n, A->values(), amax.p);
+            if (bs == 3)
+                hipLaunchKernelGGL(k_comp_lu<3>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
+                                   A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
+            else
+                hipLaunchKernelGGL(k_comp_lu<2>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
+                                   A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
+            FEM_HIP(hipGetLastError());
+            int hflag[2] = {0, 0};
+            flag.download(hflag, 2, s);
+            FEM_HIP(hipStreamSynchronize(s));
+            null_pivots = hflag[0];
+            failed = hflag[1] != 0;
+            return;
+        }
     }
     std::vector<int> perm = rcm_order(nn, ptr, adj);
     long long bwn = 0, bw_nat = 0;
@@ -670,6 +834,12 @@ void BandLU::solve(const double* b, double* x)
     fem_ctx ctx = A->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
+    if (batched) {
+        if (bs == 3) hipLaunchKernelGGL(k_comp_solve<3>, dim3(ncomp), dim3(64), 0, s, ncomp, comp_ptr.p, comp_nodes.p, fac_off.p, fac.p, ipiv.p, b, x);
+        else hipLaunchKernelGGL(k_comp_solve<2>, dim3(ncomp), dim3(64), 0, s, ncomp, comp_ptr.p, comp_nodes.p, fac_off.p, fac.p, ipiv.p, b, x);
+        FEM_HIP(hipGetLastError());
+        return;
+    }
     const unsigned g = cdiv((size_t)n, 256);
     hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);
     hipLaunchKernelGGL(k_band_lu_solve, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);

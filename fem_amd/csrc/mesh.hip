@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstring>
+#include <sched.h>
 #include <thread>
 
 #include "objects.h"
@@ -21,7 +22,16 @@ void host_ranges(long long n, F f)
     const int hc = (int)std::thread::hardware_concurrency();
     const int nt = (int)std::max<long long>(1, std::min<long long>(std::min(16, hc > 0 ? hc : 1), n / 65536));
     std::vector<std::thread> th;
-    for (int i = 1; i < nt; i++) th.emplace_back([=] { f(n * i / nt, n * (i + 1) / nt); });
+    // (a worker inherits the CPU mask of the calling thread, which an OpenMP runtime with OMP_PROC_BIND may have pinned to one
+    // core -- bench.py's process is such a case: give it every CPU the process may use)
+    for (int i = 1; i < nt; i++)
+        th.emplace_back([=] {
+            cpu_set_t all;
+            CPU_ZERO(&all);
+            for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &all);
+            (void)sched_setaffinity(0, sizeof(all), &all);
+            f(n * i / nt, n * (i + 1) / nt);
+        });
     f(0LL, n / nt);
     for (auto& t : th) t.join();
 }

@@ -253,14 +253,19 @@ def main():
     nrows, nnz, dev_bytes = prob.K.info()
     per_rank = None
     if world > 1:
-        # what every rank saw: solve time per step, CG iterations, bytes it sends per halo sum of w
-        halo_bytes = float(len(halo[2]) * mesh.pdim * 8) if halo is not None else 0.0
-        mine = torch.tensor([t_sol / args.steps * 1e3, float(its), t_asm / args.steps * 1e3, halo_bytes, float(len(halo[0]) if halo is not None else 0)],
-                            dtype=torch.float64, device="cuda")
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "t_solve_ms": float(v[0]), "cg_iterations": int(v[1]), "ms_per_cg_iteration": float(v[0]) / max(float(v[1]), 1.0),
-                     "t_assemble_ms": float(v[2]), "halo_bytes_per_exchange": float(v[3]), "neighbours": int(v[4])} for r, v in enumerate(allr)]
+        # what every rank saw: solve time per step, CG iterations, bytes it sends per halo sum of w (a collective of torch's own
+        # communicator, the same on every rank; should it fail on one, it fails on all and the line goes out without the table)
+        try:
+            halo_bytes = float(len(halo[2]) * mesh.pdim * 8) if halo is not None else 0.0
+            mine = torch.tensor([t_sol / args.steps * 1e3, float(its), t_asm / args.steps * 1e3, halo_bytes,
+                                 float(len(halo[0]) if halo is not None else 0)], dtype=torch.float64, device="cuda")
+            allr = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allr, mine)
+            per_rank = [{"rank": r, "t_solve_ms": float(v[0]), "cg_iterations": int(v[1]),
+                         "ms_per_cg_iteration": float(v[0]) / max(float(v[1]), 1.0), "t_assemble_ms": float(v[2]),
+                         "halo_bytes_per_exchange": float(v[3]), "neighbours": int(v[4])} for r, v in enumerate(allr)]
+        except Exception as e:  # noqa: BLE001
+            per_rank = [{"error": repr(e)[:200]}]
     # global DOF count of the whole job (shared interface nodes counted once)
     if hex_case:
         gn = [grid[d] * args.n + 1 for d in range(3)]

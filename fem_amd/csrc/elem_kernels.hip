@@ -431,8 +431,14 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
 #pragma unroll
     for (int b = 0; b < NPE; b++) {
         const size_t v = (size_t)gv.conn[e * NPE + b];
-#pragma unroll
-        for (int d = 0; d < PD; d++) X[b][d] = coords[v * PD + d];
+        if constexpr (PD == 3) {   // one 16 B and one 8 B load per node (8 B aligned)
+            struct alignas(8) P3 { double a, b, c; };
+            const P3 t = *reinterpret_cast<const P3*>(coords + v * 3);
+            X[b][0] = t.a; X[b][1] = t.b; X[b][2] = t.c;
+        } else {
+            const double2 t = reinterpret_cast<const double2*>(coords)[v];
+            X[b][0] = t.x; X[b][1] = t.y;
+        }
     }
 #pragma unroll
     for (int b = 0; b < NPE; b++)

@@ -47,10 +47,10 @@ FP64_PEAK_TFLOPS = 78.6
 # fp64 work of the element-by-element hex8 kernels AS COMPILED, per element (tile kernels: per element visit):
 # (fp64 vector instructions, flops with fma = 2, all vector instructions) -- tools/count_ebe_flops.py prints them
 EBE_WORK = {
-    "k_ebe_tile_x<cartesian>": (286, 336, 467),  # one-pass tiles of a mesh of axis-aligned bricks, x of the tile in LDS (three
+    "k_ebe_tile_x<cartesian>": (286, 336, 468),  # one-pass tiles of a mesh of axis-aligned bricks, x of the tile in LDS (three
                                                   # workgroups per CU)
-    "k_ebe_tile<cartesian>": (281, 349, 513),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
-    "k_ebe_tile<affine>": (475, 658, 717),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
+    "k_ebe_tile<cartesian>": (281, 349, 515),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
+    "k_ebe_tile<affine>": (475, 658, 719),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
     "k_ebe_tile<general>": (1503, 2217, 1850),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
     "k_ebe_apply<3,8,8,3>": (567, 789, 689),   # element buffer + gather, parallelepipeds
     "k_ebe_apply<3,8,8,1>": (1503, 2217, 1669),  # element buffer + gather, distorted elements
@@ -329,7 +329,8 @@ def main():
         return None
 
     bsz = 3 if hex_case else 2
-    spmv_name = f"k_spmv_sell<{bsz}>"
+    # (second template argument: the matrix stream bypasses the caches when it is larger than the Infinity Cache, mat.hip)
+    spmv_name = f"k_spmv_sell<{bsz}, {'true' if dev_bytes > (200 << 20) else 'false'}>"
 
     def spmv_roofline(avg_ms, launches, where):
         alg = spmv_algorithmic_bytes(nnz, nrows)

@@ -78,6 +78,18 @@ __device__ __forceinline__ double row_prev(double x)
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x111, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// The tile lists (slot records, flags, stored geometry, node lists) are read exactly once per product, 57 B per lane slot = 260 MB at
+// config 3, beside 2 x 81 MB of x and y that the CG's vector kernels want to find in the L2 / Infinity Cache again: the lists are
+// loaded with the streaming hint (global_load ... nt).  Config 3: product 0.1384 -> 0.1296 ms, CG iteration 0.2782 -> 0.2710 ms (and
+// 0.2572 with the hints of the CG's own kernels, ksp.hip); a mesh small enough for the caches to hold everything: unchanged.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ uint4 ld_stream(const uint4* p)
+{
+    const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+    return make_uint4(c.x, c.y, c.z, c.w);
+}
 // stage 1 (three steps ahead): the lane's slot from the tile lists -- plain global loads, nothing depends on them yet
 struct TileRaw {
     uint4 c16;
@@ -92,9 +104,9 @@ __device__ __forceinline__ void tile_fetch_raw(TileRaw& rw, bool inside, size_t 
 {
     rw.valid = false; rw.fl = 0;
     if (!inside) return;
-    const int e = telems[k];
-    rw.c16 = tconn[k];
-    rw.fl = tflags[k];
+    const int e = ld_stream(telems + k);
+    rw.c16 = ld_stream(tconn + k);
+    rw.fl = ld_stream(tflags + k);
     if (e < 0) return;   // padding of a 16-lane row
     rw.valid = true;
     if constexpr (!AFFINE) { rw.E = Ev[e]; rw.nu = nuv[e]; }
@@ -127,7 +139,7 @@ __device__ __forceinline__ void tile_fetch_data(TileData& dt, const TileIdx& in,
 {
     if (!in.valid) return;
 #pragma unroll
-    for (int j = 0; j < NG; j++) dt.geo[j] = geo[(size_t)j * geo_stride + k];
+    for (int j = 0; j < NG; j++) dt.geo[j] = ld_stream(geo + (size_t)j * geo_stride + k);
 #pragma unroll
     for (int i = 0; i < 4; i++) load_node3(dt.u[c_tminus[i]], x, in.v[c_tminus[i]]);
     if (!(in.fl & 1u)) {
@@ -245,7 +257,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     {   // node list -> LDS, sums zeroed (all loads of a lane in flight together: TILE_MAX_NODES <= 12 * 256)
         int nv[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -415,7 +427,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     {   // stage in: node list, x -> LDS, sums zeroed (all loads of a lane in flight together)
         double xv[NPT][3];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {   // a node's three values as one 16 B and one 8 B load (a third fewer trips through the address unit)
             const int i = threadIdx.x + 256 * j;
@@ -447,10 +459,10 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
         if ((int)threadIdx.x >= cnt) return;
         const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = tconn[k];
-        q.fl = tflags[k];
+        q.c16 = ld_stream(tconn + k);
+        q.fl = ld_stream(tflags + k);
 #pragma unroll
-        for (int j = 0; j < NG; j++) q.geo[j] = geo[(size_t)j * geo_stride + k];
+        for (int j = 0; j < NG; j++) q.geo[j] = ld_stream(geo + (size_t)j * geo_stride + k);
     };
     // corner values of a step's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
@@ -569,7 +581,7 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
     {
         double xv[NPT][3];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -598,12 +610,12 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
         const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
         if ((int)threadIdx.x >= cnt) return;
         const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = tconn[k];
-        q.fl = tflags[k];
-        const int e = telems[k];
+        q.c16 = ld_stream(tconn + k);
+        q.fl = ld_stream(tflags + k);
+        const int e = ld_stream(telems + k);
 #pragma unroll
-        for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + k];
-        q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + k];
+        for (int j = 0; j < NA; j++) q.a[j] = ld_stream(geo + (size_t)j * geo_stride + k);
+        q.mw = ld_stream(geo + (size_t)(KIND == 2 ? 4 : 10) * geo_stride + k);
         q.E = (e >= 0) ? Ev[e] : 1.0; q.nu = (e >= 0) ? nuv[e] : 0.25;
     };
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
@@ -742,7 +754,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
     {
         int nv[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -759,10 +771,10 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
         const int2 st = steps[step_off + s];
         if ((int)threadIdx.x >= (st.y & 0x7fffffff)) return;
         const size_t k = (size_t)elem_off + st.x + threadIdx.x;
-        const int e = telems[k];
+        const int e = ld_stream(telems + k);
         if (e < 0) return;
-        el.c16 = tconn[k];
-        el.fl = tflags[k];
+        el.c16 = ld_stream(tconn + k);
+        el.fl = ld_stream(tflags + k);
         el.E = Ev[e]; el.nu = nuv[e];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
@@ -873,7 +885,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     {
         double xv[NPT][2], cv[NPT][2];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -902,9 +914,9 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
         const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
         if ((int)threadIdx.x >= cnt) return;
         const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = tconn[k];
-        q.fl = tflags[k];
-        q.lam = geo[k]; q.mu = geo[geo_stride + k];
+        q.c16 = ld_stream(tconn + k);
+        q.fl = ld_stream(tflags + k);
+        q.lam = ld_stream(geo + k); q.mu = ld_stream(geo + geo_stride + k);
     };
     auto read_corners = [&](double (&X)[4][2], double (&u)[4][2], const Slot& q) {
         const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;

@@ -206,15 +206,23 @@ __device__ __forceinline__ CgOpen cg_open_logic(int i, double zz, double zr, dou
 __device__ __forceinline__ double cg_z(double dinv, double r) { return __dmul_rn(dinv, r); }
 __device__ __forceinline__ double cg_p(double z, double b, double p) { return __fma_rn(b, p, z); }
 
+// STREAM (problems whose vectors and tile lists do not fit the 256 MB Infinity Cache): what an iteration does not look at again
+// before the cache has turned over -- x (read and written once per iteration) and w = K p (read once) -- moves with the streaming
+// hint, so that p, r and dinv are what the caches keep.  Config 3: 0.2782 -> 0.2572 ms per iteration together with the tile lists
+// (ebe_tile.hip); at 1 M dofs, where everything fits, the same hints cost 4-8 % -- hence the switch (cg_streams()).
+template <bool STREAM> __device__ __forceinline__ double ld_once(const double* p) { return STREAM ? __builtin_nontemporal_load(p) : *p; }
+template <bool STREAM> __device__ __forceinline__ void st_once(double v, double* p) { if (STREAM) __builtin_nontemporal_store(v, p); else *p = v; }
+
 // Convergence test (KSPConvergedDefault) + beta, then p = M^-1 r + b p.
 // `it` = iterations completed so far.
+template <bool STREAM>
 __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restrict__ st,
                                                      const double* __restrict__ pzz, const double* __restrict__ pzr,
                                                      int npart, double rtol, double abstol, double dtol, int maxit,
                                                      double* __restrict__ hist, int hist_len,
                                                      const double* __restrict__ dinv, const double* __restrict__ r,
                                                      double* __restrict__ p, const double* __restrict__ zext,
-                                                     double* __restrict__ x)
+                                                     double* __restrict__ x, int descending)
 {
     // (not st->done: this kernel's own verdict sets it while other workgroups are still starting, and every workgroup owes
     // the last x += a p; `stop` is only ever written by the x / r update that follows)
@@ -253,10 +261,24 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
         return;
     }
     if (zext) { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = cg_p(zext[q], b, pq); } }   // z = M^-1 r applied by a separate PC
-    else { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = cg_p(cg_z(dinv[q], r[q]), b, pq); } }
+    else if (descending) {   // (x is not looked at again before the next iteration's update: streaming load and store)
+        for (; q < n; q += str) {
+            const size_t j = n - 1 - q;
+            const double pq = p[j];
+            st_once<STREAM>(ld_once<STREAM>(x + j) + aprev * pq, x + j);
+            p[j] = cg_p(cg_z(dinv[j], r[j]), b, pq);
+        }
+    } else {
+        for (; q < n; q += str) {
+            const double pq = p[q];
+            st_once<STREAM>(ld_once<STREAM>(x + q) + aprev * pq, x + q);
+            p[q] = cg_p(cg_z(dinv[q], r[q]), b, pq);
+        }
+    }
 }
 
 // alpha = beta / p.w, then r -= a w ; z = M^-1 r ; partials of z.z and z.r  (x += a p: see k_cg_update_p)
+template <bool STREAM>
 __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState* __restrict__ st,
                                                       const double* __restrict__ ppw, int npart,
                                                       const double* __restrict__ dinv, const double* __restrict__ w,
@@ -292,7 +314,7 @@ __global__ void __launch_bounds__(256) k_cg_update_xr(size_t n, int pd, KspState
         return;
     }
     for (; q < n; q += str) {
-        const double ri = r[q] - a * w[q];
+        const double ri = r[q] - a * ld_once<STREAM>(w + q);   // (w = K p is not read again)
         r[q] = ri;
         const double zi = cg_z(dinv[q], ri);
         if (!owned || owned[q / pd]) { zz += zi * zi; zr += zi * ri; }
@@ -672,11 +694,19 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // (FEM_AMD_REDUCE_PW_MIN: from how many partials on the separate reduction kernel is used; measurement)
     static const int pw_min = std::getenv("FEM_AMD_REDUCE_PW_MIN") ? std::atoi(std::getenv("FEM_AMD_REDUCE_PW_MIN")) : 2048;
     const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > pw_min;
+    // the p update walks the vectors from the tail: the x / r update before it ended there, so the tail of r and of dinv is what the
+    // Infinity Cache still holds (0.2711 -> 0.2704 ms per iteration at config 3; no sums in that kernel, so not a bit changes)
+    // (FEM_AMD_STREAM_MIN_DOF: from how many dofs per domain on x and w move with the streaming hint; measurement)
+    static const long long stream_min = std::getenv("FEM_AMD_STREAM_MIN_DOF") ? std::atoll(std::getenv("FEM_AMD_STREAM_MIN_DOF")) : 8000000LL;   // (5.3 M dofs: 0.1532 with, 0.1512 without; 10.1 M: 0.2577 / 0.2684)
+    const bool streams = (long long)n >= stream_min;
+    const auto kern_p = streams ? k_cg_update_p<true> : k_cg_update_p<false>;
+    const auto kern_xr = streams ? k_cg_update_xr<true> : k_cg_update_xr<false>;
+    static const int p_desc = std::getenv("FEM_AMD_CG_P_DESC") ? std::atoi(std::getenv("FEM_AMD_CG_P_DESC")) : 1;
     int queued = 0;   // iterations enqueued so far (the profile samples iteration j * period)
     auto one_iteration = [&] {
-        hipLaunchKernelGGL(k_cg_update_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
+        hipLaunchKernelGGL(kern_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
-                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr, x->d.p);
+                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr, x->d.p, p_desc);
         const bool sample = k->profiling > 0 && (queued % k->profiling) == 0;
         queued++;
         if (sample) FEM_HIP(hipEventRecord(next_event(), s));
@@ -693,7 +723,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
             FEM_HIP(hipEventRecord(cx->ev_c, cs));
             comm->allreduce_sum(&st->red[2], 1, s);                                   // p.Kp over the domains
             FEM_HIP(hipStreamWaitEvent(s, cx->ev_c, 0));
-            hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st, (const double*)nullptr, A->spmv_grid,
+            hipLaunchKernelGGL(kern_xr, dim3(g), dim3(256), 0, s, n, pd, st, (const double*)nullptr, A->spmv_grid,
                                mg ? (const double*)nullptr : k->dinv.p, k->w.p, k->r.p, owned, k->pzz.p, k->pzr.p);
             if (mg) apply_pc_and_dots();
             reduce_zz_zr();
@@ -712,7 +742,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
                 halo_sum(A->mesh, k->w.p, pd, pd, 1);
             }
         }
-        hipLaunchKernelGGL(k_cg_update_xr, dim3(g), dim3(256), 0, s, n, pd, st,
+        hipLaunchKernelGGL(kern_xr, dim3(g), dim3(256), 0, s, n, pd, st,
                            reduce_pw_first ? nullptr : A->spmv_partial.p, A->spmv_grid,
                            mg ? (const double*)nullptr : k->dinv.p, k->w.p, k->r.p, owned, k->pzz.p, k->pzr.p);
         if (mg) apply_pc_and_dots();

@@ -130,7 +130,7 @@ __global__ void __launch_bounds__(256) k_cg_init(size_t n, int pd, const double*
     const size_t st = (size_t)gridDim.x * blockDim.x;
     double zz = 0.0, zr = 0.0;
     for (; i < n; i += st) {
-        const double ri = b[i], zi = dinv[i] * ri;
+        const double ri = b[i], zi = __dmul_rn(dinv[i], ri);
         x[i] = 0.0; r[i] = ri; p[i] = 0.0;
         if (!owned || owned[i / pd]) { zz += zi * zi; zr += zi * ri; }
     }
@@ -260,20 +260,13 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
         else { for (; q < n; q += str) p[q] = cg_z(dinv[q], r[q]); }
         return;
     }
-    if (zext) { for (; q < n; q += str) { const double pq = p[q]; x[q] += aprev * pq; p[q] = cg_p(zext[q], b, pq); } }   // z = M^-1 r applied by a separate PC
-    else if (descending) {   // (x is not looked at again before the next iteration's update: streaming load and store)
-        for (; q < n; q += str) {
-            const size_t j = n - 1 - q;
-            const double pq = p[j];
-            st_once<STREAM>(ld_once<STREAM>(x + j) + aprev * pq, x + j);
-            p[j] = cg_p(cg_z(dinv[j], r[j]), b, pq);
-        }
-    } else {
-        for (; q < n; q += str) {
-            const double pq = p[q];
-            st_once<STREAM>(ld_once<STREAM>(x + q) + aprev * pq, x + q);
-            p[q] = cg_p(cg_z(dinv[q], r[q]), b, pq);
-        }
+    // z: a vector (the preconditioner is a separate kernel) or dinv * r on the fly;
+    // x is not looked at again before the next iteration's update: streaming load and store
+    for (; q < n; q += str) {
+        const size_t j = descending ? n - 1 - q : q;
+        const double pq = p[j];
+        st_once<STREAM>(ld_once<STREAM>(x + j) + aprev * pq, x + j);
+        p[j] = cg_p(zext ? zext[j] : cg_z(dinv[j], r[j]), b, pq);
     }
 }
 
@@ -388,6 +381,7 @@ struct fem_ksp_s {
     std::unique_ptr<fem::BandLU> direct_lu;      // the same on a Mat flagged unsymmetric (Newton Jacobian)
     DBuf<double> bcgs_work;                      // -ksp_type bcgs: r, r', v, t, s, p, A*in scratch
     bool mg_additive = false;
+    long long stream_min_dof = -1;           // -ksp_stream_min_dof n: streaming hints + stored z from n dofs per domain on; -1: FEM_AMD_STREAM_MIN_DOF / 8 M
     int halo_overlap = -1;                   // -ksp_halo_overlap 0|1: the exchange beside the interior tiles; -1: FEM_AMD_OVERLAP
     int fuse_allreduce = -1;                 // -ksp_fuse_allreduce 0|1: p.Kp all-reduce in the RCCL group of the halo exchange; -1: FEM_AMD_FUSE_ALLREDUCE
     double mg_box = 4.0;                     // level-1 box edge in mean node spacings
@@ -449,6 +443,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-ksp_divtol") { is >> k->dtol; }
         else if (key == "-ksp_max_it") { is >> k->maxit; }
         else if (key == "-ksp_fuse_allreduce") { is >> k->fuse_allreduce; FEM_CHECK(k->fuse_allreduce == 0 || k->fuse_allreduce == 1, 6, "-ksp_fuse_allreduce 0|1"); }
+        else if (key == "-ksp_stream_min_dof") { is >> k->stream_min_dof; FEM_CHECK(k->stream_min_dof >= 0, 6, "-ksp_stream_min_dof n >= 0"); }
         else if (key == "-ksp_halo_overlap") { is >> k->halo_overlap; FEM_CHECK(k->halo_overlap == 0 || k->halo_overlap == 1, 6, "-ksp_halo_overlap 0|1"); }
         else if (key == "-ksp_norm_type") { is >> val; FEM_CHECK(val == "preconditioned", 6, "only -ksp_norm_type preconditioned"); }
         else if (key == "-pc_factor_mat_solver_package" || key == "-pc_factor_mat_solver_type") { is >> val; }  // one built-in factorisation
@@ -647,6 +642,9 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
 
     FEM_HIP(hipMemsetAsync(st, 0, sizeof(KspState), s));
     fem::Multigrid* mg = k->mg.get();   // external preconditioner: z is a vector produced by a V-cycle
+    // (FEM_AMD_STREAM_MIN_DOF: from how many dofs per domain on x and w move with the streaming hint; measurement)
+    static const long long stream_min = std::getenv("FEM_AMD_STREAM_MIN_DOF") ? std::atoll(std::getenv("FEM_AMD_STREAM_MIN_DOF")) : 8000000LL;   // (5.3 M dofs: 0.1532 with, 0.1512 without; 10.1 M: 0.2577 / 0.2684)
+    const bool streams = (long long)n >= (k->stream_min_dof >= 0 ? k->stream_min_dof : stream_min);
     auto apply_pc_and_dots = [&] {
         if (mg->fuses_dots() && !owned) {
             mg->apply(k->r.p, k->z.p, &st->done, k->pzz.p, k->pzr.p, (int)g);
@@ -696,9 +694,6 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > pw_min;
     // the p update walks the vectors from the tail: the x / r update before it ended there, so the tail of r and of dinv is what the
     // Infinity Cache still holds (0.2711 -> 0.2704 ms per iteration at config 3; no sums in that kernel, so not a bit changes)
-    // (FEM_AMD_STREAM_MIN_DOF: from how many dofs per domain on x and w move with the streaming hint; measurement)
-    static const long long stream_min = std::getenv("FEM_AMD_STREAM_MIN_DOF") ? std::atoll(std::getenv("FEM_AMD_STREAM_MIN_DOF")) : 8000000LL;   // (5.3 M dofs: 0.1532 with, 0.1512 without; 10.1 M: 0.2577 / 0.2684)
-    const bool streams = (long long)n >= stream_min;
     const auto kern_p = streams ? k_cg_update_p<true> : k_cg_update_p<false>;
     const auto kern_xr = streams ? k_cg_update_xr<true> : k_cg_update_xr<false>;
     static const int p_desc = std::getenv("FEM_AMD_CG_P_DESC") ? std::atoi(std::getenv("FEM_AMD_CG_P_DESC")) : 1;

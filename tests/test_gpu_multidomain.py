@@ -252,3 +252,13 @@ def test_allreduce_inside_the_halo_group_gives_the_same_fields():
     for (ua, sa, ia, ra, ya, ga), (ub, sb, ib, rb, yb, gb) in zip(a, b):
         assert ia == ib and ra == rb > 0
         assert np.array_equal(ua, ub) and np.array_equal(sa, sb)
+
+
+def test_streaming_cg_on_domains_gives_the_same_fields():
+    """-ksp_stream_min_dof 0 forces what problems beyond the Infinity Cache get (x and K p with the streaming hint) on four small
+    domains: bitwise the fields of the default kernels."""
+    a = _run_domains(4, (5, 4, 3), 0.1, "-mat_mult_type ebe -ksp_rtol 1e-12")[1]
+    b = _run_domains(4, (5, 4, 3), 0.1, "-mat_mult_type ebe -ksp_rtol 1e-12 -ksp_stream_min_dof 0")[1]
+    for (ua, sa, ia, ra, ya, ga), (ub, sb, ib, rb, yb, gb) in zip(a, b):
+        assert ia == ib and ra == rb > 0
+        assert np.array_equal(ua, ub) and np.array_equal(sa, sb)

@@ -177,3 +177,16 @@ def test_medium_cube_solution_matches_oracle(gpu_ctx, oracle, n, jitter):
     assert np.abs(res.aggregate_u - u).max() <= 1e-10 * np.abs(u).max()
     assert np.abs(res.aggregate_stress - s).max() <= 1e-10 * np.abs(s).max()
     assert abs(res.its[-1] - its[-1]) <= max(3, its[-1] // 50)
+
+
+@pytest.mark.parametrize("opts", ["", "-mat_mult_type ebe", "-mat_mult_type ebe_gather"])
+@pytest.mark.parametrize("n,jitter", [((9, 8, 7), 0.0), ((7, 6, 5), 0.2)])
+def test_streaming_cg_is_bitwise_the_default_cg(gpu_ctx, opts, n, jitter):
+    """Problems larger than the Infinity Cache run the CG with the once-per-iteration vectors (x, K p) moved with the streaming
+    hint (ksp.hip, -ksp_stream_min_dof / FEM_AMD_STREAM_MIN_DOF): forced on a small mesh, the same iterations and fields to the bit."""
+    m = structured_hex(*n, jitter=jitter)
+    a = driver.run(m, f"-ksp_rtol 1e-12 {opts}", ctx=gpu_ctx)
+    b = driver.run(m, f"-ksp_rtol 1e-12 {opts} -ksp_stream_min_dof 0", ctx=gpu_ctx)
+    assert a.reasons == b.reasons and a.reasons[-1] > 0 and a.its == b.its
+    assert np.array_equal(a.aggregate_u, b.aggregate_u)
+    assert np.array_equal(a.aggregate_stress, b.aggregate_stress)

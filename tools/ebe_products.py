@@ -20,8 +20,14 @@ X, Y = capi.Vec(ctx, m.ndof), capi.Vec(ctx, m.ndof)
 X.set_array(np.sin(0.001 * np.arange(m.ndof)))
 print("avg product ms", prob.K.mult_timed(X, Y, reps), flush=True)
 S = capi.Vec(ctx, m.nnds * 6)
+import time  # noqa: E402
 for _ in range(3):                      # nodal stress over the tiles (k_tile_stress_cart on this mesh of bricks)
     prob.dmesh.recover_nodal_stress_vec(X, S)
 ctx.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    prob.dmesh.recover_nodal_stress_vec(X, S)
+ctx.synchronize()
+print("avg nodal stress ms", (time.perf_counter() - t0) * 1e3 / 20, flush=True)
 S.destroy()
 prob.destroy(); ctx.destroy()

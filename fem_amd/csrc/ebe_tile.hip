@@ -79,16 +79,22 @@ __device__ __forceinline__ double row_prev(double x)
     return __hiloint2double(hi, lo);
 }
 // The tile lists (slot records, flags, stored geometry, node lists) are read exactly once per product, 57 B per lane slot = 260 MB at
-// config 3, beside 2 x 81 MB of x and y that the CG's vector kernels want to find in the L2 / Infinity Cache again: the lists are
-// loaded with the streaming hint (global_load ... nt).  Config 3: product 0.1384 -> 0.1296 ms, CG iteration 0.2782 -> 0.2710 ms (and
-// 0.2572 with the hints of the CG's own kernels, ksp.hip); a mesh small enough for the caches to hold everything: unchanged.
+// config 3, beside 2 x 81 MB of x and y that the CG's vector kernels want to find in the L2 / Infinity Cache again: on a plan whose
+// lists and vectors do not fit those caches (EbeTilePlan::stream) the product kernels of hex8 meshes load the lists with the streaming
+// hint (global_load ... nt).  Config 3: product 0.1384 -> 0.1296 ms, CG iteration 0.2782 -> 0.2710 ms (0.2572 with the hints of the
+// CG's own kernels, ksp.hip).  Where everything fits, the next product finds the lists in the cache and the hint costs: 100^3
+// elements 0.0443 -> 0.0488 ms per product, config 2 42.6 -> 44.5 us per iteration -- hence plain loads there.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <class T>
-__device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ uint4 ld_stream(const uint4* p)
+template <bool STREAM, class T>
+__device__ __forceinline__ T ld_list(const T* p) { if constexpr (STREAM) return __builtin_nontemporal_load(p); else return *p; }
+template <bool STREAM>
+__device__ __forceinline__ uint4 ld_list(const uint4* p)
 {
-    const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
-    return make_uint4(c.x, c.y, c.z, c.w);
+    if constexpr (!STREAM) return *p;
+    else {
+        const u32x4 c = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(c.x, c.y, c.z, c.w);
+    }
 }
 // stage 1 (three steps ahead): the lane's slot from the tile lists -- plain global loads, nothing depends on them yet
 struct TileRaw {
@@ -97,16 +103,16 @@ struct TileRaw {
     unsigned fl;
     bool valid;
 };
-template <bool AFFINE>
+template <bool AFFINE, bool STREAM>
 __device__ __forceinline__ void tile_fetch_raw(TileRaw& rw, bool inside, size_t k, const int* __restrict__ telems,
                                                const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
                                                const double* __restrict__ Ev, const double* __restrict__ nuv)
 {
     rw.valid = false; rw.fl = 0;
     if (!inside) return;
-    const int e = ld_stream(telems + k);
-    rw.c16 = ld_stream(tconn + k);
-    rw.fl = ld_stream(tflags + k);
+    const int e = ld_list<STREAM>(telems + k);
+    rw.c16 = ld_list<STREAM>(tconn + k);
+    rw.fl = ld_list<STREAM>(tflags + k);
     if (e < 0) return;   // padding of a 16-lane row
     rw.valid = true;
     if constexpr (!AFFINE) { rw.E = Ev[e]; rw.nu = nuv[e]; }
@@ -133,13 +139,13 @@ __device__ __forceinline__ void load_node3(double (&o)[3], const double* __restr
 }
 // loads of one element: -x face nodes always, +x face nodes where the chain ends (the others come from the next lane, see
 // tile_complete)
-template <int NG>
+template <int NG, bool STREAM>
 __device__ __forceinline__ void tile_fetch_data(TileData& dt, const TileIdx& in, size_t k, const double* __restrict__ geo,
                                                 size_t geo_stride, const double* __restrict__ x)
 {
     if (!in.valid) return;
 #pragma unroll
-    for (int j = 0; j < NG; j++) dt.geo[j] = ld_stream(geo + (size_t)j * geo_stride + k);
+    for (int j = 0; j < NG; j++) dt.geo[j] = ld_list<STREAM>(geo + (size_t)j * geo_stride + k);
 #pragma unroll
     for (int i = 0; i < 4; i++) load_node3(dt.u[c_tminus[i]], x, in.v[c_tminus[i]]);
     if (!(in.fl & 1u)) {
@@ -227,7 +233,7 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
 // of one colour, a barrier behind the last round of a colour
 // OP 0: y = K x.  OP 1, 2: the nodal stress sums of RecoverNodalStress + src/main.F90:258-279 over the same tiles (x = the
 // displacements; y = component 0 / 3 of stress_node(nnds, 6), column-major; divided by the valence where one is given)
-template <int KIND, int OP = 0>   // 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal)
+template <int KIND, int OP = 0, bool STREAM = false>   // KIND 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal); STREAM: see ld_list
 __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ lhdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
@@ -257,7 +263,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     {   // node list -> LDS, sums zeroed (all loads of a lane in flight together: TILE_MAX_NODES <= 12 * 256)
         int nv[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
+        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_list<STREAM>(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -269,7 +275,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     auto raw_of = [&](TileRaw& rw, int s) {
         const bool have = s < nsteps;
         const int2 st = have ? steps[step_off + s] : make_int2(0, 0);
-        tile_fetch_raw<AFFINE>(rw, have && (int)threadIdx.x < (st.y & 0x7fffffff), (size_t)elem_off + st.x + threadIdx.x, telems,
+        tile_fetch_raw<AFFINE, STREAM>(rw, have && (int)threadIdx.x < (st.y & 0x7fffffff), (size_t)elem_off + st.x + threadIdx.x, telems,
                                tconn, tflags, Ev, nuv);
     };
     TileRaw r2, r3;            // steps s + 2, s + 3
@@ -279,13 +285,13 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     raw_of(r2, 1); tile_resolve(i1, r2, gl);
     raw_of(r2, 2);
     constexpr int NG = KIND == 2 ? 5 : 11;
-    if constexpr (AFFINE) tile_fetch_data<NG>(d0, i0, pos_of(0), geo, geo_stride, x);
+    if constexpr (AFFINE) tile_fetch_data<NG, STREAM>(d0, i0, pos_of(0), geo, geo_stride, x);
     auto do_step = [&](int s, TileData& dcur, TileData& dnext) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
             raw_of(r3, s + 3);
             tile_resolve(i2, r2, gl);
-            tile_fetch_data<NG>(dnext, i1, pos_of(s + 1), geo, geo_stride, x);
+            tile_fetch_data<NG, STREAM>(dnext, i1, pos_of(s + 1), geo, geo_stride, x);
         }
         // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
         double fe[8][3], dot;
@@ -398,7 +404,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 // of every wavefront (v_readlane: nothing waits for a scalar load).  The LDS adds of a step are issued BEHIND the barrier
 // that closes the previous colour and the next step's corner values are read ahead of it (x is read-only), so the adds run
 // under the next step's arithmetic; contributions to rim nodes are not added at all (their sums belong to other tiles).
-template <int KIND>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two)
+template <int KIND, bool STREAM = false>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two)
 __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist, const int* __restrict__ lhdr,
                                                        const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                        const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
@@ -427,7 +433,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     {   // stage in: node list, x -> LDS, sums zeroed (all loads of a lane in flight together)
         double xv[NPT][3];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_list<STREAM>(tnodes + node_off + i) : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {   // a node's three values as one 16 B and one 8 B load (a third fewer trips through the address unit)
             const int i = threadIdx.x + 256 * j;
@@ -459,10 +465,10 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
         if ((int)threadIdx.x >= cnt) return;
         const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = ld_stream(tconn + k);
-        q.fl = ld_stream(tflags + k);
+        q.c16 = ld_list<STREAM>(tconn + k);
+        q.fl = ld_list<STREAM>(tflags + k);
 #pragma unroll
-        for (int j = 0; j < NG; j++) q.geo[j] = ld_stream(geo + (size_t)j * geo_stride + k);
+        for (int j = 0; j < NG; j++) q.geo[j] = ld_list<STREAM>(geo + (size_t)j * geo_stride + k);
     };
     // corner values of a step's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
@@ -581,7 +587,7 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
     {
         double xv[NPT][3];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -610,12 +616,12 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
         const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
         if ((int)threadIdx.x >= cnt) return;
         const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = ld_stream(tconn + k);
-        q.fl = ld_stream(tflags + k);
-        const int e = ld_stream(telems + k);
+        q.c16 = tconn[k];
+        q.fl = tflags[k];
+        const int e = telems[k];
 #pragma unroll
-        for (int j = 0; j < NA; j++) q.a[j] = ld_stream(geo + (size_t)j * geo_stride + k);
-        q.mw = ld_stream(geo + (size_t)(KIND == 2 ? 4 : 10) * geo_stride + k);
+        for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + k];
+        q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + k];
         q.E = (e >= 0) ? Ev[e] : 1.0; q.nu = (e >= 0) ? nuv[e] : 0.25;
     };
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
@@ -754,7 +760,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
     {
         int nv[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
+        for (int j = 0; j < 12; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -771,10 +777,10 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
         const int2 st = steps[step_off + s];
         if ((int)threadIdx.x >= (st.y & 0x7fffffff)) return;
         const size_t k = (size_t)elem_off + st.x + threadIdx.x;
-        const int e = ld_stream(telems + k);
+        const int e = telems[k];
         if (e < 0) return;
-        el.c16 = ld_stream(tconn + k);
-        el.fl = ld_stream(tflags + k);
+        el.c16 = tconn[k];
+        el.fl = tflags[k];
         el.E = Ev[e]; el.nu = nuv[e];
 #pragma unroll
         for (int a = 0; a < 4; a++) {
@@ -885,7 +891,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     {
         double xv[NPT][2], cv[NPT][2];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_stream(tnodes + node_off + i) : 0; }
+        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -914,9 +920,9 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
         const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
         if ((int)threadIdx.x >= cnt) return;
         const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = ld_stream(tconn + k);
-        q.fl = ld_stream(tflags + k);
-        q.lam = ld_stream(geo + k); q.mu = ld_stream(geo + geo_stride + k);
+        q.c16 = tconn[k];
+        q.fl = tflags[k];
+        q.lam = geo[k]; q.mu = geo[geo_stride + k];
     };
     auto read_corners = [&](double (&X)[4][2], double (&u)[4][2], const Slot& q) {
         const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
@@ -1141,8 +1147,18 @@ void ebe_tile_store_geometry(fem_mesh m, EbeTilePlan& P, const unsigned char* d_
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
 {
     const char* how = std::getenv("FEM_AMD_TILE_PLAN");
-    if (how && std::string(how) == "host") return ebe_tile_build_host(m, s);
-    return ebe_tile_build_device(m, s);
+    std::shared_ptr<EbeTilePlan> P = (how && std::string(how) == "host") ? ebe_tile_build_host(m, s) : ebe_tile_build_device(m, s);
+    if (P) {
+        // what one CG iteration walks through: the lists (slot records, flags, stored geometry, node lists) and five vectors, against
+        // the 256 MB Infinity Cache (FEM_AMD_TILE_STREAM_MIN_MB: the threshold; measured -- 203 MB, 100^3 elements: plain loads 0.0443 ms
+        // per product, streaming 0.0488; 348 MB, 120^3: 0.0790 / 0.0755; 665 MB, config 3: 0.1291 / 0.1229)
+        const double min_mb = std::getenv("FEM_AMD_TILE_STREAM_MIN_MB") ? std::atof(std::getenv("FEM_AMD_TILE_STREAM_MIN_MB")) : 256.0;
+        const double geo_words = P->geo.p ? (m->pdim == 2 ? 2.0 : (P->n_aff ? 11.0 : 5.0)) : 0.0;
+        const double lists = (double)P->slots * (21.0 + 8.0 * geo_words) + 4.0 * (double)P->tile_nodes;
+        const double vectors = 5.0 * 8.0 * (double)m->nnds * m->pdim;
+        P->stream = (lists + vectors) > min_mb * 1048576.0;
+    }
+    return P;
 }
 
 // The host builder (worker threads over contiguous ranges of boxes; the mesh is copied to the host first).
@@ -1611,7 +1627,8 @@ static void hex_tile_kernel_attributes(int device)
     if (!once.first(device)) return;
     for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile<0>), reinterpret_cast<const void*>(k_ebe_tile<1>),
                           reinterpret_cast<const void*>(k_ebe_tile<2>), reinterpret_cast<const void*>(k_ebe_tile<0, 1>),
-                          reinterpret_cast<const void*>(k_ebe_tile<0, 2>)})
+                          reinterpret_cast<const void*>(k_ebe_tile<0, 2>), reinterpret_cast<const void*>(k_ebe_tile<0, 0, true>),
+                          reinterpret_cast<const void*>(k_ebe_tile<1, 0, true>), reinterpret_cast<const void*>(k_ebe_tile<2, 0, true>)})
         FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
 }
 
@@ -1670,7 +1687,8 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
     if (x_env && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_LDS_NODES && P.max_nown <= TILE_X_MAX_OWN) {
         static OncePerDevice xonce;
         if (xonce.first(A->ctx->device))
-            for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>)})
+            for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>),
+                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
         auto gox = [&](auto kern, int n, const int* list) {
             if (!n) return;
@@ -1678,13 +1696,22 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                                x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done, rcount,
                                P.ntiles, A->red_out);
         };
-        gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
-        gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+        if (P.stream) {
+            gox(k_ebe_tile_x<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+            gox(k_ebe_tile_x<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+        } else {
+            gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+            gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+        }
+    } else if (P.stream) {
+        go(k_ebe_tile<2, 0, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+        go(k_ebe_tile<1, 0, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
     } else {
         go(k_ebe_tile<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
         go(k_ebe_tile<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
     }
-    go(k_ebe_tile<0>, g1 - g0, P.lhdr_gen.p + 8 * (size_t)g0);
+    if (P.stream) go(k_ebe_tile<0, 0, true>, g1 - g0, P.lhdr_gen.p + 8 * (size_t)g0);
+    else go(k_ebe_tile<0>, g1 - g0, P.lhdr_gen.p + 8 * (size_t)g0);
 }
 // stress_node(nnds, 6) of a hex8 mesh over the tiles of the product (RecoverNodalStress per element, the sum over the
 // elements of a node src/main.F90:258-268 in LDS, the division by the valence :277-279 on the way out): two passes of

@@ -692,8 +692,9 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // (FEM_AMD_REDUCE_PW_MIN: from how many partials on the separate reduction kernel is used; measurement)
     static const int pw_min = std::getenv("FEM_AMD_REDUCE_PW_MIN") ? std::atoi(std::getenv("FEM_AMD_REDUCE_PW_MIN")) : 2048;
     const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > pw_min;
-    // the p update walks the vectors from the tail: the x / r update before it ended there, so the tail of r and of dinv is what the
-    // Infinity Cache still holds (0.2711 -> 0.2704 ms per iteration at config 3; no sums in that kernel, so not a bit changes)
+    // on problems beyond the caches the p update walks the vectors from the tail: the x / r update before it ended there, so the tail
+    // of r and of dinv is what the Infinity Cache still holds (0.2711 -> 0.2704 ms per iteration at config 3; no sums in that kernel,
+    // so not a bit changes; at 1 M dofs, where everything is resident, 43.6 -> 44.5 us: ascending there)
     const auto kern_p = streams ? k_cg_update_p<true> : k_cg_update_p<false>;
     const auto kern_xr = streams ? k_cg_update_xr<true> : k_cg_update_xr<false>;
     static const int p_desc = std::getenv("FEM_AMD_CG_P_DESC") ? std::atoi(std::getenv("FEM_AMD_CG_P_DESC")) : 1;
@@ -701,7 +702,7 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     auto one_iteration = [&] {
         hipLaunchKernelGGL(kern_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
-                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr, x->d.p, p_desc);
+                           k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr, x->d.p, streams ? p_desc : 0);
         const bool sample = k->profiling > 0 && (queued % k->profiling) == 0;
         queued++;
         if (sample) FEM_HIP(hipEventRecord(next_event(), s));

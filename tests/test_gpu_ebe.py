@@ -408,3 +408,22 @@ def test_duplicate_bc_records_and_a_changed_list(gpu_ctx, oracle):
     assert (np.abs(Ye.get_array() - yr1) <= 1e-13 * rs1).all()
     for o in (X, Ya, Ye, F, K, dm):
         o.destroy()
+
+
+@pytest.mark.parametrize("name", ["hex_uniform", "hex_sheared", "hex_half_jitter", "hex_tiles", "hex_tiles_flat", "hex_graded"])
+def test_streaming_tile_kernels_give_the_same_product(gpu_ctx, name, monkeypatch):
+    """Plans whose lists and vectors exceed the caches run the hex8 product kernels with streaming loads of the tile lists
+    (EbeTilePlan::stream, FEM_AMD_TILE_STREAM_MIN_MB): forced on small meshes, bitwise the product of the plain kernels."""
+    m = _meshes()[name]
+    ys = []
+    for mb in ("1e9", "0"):
+        monkeypatch.setenv("FEM_AMD_TILE_STREAM_MIN_MB", mb)
+        prob = driver.Problem(gpu_ctx, m, "-mat_mult_type ebe")
+        prob.assemble(); prob.ksp.set_up()
+        X, Y = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof)
+        X.set_array(np.cos(0.37 * np.arange(m.ndof)))
+        prob.K.mult(X, Y)
+        ys.append(Y.get_array())
+        assert prob.K.get_mult_info()["kind"] == 2
+        X.destroy(); Y.destroy(); prob.destroy()
+    assert np.array_equal(ys[0], ys[1])

@@ -694,7 +694,8 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     const bool reduce_pw_first = self_reduce || comm || A->spmv_grid > pw_min;
     // on problems beyond the caches the p update walks the vectors from the tail: the x / r update before it ended there, so the tail
     // of r and of dinv is what the Infinity Cache still holds (0.2711 -> 0.2704 ms per iteration at config 3; no sums in that kernel,
-    // so not a bit changes; at 1 M dofs, where everything is resident, 43.6 -> 44.5 us: ascending there)
+    // so not a bit changes; with the streaming hints in place the difference is inside the noise, as is a walk in eight fronts that mirrors
+    // the product's XCD chunks: 0.2565-0.2581 / 0.2557-0.2579 / 0.2548-0.2583 ms; at 1 M dofs, where everything is resident, 43.6 -> 44.5 us: ascending there)
     const auto kern_p = streams ? k_cg_update_p<true> : k_cg_update_p<false>;
     const auto kern_xr = streams ? k_cg_update_xr<true> : k_cg_update_xr<false>;
     static const int p_desc = std::getenv("FEM_AMD_CG_P_DESC") ? std::atoi(std::getenv("FEM_AMD_CG_P_DESC")) : 1;

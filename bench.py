@@ -368,9 +368,13 @@ def main():
             # x read once, y written once
             slot_bytes = 17.0 if (affine and x_in_lds) else 21.0     # (the brick kernel does not read the element ids)
             alg = slots * slot_bytes + tnodes * 4.0 + nrows * 16.0
-            alg += visits * 40.0 if affine else visits * 16.0 + nrows * 8.0
+            per_tile = bool(info.get("per_tile_records")) and affine and x_in_lds   # one geometry record per tile (uniform bricks)
+            alg_slot_records = alg + (visits * 40.0 if affine else visits * 16.0 + nrows * 8.0)   # (the byte model of rounds 2-3a: a record per element visit)
+            if per_tile: alg += info["tiles"] * 40.0
+            else: alg = alg_slot_records
             model = (f"tile lists {slot_bytes:.0f} B/lane slot + node lists 4 B/entry + " +
-                     ("stored geometry 40 B/element visit" if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
+                     (("stored geometry 40 B/tile (one record for the tile's elements)" if per_tile else "stored geometry 40 B/element visit")
+                      if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
                      " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
             traffic = traffic_of("ebe_traffic.json") if (affine and x_in_lds) else None   # (the PMC passes were taken on the regular brick, default kernel)
         else:
@@ -387,6 +391,10 @@ def main():
              "kernel": f"{kname} (element-by-element MatMult inside KSPCG" + (", the whole product in one pass)" if info["kind"] == 2 else ")"),
              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
              "traffic": traffic, "algorithmic_bytes": alg, "bytes_model": model, "avg_launch_ms": avg_el_ms, "launches": launches,
+             **({"frac_with_per_slot_records": alg_slot_records / secs / 1e9 / HBM_PEAK_GBS,
+                 "frac_with_per_slot_records_note": "the same launch time against the byte model of round 2 (a 40 B geometry record per "
+                 "element visit, 448 MB): the figure comparable with round 2's 0.42; the kernel now reads one record per tile"}
+                if (info["kind"] == 2 and per_tile) else {}),
              "fp64": {"flops_per_element_visit": flops_per, "element_visits": visits, "elements": nel,
                       "achieved_TFLOPs": flops / secs / 1e12, "frac_of_fp64_peak": flops / secs / 1e12 / FP64_PEAK_TFLOPS,
                       "vector_instr_per_visit": valu,

@@ -71,6 +71,7 @@ _SIGS = {
     "fem_mat_get_profile": [_h, C.c_int, _ip, _dp, _dp, _dp],
     "fem_mat_get_mult_info": [_h, _ip, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong),
                               C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), _dp],
+    "fem_mat_get_tile_geometry_info": [_h, C.POINTER(C.c_longlong), _ip, _ip],
     "fem_mesh_tile_plan_digest": [_h, C.c_char_p, C.POINTER(C.c_ulonglong), _dp],
     "fem_mat_get_diagonal": [_h, _h],
     "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
@@ -513,8 +514,11 @@ class Mat:
         ms = C.c_double(0)
         _ck(_lib.fem_mat_get_mult_info(self.h, C.byref(k), C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(e),
                                        C.byref(ms)))
+        u, pt, st = C.c_longlong(0), C.c_int(0), C.c_int(0)
+        _ck(_lib.fem_mat_get_tile_geometry_info(self.h, C.byref(u), C.byref(pt), C.byref(st)))
         return {"kind": k.value, "tiles": a.value, "affine_tiles": b.value, "element_visits": c.value, "lane_slots": d.value,
-                "tile_nodes": e.value, "setup_ms": ms.value}
+                "tile_nodes": e.value, "setup_ms": ms.value, "uniform_tiles": u.value, "per_tile_records": bool(pt.value),
+                "streaming_lists": bool(st.value)}
 
     def set_mult_type(self, kind: str):
         """'assembled' (sliced block-ELL SpMV), 'ebe' (element-by-element recomputation: one-pass tile kernel on a mesh of

@@ -24,6 +24,7 @@ void mat_set_mult_type_impl(fem_mat, const char*);
 void mat_set_profiling_impl(fem_mat, int);
 void mat_get_profile_impl(fem_mat, int, int*, double*, double*, double*);
 void mat_get_mult_info_impl(fem_mat, int*, long long*, long long*, long long*, long long*, long long*, double*);
+void mat_get_tile_geometry_info_impl(fem_mat, long long*, int*, int*);
 void mesh_tile_plan_digest_impl(fem_mesh, const char*, unsigned long long*, double*);
 void mat_apply_kbc_impl(fem_mat, int, const int*);
 void mat_get_csr_impl(fem_mat, int*, int*, double*);
@@ -382,6 +383,14 @@ int fem_mat_get_mult_info(fem_mat A, int* kind, long long* tiles, long long* aff
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
     mat_get_mult_info_impl(A, kind, tiles, affine_tiles, element_visits, lane_slots, tile_nodes, setup_ms);
+    FEM_CATCH
+}
+
+int fem_mat_get_tile_geometry_info(fem_mat A, long long* uniform_tiles, int* per_tile_records, int* streaming_lists)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    mat_get_tile_geometry_info_impl(A, uniform_tiles, per_tile_records, streaming_lists);
     FEM_CATCH
 }
 

@@ -33,6 +33,7 @@ struct EbeTilePlan {
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
     double t_setup_ms = 0.0;
+    long long n_uniform = 0;   // tiles of list_cart / list_aff whose elements share one geometry record (read once per tile: lhdr[7])
     bool stream = false;   // lists + the CG's vectors beyond the caches: the product loads the lists with the streaming hint (ebe_tile.hip)
 };
 

@@ -228,6 +228,45 @@ __global__ void __launch_bounds__(256) k_tile_geom(size_t ntel, const int* __res
     geo[(size_t)10 * ntel + k] = mw;
 }
 
+// Tiles whose elements all carry the same geometry record, bit for bit (a brick of one spacing and one material: every tile): the
+// position of that record goes into the tile's list header (lhdr[8 i + 7] = slot + 1, 0 otherwise) and the product reads 40 B (88 B)
+// per TILE instead of per lane slot.  One workgroup per tile of the list; NG words per record.
+template <int NG>
+__global__ void __launch_bounds__(256) k_tile_geo_uniform(int nlist, int* __restrict__ lhdr, const int2* __restrict__ steps,
+                                                          const int* __restrict__ telems, const double* __restrict__ geo,
+                                                          size_t stride, unsigned long long* __restrict__ count)
+{
+    const int i = blockIdx.x;
+    if (i >= nlist) return;
+    const int* hd = lhdr + 8 * (size_t)i;
+    const int elem_off = hd[3], step_off = hd[4], nsteps = hd[5];
+    __shared__ int s_ref, s_diff;
+    if (threadIdx.x == 0) { s_ref = 0x7fffffff; s_diff = 0; }
+    __syncthreads();
+    int mine = 0x7fffffff;   // first slot of the tile that holds an element
+    for (int s = 0; s < nsteps; s++) {
+        const int2 st = steps[step_off + s];
+        if ((int)threadIdx.x < (st.y & 0x7fffffff) && telems[(size_t)elem_off + st.x + threadIdx.x] >= 0) mine = min(mine, st.x + (int)threadIdx.x);
+    }
+    atomicMin(&s_ref, mine);
+    __syncthreads();
+    const int ref = s_ref;
+    if (ref == 0x7fffffff) return;   // (no element: the header keeps 0)
+    long long rv[NG];
+    for (int j = 0; j < NG; j++) rv[j] = __double_as_longlong(geo[(size_t)j * stride + elem_off + ref]);
+    int diff = 0;
+    for (int s = 0; s < nsteps; s++) {
+        const int2 st = steps[step_off + s];
+        if ((int)threadIdx.x >= (st.y & 0x7fffffff)) continue;
+        const size_t k = (size_t)elem_off + st.x + threadIdx.x;
+        if (telems[k] < 0) continue;
+        for (int j = 0; j < NG; j++) diff |= (__double_as_longlong(geo[(size_t)j * stride + k]) != rv[j]);
+    }
+    if (diff) s_diff = 1;
+    __syncthreads();
+    if (threadIdx.x == 0 && !s_diff) { lhdr[8 * (size_t)i + 7] = elem_off + ref + 1; atomicAdd(count, 1ull); }
+}
+
 // one tile per workgroup.  LDS: acc[3 * nnode] nodal sums, then gl[nnode] global node ids.
 // steps[step_off .. step_off + nsteps): {first element (relative), count | barrier-after << 31}: rounds of 256 elements
 // of one colour, a barrier behind the last round of a colour
@@ -404,7 +443,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 // of every wavefront (v_readlane: nothing waits for a scalar load).  The LDS adds of a step are issued BEHIND the barrier
 // that closes the previous colour and the next step's corner values are read ahead of it (x is read-only), so the adds run
 // under the next step's arithmetic; contributions to rim nodes are not added at all (their sums belong to other tiles).
-template <int KIND, bool STREAM = false>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two)
+template <int KIND, bool STREAM = false, bool UNI = false>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two); UNI: every tile of the plan has one geometry record (lhdr[7])
 __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist, const int* __restrict__ lhdr,
                                                        const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                        const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
@@ -426,6 +465,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
     const int* hd = lhdr + 8 * (size_t)lb;
     const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
+    const int uref = UNI ? hd[7] : 0;   // every element of the tile has the geometry record of slot uref - 1 (k_tile_geo_uniform)
     constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
     double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
     double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
@@ -467,8 +507,13 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         const size_t k = (size_t)elem_off + first + threadIdx.x;
         q.c16 = ld_list<STREAM>(tconn + k);
         q.fl = ld_list<STREAM>(tflags + k);
+        if constexpr (UNI) {   // one record for the tile: the same address in every lane (and every step: the caches hold it)
 #pragma unroll
-        for (int j = 0; j < NG; j++) q.geo[j] = ld_list<STREAM>(geo + (size_t)j * geo_stride + k);
+            for (int j = 0; j < NG; j++) q.geo[j] = geo[(size_t)j * geo_stride + (uref - 1)];
+        } else {
+#pragma unroll
+            for (int j = 0; j < NG; j++) q.geo[j] = ld_list<STREAM>(geo + (size_t)j * geo_stride + k);
+        }
     };
     // corner values of a step's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
@@ -1137,6 +1182,19 @@ void ebe_tile_store_geometry(fem_mesh m, EbeTilePlan& P, const unsigned char* d_
     const ElemTable& tab = host_elem_tables()[FEM_HEX];   // (only hex8 tiles are ever in those lists)
     hipLaunchKernelGGL(k_tile_geom, dim3((unsigned)((P.slots + 255) / 256)), dim3(256), 0, s, (size_t)P.slots, P.elems.p, d_taff,
                        grp.conn.p, m->coords.p, grp.E.p, grp.nu.p, tab.w[0], P.geo.p);
+    // tiles with one record for all their elements (FEM_AMD_TILE_UNIFORM=0: every tile reads its records slot by slot)
+    const bool uni = !(std::getenv("FEM_AMD_TILE_UNIFORM") && std::atoi(std::getenv("FEM_AMD_TILE_UNIFORM")) == 0);
+    P.n_uniform = 0;
+    if (uni && P.slots < 0x7fffffffLL) {
+        DBuf<unsigned long long> cnt(1);
+        cnt.zero(s);
+        if (P.n_cart) hipLaunchKernelGGL(k_tile_geo_uniform<5>, dim3(P.n_cart), dim3(256), 0, s, P.n_cart, P.lhdr_cart.p, P.steps.p, P.elems.p, P.geo.p, (size_t)P.slots, cnt.p);
+        if (P.n_aff) hipLaunchKernelGGL(k_tile_geo_uniform<11>, dim3(P.n_aff), dim3(256), 0, s, P.n_aff, P.lhdr_aff.p, P.steps.p, P.elems.p, P.geo.p, (size_t)P.slots, cnt.p);
+        unsigned long long h = 0;
+        cnt.download(&h, 1, s);
+        FEM_HIP(hipStreamSynchronize(s));
+        P.n_uniform = (long long)h;
+    }
     FEM_HIP(hipGetLastError());
 }
 
@@ -1621,6 +1679,13 @@ void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_til
     *tiles = P.ntiles; *affine_tiles = P.n_aff + P.n_cart; *visits = P.tile_elements; *slots = P.slots; *nodes = P.tile_nodes; *ms = P.t_setup_ms;
 }
 
+void ebe_tile_geometry_info(const EbeTilePlan& P, long long* uniform_tiles, int* per_tile_records, int* streaming_lists)
+{
+    if (uniform_tiles) *uniform_tiles = P.n_uniform;
+    if (per_tile_records) *per_tile_records = (P.n_cart + P.n_aff > 0 && P.n_uniform == (long long)P.n_cart + P.n_aff) ? 1 : 0;
+    if (streaming_lists) *streaming_lists = P.stream ? 1 : 0;
+}
+
 static void hex_tile_kernel_attributes(int device)
 {
     static OncePerDevice once;
@@ -1688,7 +1753,9 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         static OncePerDevice xonce;
         if (xonce.first(A->ctx->device))
             for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>),
-                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true>)})
+                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true>),
+                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, false, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, false, true>),
+                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, true, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
         auto gox = [&](auto kern, int n, const int* list) {
             if (!n) return;
@@ -1696,9 +1763,18 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                                x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done, rcount,
                                P.ntiles, A->red_out);
         };
-        if (P.stream) {
+        // (a run-time test of the header word inside one kernel cost more than the records: 0.131 against 0.124 ms; so the variant is
+        // per plan -- a mesh with a graded region or a second material keeps the records slot by slot)
+        const bool uni = P.n_uniform == (long long)P.n_cart + P.n_aff;
+        if (P.stream && uni) {
+            gox(k_ebe_tile_x<2, true, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+            gox(k_ebe_tile_x<1, true, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+        } else if (P.stream) {
             gox(k_ebe_tile_x<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
             gox(k_ebe_tile_x<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+        } else if (uni) {
+            gox(k_ebe_tile_x<2, false, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
+            gox(k_ebe_tile_x<1, false, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
         } else {
             gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
             gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);

@@ -1187,6 +1187,18 @@ void mat_get_mult_info_impl(fem_mat A, int* kind, long long* tiles, long long* a
                       lane_slots ? lane_slots : &z, tile_nodes ? tile_nodes : &z, setup_ms ? setup_ms : &zd);
 }
 
+// one-pass tiles: how many tiles keep one geometry record for all their elements, whether the product uses that (every tile of
+// the plan does) and whether the tile lists are loaded with the streaming hint
+void ebe_tile_geometry_info(const EbeTilePlan& P, long long* uniform_tiles, int* per_tile_records, int* streaming_lists);   // ebe_tile.hip
+void mat_get_tile_geometry_info_impl(fem_mat A, long long* uniform_tiles, int* per_tile_records, int* streaming_lists)
+{
+    if (uniform_tiles) *uniform_tiles = 0;
+    if (per_tile_records) *per_tile_records = 0;
+    if (streaming_lists) *streaming_lists = 0;
+    if (!(A->mult_ebe && A->ebe_use_tile)) return;
+    ebe_tile_geometry_info(*A->pat->ebe_tile, uniform_tiles, per_tile_records, streaming_lists);
+}
+
 void mat_set_profiling_impl(fem_mat A, int on)
 {
     A->profiling = on > 0 ? on : 0;

@@ -372,6 +372,14 @@ module fem_amd_capi
       real(c_double), intent(out) :: setup_ms
       integer(c_int) :: ierr
     end function
+    function fem_mat_get_tile_geometry_info(mat, uniform_tiles, per_tile_records, streaming_lists) &
+        bind(C, name="fem_mat_get_tile_geometry_info") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: mat
+      integer(c_long_long), intent(out) :: uniform_tiles
+      integer(c_int), intent(out) :: per_tile_records, streaming_lists
+      integer(c_int) :: ierr
+    end function
     function fem_mesh_tile_plan_digest(mesh, builder, digest, setup_ms) bind(C, name="fem_mesh_tile_plan_digest") result(ierr)
       import :: c_int, c_ptr, c_double, c_long_long, c_char
       type(c_ptr), value :: mesh

@@ -188,6 +188,11 @@ int fem_mat_get_profile(fem_mat mat, int max_products, int *n, double *element_m
  * node lists, host set-up time). */
 int fem_mat_get_mult_info(fem_mat mat, int *kind, long long *tiles, long long *affine_tiles, long long *element_visits,
                           long long *lane_slots, long long *tile_nodes, double *setup_ms);
+/* One-pass tiles, further figures of the plan: the tiles (of parallelepipeds) whose elements all carry one stored geometry record,
+ * whether the product reads that record once per tile (it does when every such tile of the plan has one) and whether the plan is
+ * large enough for its lists to be loaded with the streaming hint (lists + five vectors beyond the 256 MB Infinity Cache).  Zeros for
+ * the other products.  (No reference counterpart: the reference's MatMult is PETSc's, src/main.F90:247.) */
+int fem_mat_get_tile_geometry_info(fem_mat mat, long long *uniform_tiles, int *per_tile_records, int *streaming_lists);
 /* Cross-check of the tile plan behind `-mat_mult_type ebe` (hex8 / quad4 meshes): builds the plan afresh with the named
  * builder -- "device" (the one the product uses: integer kernels, nothing leaves HBM) or "host" (worker threads over a host
  * copy of the mesh, kept as the check) -- without caching it, and returns a digest of every array: [0] tiles, [1] lane

@@ -427,3 +427,30 @@ def test_streaming_tile_kernels_give_the_same_product(gpu_ctx, name, monkeypatch
         assert prob.K.get_mult_info()["kind"] == 2
         X.destroy(); Y.destroy(); prob.destroy()
     assert np.array_equal(ys[0], ys[1])
+
+
+@pytest.mark.parametrize("name,expect", [("hex_uniform", True), ("hex_sheared", False), ("hex_tiles_flat", True),
+                                         ("hex_two_materials", False), ("hex_graded", False)])
+def test_one_geometry_record_per_tile(gpu_ctx, name, expect, monkeypatch):
+    """Tiles whose elements share one stored geometry record (same spacing, same material) are marked by k_tile_geo_uniform; when
+    every tile of the plan is, the product reads the record once per tile (k_ebe_tile_x<.., UNI>): bitwise the product of the
+    slot-by-slot records (FEM_AMD_TILE_UNIFORM=0).  A second material, a graded spacing or a shear (records equal only up to rounding)
+    keep the per-slot records."""
+    m = _meshes()[name]
+    ys, infos = [], []
+    for u in ("0", "1"):
+        monkeypatch.setenv("FEM_AMD_TILE_UNIFORM", u)
+        prob = driver.Problem(gpu_ctx, m, "-mat_mult_type ebe")
+        prob.assemble(); prob.ksp.set_up()
+        X, Y = capi.Vec(gpu_ctx, m.ndof), capi.Vec(gpu_ctx, m.ndof)
+        X.set_array(np.sin(0.11 * np.arange(m.ndof)) + 0.3)
+        prob.K.mult(X, Y)
+        ys.append(Y.get_array()); infos.append(prob.K.get_mult_info())
+        X.destroy(); Y.destroy(); prob.destroy()
+    assert infos[0]["kind"] == 2 and infos[0]["uniform_tiles"] == 0 and not infos[0]["per_tile_records"]
+    assert infos[1]["per_tile_records"] == expect
+    if expect:
+        assert infos[1]["uniform_tiles"] == infos[1]["affine_tiles"] > 0
+    else:
+        assert infos[1]["uniform_tiles"] < infos[1]["affine_tiles"]
+    assert np.array_equal(ys[0], ys[1])

@@ -30,6 +30,7 @@
 #include <thread>
 
 #include "comm.h"
+#include "cg_device.h"
 #include "ebe_tile.h"
 #include "hex8_ebe.h"
 #include "quad4_ebe.h"
@@ -912,6 +913,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
 // LDS: x and X of the tile's nodes (32 B each) + the sums of its owned nodes (16 B each): 50 KB for the 33 x 33-node tile.
 constexpr int TILE_Q4X_MAX_NODES = 1280, TILE_Q4X_MAX_OWN = 1024;   // 5 / 4 slots per thread
 constexpr int TILE_Q4X_LDS_NODES = 1104, TILE_Q4X_LDS_OWN = 976;    // the LDS image (33 x 33 nodes, 31 x 31 owned): 50 KB, three workgroups per CU
+template <bool FUSED>   // FUSED: the kernel opens the CG iteration itself (convergence test, p = M^-1 r + b p in the stage-in, x += a p): cg_device.h
 __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
                                                       const int* __restrict__ tnodes, const uint4* __restrict__ tconn,
                                                       const unsigned char* __restrict__ tflags, const double* __restrict__ geo,
@@ -919,14 +921,20 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
                                                       const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
                                                       const double* __restrict__ bc_shift, double g, double w,
                                                       double* __restrict__ y, double* __restrict__ partial, const int* __restrict__ done,
-                                                      unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red)
+                                                      unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red, CgFuseArgs cg)
 {
-    if (done && *done) return;
     constexpr int NPT = TILE_Q4X_MAX_NODES / 256, NPO = TILE_Q4X_MAX_OWN / 256, MN = TILE_Q4X_LDS_NODES, MO = TILE_Q4X_LDS_OWN;
     extern __shared__ double lds[];
     __shared__ double sh[4];
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // XCD-wise, as k_ebe_tile
-    if (lb >= (unsigned)nlist) return;
+    if constexpr (FUSED) {
+        // (as k_cg_update_p: not on st->done, which this kernel's own verdict sets while other workgroups are still starting and
+        // every workgroup owes the last x += a p of its nodes; `stop` is written by the x / r update that follows)
+        if (cg.open.st->stop) return;
+    } else {
+        if (done && *done) return;
+    }
+    if (lb >= (unsigned)nlist) return;   // (workgroup 0, which records the verdict of a fused opening, holds tile 0 of the list)
     const int* hd = lhdr + 8 * (size_t)lb;
     const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     double* xs = lds;               // xs[d * MN + i]: x of the tile's nodes
@@ -937,12 +945,43 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
         double xv[NPT][2], cv[NPT][2];
 #pragma unroll
         for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        if constexpr (FUSED) {
+            // everything the stage-in reads is asked for BEFORE the scalars of the opening are summed (they do not depend on each
+            // other, and with fewer tiles than workgroup slots the kernel lasts as long as one tile's chain of latencies)
+            double2 rr[NPT], dd[NPT], po[NPT], xo[NPT];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) {
-            const int i = threadIdx.x + 256 * j;
-            const double2 xn = (i < nnode) ? reinterpret_cast<const double2*>(x)[nv[j]] : make_double2(0.0, 0.0);   // (16 B aligned)
-            const double2 cn = (i < nnode) ? reinterpret_cast<const double2*>(coords)[nv[j]] : make_double2(0.0, 0.0);
-            xv[j][0] = xn.x; xv[j][1] = xn.y; cv[j][0] = cn.x; cv[j][1] = cn.y;
+            for (int j = 0; j < NPT; j++) {
+                const int i = threadIdx.x + 256 * j;
+                const double2 z2 = make_double2(0.0, 0.0);
+                rr[j] = (i < nnode) ? reinterpret_cast<const double2*>(cg.r)[nv[j]] : z2;
+                dd[j] = (i < nnode) ? reinterpret_cast<const double2*>(cg.dinv)[nv[j]] : z2;
+                po[j] = (i < nnode) ? reinterpret_cast<const double2*>(cg.p_old)[nv[j]] : z2;   // (iteration 0: whatever the buffer holds; not used)
+                xo[j] = (i < nown) ? reinterpret_cast<const double2*>(cg.x)[nv[j]] : z2;
+                const double2 cn = (i < nnode) ? reinterpret_cast<const double2*>(coords)[nv[j]] : z2;
+                cv[j][0] = cn.x; cv[j][1] = cn.y;
+            }
+            const CgOpened op = cg_open_block(cg.open, blockIdx.x == 0 && threadIdx.x == 0, sh);
+#pragma unroll
+            for (int j = 0; j < NPT; j++) {
+                const int i = threadIdx.x + 256 * j;
+                if (op.i > 0 && i < nown) {   // the x += a p the iteration just completed owes the owned nodes
+                    xo[j].x += op.aprev * po[j].x; xo[j].y += op.aprev * po[j].y;
+                    reinterpret_cast<double2*>(cg.x)[nv[j]] = xo[j];
+                }
+                // (iteration 0: p = z; b = 0 there, but 0 * p_old must not meet whatever the buffer holds)
+                xv[j][0] = (op.i > 0) ? cg_p(cg_z(dd[j].x, rr[j].x), op.b, po[j].x) : cg_z(dd[j].x, rr[j].x);
+                xv[j][1] = (op.i > 0) ? cg_p(cg_z(dd[j].y, rr[j].y), op.b, po[j].y) : cg_z(dd[j].y, rr[j].y);
+                if (!op.reason && i < nown) reinterpret_cast<double2*>(cg.p_new)[nv[j]] = make_double2(xv[j][0], xv[j][1]);
+            }
+            if (op.reason) return;   // the solve ends here (uniform over the grid: every workgroup reached the same verdict)
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPT; j++) {
+                const int i = threadIdx.x + 256 * j;
+                const double2 xn = (i < nnode) ? reinterpret_cast<const double2*>(x)[nv[j]] : make_double2(0.0, 0.0);   // (16 B aligned)
+                const double2 cn = (i < nnode) ? reinterpret_cast<const double2*>(coords)[nv[j]] : make_double2(0.0, 0.0);
+                xv[j][0] = xn.x; xv[j][1] = xn.y; cv[j][0] = cn.x; cv[j][1] = cn.y;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
@@ -1697,9 +1736,19 @@ static void hex_tile_kernel_attributes(int device)
         FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, TILE_MAX_NODES * 28));
 }
 
+// the plans whose product can open the CG iteration itself: quad4 with x of the tile in LDS (2-D: a tile's rim is 13 % of its nodes)
+bool ebe_tile_can_fuse(fem_mat A, const EbeTilePlan& P)
+{
+    static const bool qx_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
+    return A->mesh->groups.size() == 1 && A->mesh->groups[0].type == FEM_QUA && qx_env && P.geo.p && P.max_nsteps <= 64 &&
+           P.max_nnode <= TILE_Q4X_LDS_NODES && P.max_nown <= TILE_Q4X_LDS_OWN && P.n_gen > 0;
+}
+
 // y = K x, p.Kp partials into part[0 .. ntiles)
 // phase -1: every tile; 0: the tiles that own nodes shared with other domains; 1: the others
-void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase)
+// cg != nullptr (quad4 plans that pass ebe_tile_can_fuse, phase -1): x is not read -- the kernel forms p itself (cg_device.h)
+void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase,
+                   const CgFuseArgs* cg)
 {
     fem_mesh m = A->mesh;
     hipStream_t s = A->ctx->stream;
@@ -1722,19 +1771,26 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
             constexpr size_t shqx = (size_t)(4 * TILE_Q4X_LDS_NODES + 2 * TILE_Q4X_LDS_OWN) * sizeof(double);
             static OncePerDevice qxonce;
             if (qxonce.first(A->ctx->device))
-                FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_ebe_tile_q4x), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shqx));
-            if (n1 > n0)
-                hipLaunchKernelGGL(k_ebe_tile_q4x, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shqx, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
-                                   P.steps.p, P.nodes.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn, A->bc_dof.p,
-                                   A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out);
+                for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_q4x<false>), reinterpret_cast<const void*>(k_ebe_tile_q4x<true>)})
+                    FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shqx));
+            if (n1 > n0) {
+                auto launch = [&](auto kern, const CgFuseArgs& ca) {
+                    hipLaunchKernelGGL(kern, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shqx, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
+                                       P.steps.p, P.nodes.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn,
+                                       A->bc_dof.p, A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out, ca);
+                };
+                if (cg) launch(k_ebe_tile_q4x<true>, *cg); else launch(k_ebe_tile_q4x<false>, CgFuseArgs{});
+            }
             return;
         }
+        FEM_CHECK(!cg, 7, "ebe_tile_mult: the fused CG opening needs the quad4 kernel with x in LDS");
         if (n1 > n0)
             hipLaunchKernelGGL(k_ebe_tile_q4, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shq, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
                                P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn,
                                A->bc_dof.p, A->bc_shift.p, g, w, P.max_nnode, y, part, done, rcount, P.ntiles, A->red_out);
         return;
     }
+    FEM_CHECK(!cg, 7, "ebe_tile_mult: the fused CG opening is a quad4 path");
     const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
     hex_tile_kernel_attributes(m->ctx->device);
     auto go = [&](auto kern, int n, const int* list) {

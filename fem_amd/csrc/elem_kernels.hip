@@ -20,6 +20,7 @@
 
 #include <cstdlib>
 
+#include "cg_device.h"
 #include "comm.h"
 #include "scan.h"
 #include "hex8_ebe.h"
@@ -984,7 +985,9 @@ static int ebe_blocks(const fem_mesh m)
 
 std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);   // ebe_tile.hip
 int ebe_tile_partials(const EbeTilePlan& P);
-void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase);
+void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase,
+                   const CgFuseArgs* cg = nullptr);
+bool ebe_tile_can_fuse(fem_mat A, const EbeTilePlan& P);
 bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* S, const double* valence);
 bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P);
 
@@ -1140,6 +1143,19 @@ bool ebe_tile_phase(fem_mat A, const double* x, double* y, double* partial, cons
     }
     if (phase >= 0) ebe_tile_mult(A, *A->pat->ebe_tile, x, y, partial ? partial : A->ebe_partial.p, done, phase);
     if (phase == 1) { ebe_mark(A); ebe_mark(A); ebe_mark(A); }
+    return true;
+}
+
+// The product that opens the CG iteration itself (cg_device.h): cg == nullptr asks whether this Mat's product can (quad4 tile plans
+// with x in LDS, no penalty-free shortcuts needed); otherwise y = K p with p formed in the stage-in, p.Kp partials as ebe_mult_impl.
+bool ebe_mult_fused_impl(fem_mat A, const CgFuseArgs* cg, double* y, double* partial)
+{
+    if (!A->mult_ebe || !A->ebe_use_tile || !ebe_tile_can_fuse(A, *A->pat->ebe_tile)) return false;
+    if (!cg) return true;
+    A->sampling = A->profiling > 0 && (A->prod_count++ % (size_t)A->profiling) == 0;
+    ebe_mark(A);
+    ebe_tile_mult(A, *A->pat->ebe_tile, nullptr, y, partial ? partial : A->ebe_partial.p, nullptr, -1, cg);
+    ebe_mark(A); ebe_mark(A); ebe_mark(A);
     return true;
 }
 

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <sstream>
 
+#include "cg_device.h"
 #include "comm.h"
 #include "direct.h"
 #include "mg.h"
@@ -30,29 +31,13 @@ using namespace fem;
 void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const int* done);
 void mat_set_mult_type_impl(fem_mat A, const char* type);
 bool ebe_tile_phase(fem_mat A, const double* x, double* y, double* partial, const int* done, int phase);   // elem_kernels.hip
+bool ebe_mult_fused_impl(fem_mat A, const fem::CgFuseArgs* cg, double* y, double* partial);               // elem_kernels.hip
 void mat_get_diagonal_raw(fem_mat A, double* d);
 
 namespace fem {
 
 constexpr int VGRID = 1024;  // workgroups of the vector kernels = number of partials
 
-struct KspState {
-    double beta, betaold, a, b, dp, rnorm0, ttol;
-    double dpi2[2];  // p.w of the last two iterations (ping-pong: see the field table below)
-    double red[4];   // reduced scalars: [0] z.z  [1] z.r  [2] p.w
-    int it, its, reason, done;
-    int stop;        // `done` as the x / r update saw it: what k_cg_update_p may end on (see there)
-};
-
-__device__ __forceinline__ double block_sum(double v, double* sh)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-    const int w = threadIdx.x >> 6;
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sh[w] = v;
-    __syncthreads();
-    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
-}
 // same for a 1024-thread workgroup (16 waves), fixed summation order
 __device__ __forceinline__ double block_sum16(double v, double* sh)
 {
@@ -176,36 +161,6 @@ __global__ void __launch_bounds__(256) k_cg_init_ext(size_t n, const double* __r
 // workgroup sums in a fixed order, or already reduced in st->red (after k_reduce
 // and, multi-domain, the all-reduce).
 
-// What opens iteration i + 1 of KSPSolve_CG (i = iterations completed): KSPConvergedDefault on the preconditioned residual
-// norm sqrt(z.z), then beta = z.r and b = beta / beta_old.  Pure function of its arguments: every workgroup of a kernel
-// evaluates it from the same inputs.
-struct CgOpen { double dp, rnorm0, ttol, b; int reason, its; };
-__device__ __forceinline__ CgOpen cg_open_logic(int i, double zz, double zr, double betaold, double rnorm0_in, double ttol_in,
-                                                double rtol, double abstol, double dtol, int maxit)
-{
-    CgOpen o;
-    o.dp = sqrt(zz);
-    o.rnorm0 = (i == 0) ? o.dp : rnorm0_in;
-    o.ttol = (i == 0) ? fmax(rtol * o.dp, abstol) : ttol_in;
-    o.reason = 0;
-    if (isnan(o.dp) || isinf(o.dp)) o.reason = FEM_KSP_DIVERGED_NANORINF;
-    else if (o.dp <= o.ttol) o.reason = (o.dp < abstol) ? FEM_KSP_CONVERGED_ATOL : FEM_KSP_CONVERGED_RTOL;
-    else if (o.dp >= dtol * o.rnorm0) o.reason = FEM_KSP_DIVERGED_DTOL;
-    else if (i >= maxit) o.reason = FEM_KSP_DIVERGED_ITS;
-    o.its = -1;
-    if (!o.reason) {
-        o.its = i + 1;   // PETSc sets ksp->its = i+1 before the beta checks
-        if (zr == 0.0) o.reason = FEM_KSP_CONVERGED_ATOL;
-        else if (i > 0 && zr * betaold < 0.0) o.reason = FEM_KSP_DIVERGED_INDEFINITE_PC;
-    }
-    o.b = (i == 0) ? 0.0 : zr / betaold;
-    return o;
-}
-// z = M^-1 r and p = z + b p with one rounding each, written the same way in every kernel that forms them (the compiler is
-// free to contract a * b + c either way round; the kernels of one solve have to agree to the bit)
-__device__ __forceinline__ double cg_z(double dinv, double r) { return __dmul_rn(dinv, r); }
-__device__ __forceinline__ double cg_p(double z, double b, double p) { return __fma_rn(b, p, z); }
-
 // STREAM (problems whose vectors and tile lists do not fit the 256 MB Infinity Cache): what an iteration does not look at again
 // before the cache has turned over -- x (read and written once per iteration) and w = K p (read once) -- moves with the streaming
 // hint, so that p, r and dinv are what the caches keep.  Config 3: 0.2782 -> 0.2572 ms per iteration together with the tile lists
@@ -228,27 +183,10 @@ __global__ void __launch_bounds__(256) k_cg_update_p(size_t n, KspState* __restr
     // the last x += a p; `stop` is only ever written by the x / r update that follows)
     if (st->stop) return;
     __shared__ double sh[4];
-    double zz, zr;
-    if (pzz) {
-        double s0 = 0.0, s1 = 0.0;
-        for (int k = threadIdx.x; k < npart; k += 256) { s0 += pzz[k]; s1 += pzr[k]; }
-        zz = block_sum(s0, sh);
-        zr = block_sum(s1, sh);
-    } else { zz = st->red[0]; zr = st->red[1]; }
-    const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
-    const int i = st->it;
-    const CgOpen o = cg_open_logic(i, zz, zr, st->betaold, st->rnorm0, st->ttol, rtol, abstol, dtol, maxit);
-    const int reason = o.reason;
-    const double b = o.b;
-    const double aprev = st->a;   // alpha of the iteration just completed (x += a p is still owed; 0 before the first)
-    if (writer) {
-        st->dp = o.dp;
-        if (hist && i < hist_len) hist[i] = o.dp;
-        if (i == 0) { st->rnorm0 = o.rnorm0; st->ttol = o.ttol; }
-        if (o.its >= 0) st->its = o.its;
-        if (reason) { st->reason = reason; st->done = 1; }
-        else { st->b = b; st->beta = zr; }
-    }
+    const CgOpened o = cg_open_block(CgOpenArgs{st, pzz, pzr, npart, rtol, abstol, dtol, maxit, hist, hist_len},
+                                     blockIdx.x == 0 && threadIdx.x == 0, sh);
+    const int i = o.i, reason = o.reason;
+    const double b = o.b, aprev = o.aprev;
     size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t str = (size_t)gridDim.x * blockDim.x;
     if (reason) {   // the solve ends here: the last iteration's x += a p
@@ -376,6 +314,8 @@ struct fem_ksp_s {
     bool setup_done = false;
     long long n = 0;
     DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
+    DBuf<double> p2;                         // the second p of the CG whose product opens the iteration (cg_device.h): p alternates
+    int fuse_p = -1;                         // -ksp_cg_fuse_p 0|1; -1: FEM_AMD_CG_FUSE_P, default on where the product can
     std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
     std::unique_ptr<fem::BandCholesky> direct;   // -ksp_type preonly -pc_type lu|cholesky
     std::unique_ptr<fem::BandLU> direct_lu;      // the same on a Mat flagged unsymmetric (Newton Jacobian)
@@ -443,6 +383,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-ksp_divtol") { is >> k->dtol; }
         else if (key == "-ksp_max_it") { is >> k->maxit; }
         else if (key == "-ksp_fuse_allreduce") { is >> k->fuse_allreduce; FEM_CHECK(k->fuse_allreduce == 0 || k->fuse_allreduce == 1, 6, "-ksp_fuse_allreduce 0|1"); }
+        else if (key == "-ksp_cg_fuse_p") { is >> k->fuse_p; FEM_CHECK(k->fuse_p == 0 || k->fuse_p == 1, 6, "-ksp_cg_fuse_p 0|1"); }
         else if (key == "-ksp_stream_min_dof") { is >> k->stream_min_dof; FEM_CHECK(k->stream_min_dof >= 0, 6, "-ksp_stream_min_dof n >= 0"); }
         else if (key == "-ksp_halo_overlap") { is >> k->halo_overlap; FEM_CHECK(k->halo_overlap == 0 || k->halo_overlap == 1, 6, "-ksp_halo_overlap 0|1"); }
         else if (key == "-ksp_norm_type") { is >> val; FEM_CHECK(val == "preconditioned", 6, "only -ksp_norm_type preconditioned"); }
@@ -698,9 +639,32 @@ void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
     // the product's XCD chunks: 0.2565-0.2581 / 0.2557-0.2579 / 0.2548-0.2583 ms; at 1 M dofs, where everything is resident, 43.6 -> 44.5 us: ascending there)
     const auto kern_p = streams ? k_cg_update_p<true> : k_cg_update_p<false>;
     const auto kern_xr = streams ? k_cg_update_xr<true> : k_cg_update_xr<false>;
+    // Problems that sit in the caches, quad4 tile product: the product opens the iteration itself -- convergence test, p = M^-1 r + b p
+    // formed in the stage-in of every tile (2-D: the rim it recomputes is 13 % of a tile's nodes), the owed x += a p -- and
+    // k_cg_update_p with its launch is gone: two kernels per iteration (config 2: see DESIGN.md 4d).  Same operations, same bits.
+    static const bool fuse_p_env = !(std::getenv("FEM_AMD_CG_FUSE_P") && std::atoi(std::getenv("FEM_AMD_CG_FUSE_P")) == 0);
+    const bool fuse_p = (k->fuse_p >= 0 ? k->fuse_p != 0 : fuse_p_env) && !comm && !mg && !streams && !self_reduce &&
+                        (k->pc == "jacobi" || k->pc == "none") && ebe_mult_fused_impl(A, nullptr, nullptr, nullptr);
+    if (fuse_p && k->p2.n < n) k->p2.alloc(n);
+    double* const pbuf[2] = {k->p.p, k->p2.p};
     static const int p_desc = std::getenv("FEM_AMD_CG_P_DESC") ? std::atoi(std::getenv("FEM_AMD_CG_P_DESC")) : 1;
     int queued = 0;   // iterations enqueued so far (the profile samples iteration j * period)
     auto one_iteration = [&] {
+        if (fuse_p) {
+            const CgFuseArgs ca{CgOpenArgs{st, k->pzz.p, k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p, k->hist_len},
+                                k->dinv.p, k->r.p, pbuf[queued & 1], pbuf[(queued + 1) & 1], x->d.p};
+            const bool sample = k->profiling > 0 && (queued % k->profiling) == 0;
+            queued++;
+            if (sample) FEM_HIP(hipEventRecord(next_event(), s));
+            ebe_mult_fused_impl(A, &ca, k->w.p, A->spmv_partial.p);
+            if (sample) FEM_HIP(hipEventRecord(next_event(), s));
+            if (reduce_pw_first)
+                hipLaunchKernelGGL(k_reduce, dim3(1), dim3(1024), 0, s, A->spmv_partial.p, (const double*)nullptr, A->spmv_grid,
+                                   &st->red[2], &st->done);
+            hipLaunchKernelGGL(kern_xr, dim3(g), dim3(256), 0, s, n, pd, st, reduce_pw_first ? nullptr : A->spmv_partial.p,
+                               A->spmv_grid, k->dinv.p, k->w.p, k->r.p, owned, k->pzz.p, k->pzr.p);
+            return;
+        }
         hipLaunchKernelGGL(kern_p, dim3(g), dim3(256), 0, s, n, st, comm ? nullptr : k->pzz.p,
                            comm ? nullptr : k->pzr.p, (int)g, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p,
                            k->hist_len, k->dinv.p, k->r.p, k->p.p, mg ? k->z.p : (const double*)nullptr, x->d.p, streams ? p_desc : 0);

@@ -190,3 +190,19 @@ def test_streaming_cg_is_bitwise_the_default_cg(gpu_ctx, opts, n, jitter):
     assert a.reasons == b.reasons and a.reasons[-1] > 0 and a.its == b.its
     assert np.array_equal(a.aggregate_u, b.aggregate_u)
     assert np.array_equal(a.aggregate_stress, b.aggregate_stress)
+
+
+@pytest.mark.parametrize("n,jitter", [((9, 7), 0.2), ((40, 33), 0.0), ((70, 45), 0.15)])
+def test_cg_opened_by_the_quad4_product_is_bitwise_the_three_kernel_cg(gpu_ctx, n, jitter):
+    """Quad4 meshes that sit in the caches: the tile product opens the CG iteration itself (convergence test, p = M^-1 r + b p in its
+    stage-in, the owed x += a p; cg_device.h, -ksp_cg_fuse_p).  Same iterations, residual norm and fields to the bit as the CG with
+    k_cg_update_p (-ksp_cg_fuse_p 0), and both agree with the assembled product to round-off."""
+    from fem_amd.mesh import structured_quad
+    m = structured_quad(*n, jitter=jitter)
+    a = driver.run(m, "-ksp_rtol 1e-12 -mat_mult_type ebe -ksp_cg_fuse_p 0", ctx=gpu_ctx)
+    b = driver.run(m, "-ksp_rtol 1e-12 -mat_mult_type ebe -ksp_cg_fuse_p 1", ctx=gpu_ctx)
+    c = driver.run(m, "-ksp_rtol 1e-12", ctx=gpu_ctx)
+    assert a.reasons == b.reasons and a.reasons[-1] > 0 and a.its == b.its
+    assert np.array_equal(a.aggregate_u, b.aggregate_u)
+    assert np.array_equal(a.aggregate_stress, b.aggregate_stress)
+    assert np.abs(b.aggregate_u - c.aggregate_u).max() <= 1e-9 * np.abs(c.aggregate_u).max()

@@ -1,7 +1,7 @@
 // fem_amd/csrc/cg_device.h -- the device-resident state of KSPSolve_CG and the scalar logic every workgroup of its kernels evaluates
 // (ksp.hip), shared with the tile product that opens an iteration itself (ebe_tile.hip, k_ebe_tile_q4x<true>).
-// Reference semantics: PETSc KSPSolve_CG + KSPConvergedDefault, as restated in oracle/defmod_oracle.c (the reference selects them
-// through `-ksp_type cg -pc_type jacobi`, src/main.F90:354,377).
+// Reference semantics: PETSc KSPSolve_CG + KSPConvergedDefault (the reference selects them through `-ksp_type cg -pc_type jacobi`,
+// src/main.F90:354,377).
 #pragma once
 #include <hip/hip_runtime.h>
 

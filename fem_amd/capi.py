@@ -74,6 +74,7 @@ _SIGS = {
     "fem_mat_get_tile_geometry_info": [_h, C.POINTER(C.c_longlong), _ip, _ip],
     "fem_mesh_tile_plan_digest": [_h, C.c_char_p, C.POINTER(C.c_ulonglong), _dp],
     "fem_mat_get_diagonal": [_h, _h],
+    "fem_mat_set_values": [_h, C.c_int, _ip, C.c_int, _ip, _dp, C.c_int],
     "fem_mat_mult_timed": [_h, _h, _h, C.c_int, _dp],
     "fem_vec_create": [_h, C.c_longlong, C.POINTER(_h)],
     "fem_vec_destroy": [_h],
@@ -529,6 +530,13 @@ class Mat:
         ms = C.c_double(0)
         _ck(_lib.fem_mat_mult_timed(self.h, x.h, y.h, reps, C.byref(ms)))
         return ms.value
+
+    def set_values(self, rows, cols, v, mode="insert"):
+        """MatSetValues (src/m_global.F90:257-260,296): dense len(rows) x len(cols) block, row-major, 0-based dofs."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32); cols = np.ascontiguousarray(cols, dtype=np.int32)
+        v = np.ascontiguousarray(v, dtype=np.float64).reshape(len(rows), len(cols))
+        _ck(_lib.fem_mat_set_values(self.h, len(rows), _i(rows), len(cols), _i(cols), _d(v),
+                                    {"insert": 1, "add": 2}[mode]))
 
     def get_diagonal(self, d: Vec):
         _ck(_lib.fem_mat_get_diagonal(self.h, d.h))

@@ -28,6 +28,7 @@ void mat_get_tile_geometry_info_impl(fem_mat, long long*, int*, int*);
 void mesh_tile_plan_digest_impl(fem_mesh, const char*, unsigned long long*, double*);
 void mat_apply_kbc_impl(fem_mat, int, const int*);
 void mat_get_csr_impl(fem_mat, int*, int*, double*);
+void mat_set_values_impl(fem_mat, int, const int*, int, const int*, const double*, int);
 void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
 void mat_get_diagonal_raw(fem_mat, double*);
 void form_el_ke_impl(fem_ctx, int, int, const double*, const double*, const double*, double*);
@@ -425,6 +426,16 @@ int fem_mat_get_csr(fem_mat A, int* rowptr, int* colind, double* val)
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
     mat_get_csr_impl(A, rowptr, colind, val);
+    FEM_CATCH
+}
+
+int fem_mat_set_values(fem_mat A, int m, const int* rows, int n, const int* cols, const double* v, int mode)
+{
+    FEM_TRY
+    FEM_CHECK(A, 1, "null matrix");
+    FEM_CHECK(m >= 0 && n >= 0 && (m == 0 || rows) && (n == 0 || cols) && (m == 0 || n == 0 || v), 2, "fem_mat_set_values: bad arguments");
+    FEM_CHECK(mode == 1 || mode == 2, 2, "fem_mat_set_values: mode must be 1 (INSERT_VALUES) or 2 (ADD_VALUES)");
+    if (m && n) mat_set_values_impl(A, m, rows, n, cols, v, mode);
     FEM_CATCH
 }
 

@@ -663,7 +663,9 @@ __global__ void __launch_bounds__(64) k_comp_lu(int ncomp, const int* __restrict
             __syncthreads();
             continue;
         }
-        if (p != k && lane < m) { const double t = a[k][lane]; a[k][lane] = a[p][lane]; a[p][lane] = t; }
+        // only the active part of the two rows changes places (as k_band_lu and LAPACK's dgbtf2 do): the multipliers already stored in
+        // columns < k stay where the step that made them put them, which is what k_comp_solve's interleaved exchanges assume
+        if (p != k && lane >= k && lane < m) { const double t = a[k][lane]; a[k][lane] = a[p][lane]; a[p][lane] = t; }
         __syncthreads();
         if (lane > k && lane < m) {
             const double l = a[lane][k] / a[k][k];

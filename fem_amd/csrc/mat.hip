@@ -11,6 +11,7 @@
 // 5.5 TB/s (96 % of the box's 5.75 TB/s read ceiling) where scalar CSR reaches
 // 3.7 TB/s and row-per-wave BSR 2.9 TB/s.
 #include <algorithm>
+#include <map>
 
 #include "comm.h"
 #include "objects.h"
@@ -539,6 +540,70 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
                            A->bcol.p, A->values(), owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
     A->bc_saved = true;
     A->h_bc = std::move(merged);
+    FEM_HIP(hipGetLastError());
+    FEM_HIP(hipStreamSynchronize(s));
+}
+
+// MatSetValues (src/m_global.F90:257-260 ADD_VALUES from FormLocalK, :296 INSERT_VALUES of the penalty): a logically dense
+// m x n block of scalar entries given by 0-based dof indices, row-major as PETSc's default; negative indices are skipped as
+// PETSc skips them; an entry outside the sparsity of MatCreateAIJ is an error (PETSc with MAT_NEW_NONZERO_LOCATION_ERR).  The
+// host looks the positions up in the block rows concerned, one small kernel writes them: meant for a host that patches a few
+// rows (the reference's penalty INSERT, tests), not for the element loop (fem_mat_assemble_elements).
+__global__ void __launch_bounds__(256) k_set_values(int n, const long long* __restrict__ pos, const double* __restrict__ v,
+                                                    int add, double* __restrict__ val)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (add) val[pos[i]] += v[i];
+    else val[pos[i]] = v[i];
+}
+void mat_set_values_impl(fem_mat A, int m, const int* rows, int n, const int* cols, const double* v, int mode)
+{
+    fem_ctx ctx = A->ctx;
+    ctx->bind();
+    hipStream_t s = ctx->stream;
+    const int bs = A->bs, nn = A->nbrows;
+    const long long nd = (long long)nn * bs;
+    std::vector<long long> pos;
+    std::vector<double> vals;
+    std::vector<int> hc;
+    // duplicate positions inside one call: ADD accumulates, INSERT keeps the last one, as a sequential MatSetValues would
+    std::map<long long, size_t> seen;
+    for (int i = 0; i < m; i++) {
+        const int row = rows[i];
+        if (row < 0) continue;
+        FEM_CHECK(row < nd, 3, "fem_mat_set_values: row index out of range");
+        const int node = row / bs, r = row % bs, lane = node & 63, len = A->h_rowlen[node];
+        const size_t o0 = (size_t)A->h_boff[node >> 6];
+        hc.resize((size_t)std::max(len, 1));
+        if (len)
+            FEM_HIP(hipMemcpy2DAsync(hc.data(), sizeof(int), A->bcol.p + o0 * 64 + lane, 64 * sizeof(int), sizeof(int), (size_t)len,
+                                     hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        for (int jn = 0; jn < n; jn++) {
+            const int col = cols[jn];
+            if (col < 0) continue;
+            FEM_CHECK(col < nd, 3, "fem_mat_set_values: column index out of range");
+            const int cnode = col / bs, c = col % bs;
+            int j = -1;
+            for (int q = 0; q < len; q++)
+                if (hc[(size_t)q] == cnode) { j = q; break; }
+            FEM_CHECK(j >= 0, 4, "fem_mat_set_values: entry outside the sparsity pattern of MatCreateAIJ");
+            const long long p = (long long)(((o0 + (size_t)j) * bs * bs + (size_t)r * bs + c) * 64 + lane);
+            const double x = v[(size_t)i * n + jn];
+            if (row != col) A->unsymmetric = true;   // (what the host writes off the diagonal is not known to be symmetric: LU, not Cholesky)
+            auto it = seen.find(p);
+            if (it == seen.end()) { seen[p] = pos.size(); pos.push_back(p); vals.push_back(x); }
+            else if (mode == 2) vals[it->second] += x;
+            else vals[it->second] = x;
+        }
+    }
+    if (pos.empty()) return;
+    DBuf<long long> dpos; DBuf<double> dval;
+    dpos.alloc(pos.size()); dval.alloc(vals.size());
+    dpos.upload(pos.data(), pos.size(), s); dval.upload(vals.data(), vals.size(), s);
+    double* dst = A->values();
+    hipLaunchKernelGGL(k_set_values, dim3(cdiv(pos.size(), 256)), dim3(256), 0, s, (int)pos.size(), dpos.p, dval.p, mode == 2 ? 1 : 0, dst);
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
 }

@@ -388,6 +388,14 @@ module fem_amd_capi
       real(c_double), intent(out) :: setup_ms
       integer(c_int) :: ierr
     end function
+    function fem_mat_set_values(mat, m, rows, n, cols, v, mode) bind(C, name="fem_mat_set_values") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: mat
+      integer(c_int), value :: m, n, mode
+      integer(c_int), intent(in) :: rows(*), cols(*)
+      real(c_double), intent(in) :: v(*)
+      integer(c_int) :: ierr
+    end function
     function fem_mat_get_diagonal(mat, d) bind(C, name="fem_mat_get_diagonal") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: mat, d

@@ -200,6 +200,11 @@ int fem_mat_get_tile_geometry_info(fem_mat mat, long long *uniform_tiles, int *p
  * tile lists, the stored geometry.  A Mat must have been created from the mesh (its symbolic phase supplies the node ->
  * element lists).  digest[0] = 0 when the mesh gets no tile plan (other element types, more than 16 colours). */
 int fem_mesh_tile_plan_digest(fem_mesh mesh, const char *builder, unsigned long long digest[12], double *setup_ms);
+/* MatSetValues (src/m_global.F90:257-260 ADD_VALUES, :296 INSERT_VALUES): a logically dense m x n block, row-major, by
+ * 0-based scalar dof indices; negative indices are skipped (as PETSc does); mode 1 = INSERT_VALUES, 2 = ADD_VALUES.  An
+ * entry outside the sparsity of fem_mat_create_aij is an error.  Acts on the assembled values (a host patching a few rows);
+ * the element loop is fem_mat_assemble_elements. */
+int fem_mat_set_values(fem_mat mat, int m, const int *rows, int n, const int *cols, const double *v, int mode);
 /* MatMult: y = K x (sub-assembled product + halo sum when a halo is attached). */
 int fem_mat_mult(fem_mat mat, fem_vec x, fem_vec y);
 int fem_mat_get_diagonal(fem_mat mat, fem_vec d);

@@ -123,3 +123,73 @@ def test_direct_solve_config2_full_size(gpu_ctx):
     for o in (R, D):
         o.destroy()
     prob.destroy()
+
+
+def _overwrite_with(prob, rng, scale_diag):
+    """Replaces every stored entry of prob.K through MatSetValues(INSERT) by an unsymmetric matrix whose diagonal is
+    `scale_diag` times smaller than what stands below it, so that every elimination step exchanges rows.  Returns it dense."""
+    rp, ci, _ = prob.K.get_csr()
+    n = len(rp) - 1
+    A = np.zeros((n, n))
+    for r in range(n):
+        cols = ci[rp[r]:rp[r + 1]]
+        v = rng.uniform(-1.0, 1.0, len(cols))
+        v[cols == r] *= scale_diag
+        prob.K.set_values([r], cols, v, "insert")
+        A[r, cols] = v
+    return A
+
+
+@pytest.mark.parametrize("name,mesh", [
+    ("one_quad", lambda: structured_quad(1, 1)),                      # 8 dofs: one component block (k_comp_lu)
+    ("one_hex", lambda: structured_hex(1, 1, 1)),                     # 24 dofs, block size 3
+    ("quad3x2", lambda: structured_quad(3, 2, jitter=0.1)),           # 24 dofs
+    ("quad12x9", lambda: structured_quad(12, 9, jitter=0.1)),         # 260 dofs > 64: the band LU (k_band_lu)
+])
+def test_lu_with_row_exchanges_against_numpy(gpu_ctx, name, mesh):
+    """Partial pivoting that really exchanges rows (round-3 advice: the batched block LU swapped whole rows, multipliers
+    included, while its solve assumed they stay): MatSetValues(INSERT) of an unsymmetric matrix with a small diagonal on the
+    sparsity of the mesh, `-ksp_type preonly -pc_type lu`, against numpy.linalg.solve."""
+    m = mesh()
+    rng = np.random.default_rng(7)
+    prob = driver.Problem(gpu_ctx, m, LU)
+    prob.create_matrix()
+    prob.K.zero_entries()
+    prob.K.assemble_elements()
+    A = _overwrite_with(prob, rng, 1e-3)
+    rp, ci, v = prob.K.get_csr()
+    B = np.zeros_like(A)
+    for r in range(len(rp) - 1):
+        B[r, ci[rp[r]:rp[r + 1]]] = v[rp[r]:rp[r + 1]]
+    assert np.array_equal(A, B)                                        # MatSetValues(INSERT) wrote what MatView reads
+    prob.ksp.set_operators(prob.K)
+    prob.ksp.set_up()
+    b = rng.uniform(-1.0, 1.0, m.ndof)
+    prob.F.set_array(b)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == 4
+    x = prob.U.get_array()
+    ref = np.linalg.solve(A, b)
+    assert np.abs(A @ x - b).max() <= 1e-10 * np.abs(b).max() * np.linalg.cond(A)
+    assert np.abs(x - ref).max() <= 1e-9 * np.abs(ref).max() * max(1.0, np.linalg.cond(A) * 1e-6)
+    prob.destroy()
+
+
+def test_mat_set_values_semantics(gpu_ctx):
+    """ADD adds, INSERT overwrites, negative indices are skipped, an entry outside the sparsity is refused."""
+    m = structured_quad(3, 1)
+    prob = driver.Problem(gpu_ctx, m, "")
+    prob.assemble()
+    rp, ci, v0 = prob.K.get_csr()
+    prob.K.set_values([0, -1, 1], [1, 0, -3], 1e9 * np.arange(9.0).reshape(3, 3), "add")
+    _, _, v1 = prob.K.get_csr()
+    d = {(r, int(c)): v1[k] - v0[k] for r in range(len(rp) - 1) for k, c in zip(range(rp[r], rp[r + 1]), ci[rp[r]:rp[r + 1]])}
+    want = {(0, 1): 0.0, (0, 0): 1e9, (1, 1): 6e9, (1, 0): 7e9}
+    assert all(abs(d[k] - want.get(k, 0.0)) <= 1e-3 for k in d)
+    prob.K.set_values([2], [2], [5.5], "insert")
+    _, _, v2 = prob.K.get_csr()
+    k22 = rp[2] + list(ci[rp[2]:rp[3]]).index(2)
+    assert v2[k22] == 5.5
+    with pytest.raises(capi.FemError):
+        prob.K.set_values([0], [m.ndof - 1], [1.0], "add")            # node 0 and the last node share no element
+    prob.destroy()

@@ -130,6 +130,8 @@ _SIGS = {
     "fem_comm_get_unique_id": [C.c_char_p],
     "fem_comm_create_rccl": [_h, C.c_int, C.c_int, C.c_char_p, C.POINTER(_h)],
     "fem_comm_create_local_group": [C.c_int, C.POINTER(_h), C.POINTER(_h)],
+    "fem_comm_create_callbacks": [_h, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_h)],
+    "fem_comm_get_stats": [_h, C.POINTER(C.c_longlong)],
     "fem_comm_destroy": [_h],
     "fem_comm_rank": [_h, _ip, _ip],
     "fem_comm_exchange": [_h, C.c_int, _ip, C.POINTER(C.c_longlong), _h, _h],
@@ -301,6 +303,73 @@ class Comm:
         out = (_h * n)()
         _ck(_lib.fem_comm_create_local_group(n, ca, out))
         return [Comm(_h(out[i])) for i in range(n)]
+
+    _AR = C.CFUNCTYPE(None, C.c_void_p, _dp, C.c_int)
+    _EX = C.CFUNCTYPE(None, C.c_void_p, C.c_int, _ip, C.POINTER(C.c_longlong), _dp, _dp)
+
+    @staticmethod
+    def callbacks(ctx: Context, nranks: int, rank: int, allreduce, exchange) -> "Comm":
+        """Host-staged communicator (fem_comm_create_callbacks): `allreduce(buf)` sums the float64 array `buf` over all ranks in
+        place; `exchange(neigh_rank, off, send, recv)` sends send[off[i]:off[i+1]] to neigh_rank[i] and fills the same range of
+        recv from it.  The arrays are views of the library's pinned buffers, valid during the call only.  An exception in a
+        callback cannot cross the C frames: it is kept, the process's peers would wait for ever, so the process is ended."""
+        def _guard(fn):
+            def run(*a):
+                try:
+                    fn(*a)
+                except BaseException:  # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    os._exit(70)
+            return run
+
+        @_guard
+        def ar(_user, buf, n):
+            allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+
+        @_guard
+        def ex(_user, nneigh, nr, off, send, recv):
+            o = np.ctypeslib.as_array(off, shape=(nneigh + 1,))
+            tot = int(o[nneigh])
+            exchange(np.ctypeslib.as_array(nr, shape=(nneigh,)), o,
+                     np.ctypeslib.as_array(send, shape=(max(tot, 1),))[:tot], np.ctypeslib.as_array(recv, shape=(max(tot, 1),))[:tot])
+        car, cex = Comm._AR(ar), Comm._EX(ex)
+        h = _h()
+        _ck(_lib.fem_comm_create_callbacks(ctx.h, nranks, rank, C.cast(car, C.c_void_p), C.cast(cex, C.c_void_p), None, C.byref(h)))
+        c = Comm(h)
+        c._keep = (car, cex)          # the C side holds the function pointers for the communicator's lifetime
+        return c
+
+    @staticmethod
+    def gloo(ctx: Context, group=None) -> "Comm":
+        """The host-staged communicator over torch.distributed's gloo back end (process group already initialised): what
+        bench.py --rehearse and the multi-process tests use to run the N > 1 paths as real processes on one GPU."""
+        import torch
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def allreduce(buf):
+            dist.all_reduce(torch.from_numpy(buf), group=group)
+
+        def exchange(nr, off, send, recv):
+            ts, tr = torch.from_numpy(send), torch.from_numpy(recv)
+            ops = []
+            for i, q in enumerate(nr):
+                a, b = int(off[i]), int(off[i + 1])
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, ts[a:b], int(q), group))
+                    ops.append(dist.P2POp(dist.irecv, tr[a:b], int(q), group))
+            if ops:
+                for w in dist.batch_isend_irecv(ops):
+                    w.wait()
+        return Comm.callbacks(ctx, world, rank, allreduce, exchange)
+
+    def stats(self) -> dict:
+        """fem_comm_get_stats: calls, largest and total count (doubles) of the all-reduces and of the neighbour exchanges."""
+        st = (C.c_longlong * 6)()
+        _ck(_lib.fem_comm_get_stats(self.h, st))
+        return {"allreduce_calls": st[0], "allreduce_max_doubles": st[1], "allreduce_total_doubles": st[2],
+                "exchange_calls": st[3], "exchange_max_doubles": st[4], "exchange_total_doubles": st[5]}
 
     def exchange(self, neigh_rank, off, send: "Vec", recv: "Vec"):
         """Neighbour i gets send[off[i]:off[i+1]]; recv[off[i]:off[i+1]] is filled from neighbour i."""

@@ -56,6 +56,8 @@ fem_comm comm_create_self_impl(fem_ctx);
 void comm_get_unique_id_impl(char*);
 fem_comm comm_create_rccl_impl(fem_ctx, int, int, const char*);
 void comm_create_local_group_impl(int, const fem_ctx*, fem_comm*);
+fem_comm comm_create_callbacks_impl(fem_ctx, int, int, void (*)(void*, double*, int),
+                                    void (*)(void*, int, const int*, const long long*, const double*, double*), void*);
 
 void shape_funcd_impl(fem_ctx, int, int, const double*, double*);
 void form_dn_detj_impl(fem_ctx, int, int, const double*, const double*, double*, double*);
@@ -917,6 +919,23 @@ int fem_comm_create_local_group(int n, const fem_ctx* ctxs, fem_comm* comms)
 {
     FEM_TRY
     comm_create_local_group_impl(n, ctxs, comms);
+    FEM_CATCH
+}
+int fem_comm_create_callbacks(fem_ctx ctx, int nranks, int rank, fem_comm_allreduce_fn allreduce, fem_comm_exchange_fn exchange,
+                              void* user, fem_comm* comm)
+{
+    FEM_TRY
+    FEM_CHECK(comm, 1, "fem_comm_create_callbacks: null output");
+    *comm = comm_create_callbacks_impl(ctx, nranks, rank, allreduce, exchange, user);
+    FEM_CATCH
+}
+int fem_comm_get_stats(fem_comm c, long long* stats)
+{
+    FEM_TRY
+    FEM_CHECK(c && c->impl && stats, 1, "fem_comm_get_stats: null handle");
+    const fem::Comm* m = c->impl;
+    stats[0] = m->n_allreduce; stats[1] = m->max_allreduce; stats[2] = m->sum_allreduce;
+    stats[3] = m->n_exchange; stats[4] = m->max_exchange; stats[5] = m->sum_exchange;
     FEM_CATCH
 }
 int fem_comm_destroy(fem_comm c)

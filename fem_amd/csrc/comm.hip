@@ -87,6 +87,7 @@ struct RcclComm : Comm {
         if (nc && rccl().CommDestroy) rccl().CommDestroy(nc);
     }
     void allreduce_sum(double* dbuf, int n, hipStream_t s) override {
+        note_allreduce(n);
         FEM_NCCL(rccl().AllReduce(dbuf, dbuf, (size_t)n, NCCL_FLOAT64, NCCL_SUM, nc, s));
     }
     // every GPU of an MI355X node has a direct xGMI link to every other one, so
@@ -94,6 +95,7 @@ struct RcclComm : Comm {
     void exchange(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf, double* recvbuf,
                   hipStream_t s) override {
         if (!nneigh) return;
+        note_exchange((long long)off[nneigh]);
         FEM_NCCL(rccl().GroupStart());
         for (int i = 0; i < nneigh; i++) {
             const size_t cnt = off[i + 1] - off[i];
@@ -106,6 +108,8 @@ struct RcclComm : Comm {
     // the CG's p.Kp all-reduce inside the group of the halo exchange that follows it: one RCCL launch per iteration less
     void exchange_allreduce(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf, double* recvbuf,
                             double* red, int nred, hipStream_t s) override {
+        note_allreduce(nred);
+        note_exchange((long long)off[nneigh]);
         FEM_NCCL(rccl().GroupStart());
         FEM_NCCL(rccl().AllReduce(red, red, (size_t)nred, NCCL_FLOAT64, NCCL_SUM, nc, s));
         for (int i = 0; i < nneigh; i++) {
@@ -148,6 +152,7 @@ struct LocalComm : Comm {
     }
     void allreduce_sum(double* dbuf, int n, hipStream_t s) override {
         // (as in exchange below: a failing domain still arrives at both barriers and throws afterwards)
+        note_allreduce(n);
         std::string err;
         std::vector<double>& mine = sh->slots[rank];
         mine.assign((size_t)n, 0.0);
@@ -167,6 +172,7 @@ struct LocalComm : Comm {
                   hipStream_t s) override {
         // A failure on one domain must not strand its peers in a barrier: the error is recorded, every
         // domain still arrives at both barriers, and the failing one throws afterwards.
+        note_exchange(nneigh ? (long long)off[nneigh] : 0);
         std::string err;
         if (hipStreamSynchronize(s) != hipSuccess) err = "local exchange: stream synchronisation failed";
         sh->sendbuf[rank] = sendbuf; sh->neigh_rank[rank] = neigh_rank; sh->off[rank] = off; sh->nneigh[rank] = nneigh;
@@ -186,6 +192,57 @@ struct LocalComm : Comm {
         if (hipStreamSynchronize(s) != hipSuccess && err.empty()) err = "local exchange: stream synchronisation failed";
         sh->barrier();
         FEM_CHECK(err.empty(), 62, err);
+    }
+};
+
+// ---------------------------------------------------------------- Callbacks (host-staged)
+// The two operations are handed to the host program: the data goes through pinned host buffers, the caller's functions run
+// on the calling thread between two stream synchronisations.  This is the back end for a host that already owns a message
+// passing layer -- the reference is an MPI program (Makefile:6-10; MPI_AllReduce src/main.F90:274, Send/Recv src/m_io.F90:150-237):
+// its all-reduce callback is one MPI_Allreduce(MPI_IN_PLACE, ...), its exchange callback a loop of MPI_Sendrecv -- and what
+// bench.py --rehearse drives with torch.distributed's gloo, so that the N > 1 code paths run as real processes on one GPU.
+struct PinnedBuf {
+    double* p = nullptr;
+    size_t n = 0;
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+    double* need(size_t cnt) {
+        if (cnt > n) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr; n = 0;
+            const size_t want = std::max<size_t>(cnt, 64);
+            FEM_HIP(hipHostMalloc((void**)&p, want * sizeof(double), hipHostMallocDefault));
+            n = want;
+        }
+        return p;
+    }
+};
+struct CallbackComm : Comm {
+    void (*ar)(void*, double*, int) = nullptr;
+    void (*ex)(void*, int, const int*, const long long*, const double*, double*) = nullptr;
+    void* user = nullptr;
+    PinnedBuf hred, hsend, hrecv;
+    void allreduce_sum(double* dbuf, int n, hipStream_t s) override {
+        note_allreduce(n);
+        double* h = hred.need((size_t)n);
+        FEM_HIP(hipMemcpyAsync(h, dbuf, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        ar(user, h, n);
+        FEM_HIP(hipMemcpyAsync(dbuf, h, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        FEM_HIP(hipStreamSynchronize(s));   // (the pinned buffer is reused by the next call)
+    }
+    void exchange(int nneigh, const int* neigh_rank, const size_t* off, const double* sendbuf, double* recvbuf,
+                  hipStream_t s) override {
+        if (!nneigh) return;
+        const size_t tot = off[nneigh];
+        note_exchange((long long)tot);
+        double* hs = hsend.need(tot);
+        double* hr = hrecv.need(tot);
+        if (tot) FEM_HIP(hipMemcpyAsync(hs, sendbuf, sizeof(double) * tot, hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        std::vector<long long> o(off, off + nneigh + 1);
+        ex(user, nneigh, neigh_rank, o.data(), hs, hr);
+        if (tot) FEM_HIP(hipMemcpyAsync(recvbuf, hr, sizeof(double) * tot, hipMemcpyHostToDevice, s));
+        FEM_HIP(hipStreamSynchronize(s));
     }
 };
 
@@ -224,12 +281,18 @@ __global__ void __launch_bounds__(256) k_halo_unpack(int ninodes, const int* __r
 
 void halo_sum(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc) { halo_sum_on(mesh, vec, ncomp, sn, sc, mesh->ctx->stream); }
 
-void halo_sum_on(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, hipStream_t s)
+void halo_sum_on(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t sc, hipStream_t s) { halo_sum_h(mesh->halo.get(), vec, ncomp, sn, sc, s, false); }
+
+// the same over any list of shared items (the box levels of the partitioned multigrid keep one Halo per level, mg.hip)
+void halo_sum_h(Halo* h, double* vec, int ncomp, size_t sn, size_t sc, hipStream_t s, bool call_when_empty)
 {
-    Halo* h = mesh->halo.get();
     if (!h || h->comm->size == 1) return;
     const int nslots = h->neigh_ptr[h->nneigh];
-    if (nslots == 0) return;
+    if (nslots == 0) {
+        // the in-process communicator meets at a barrier in every exchange: a domain that shares nothing on this list still has to arrive
+        if (call_when_empty) { const size_t z = 0; h->comm->exchange(0, nullptr, &z, nullptr, nullptr, s); }
+        return;
+    }
     FEM_CHECK((size_t)ncomp <= 6, 63, "halo_sum: too many components");
     hipLaunchKernelGGL(k_halo_pack, dim3(cdiv((size_t)nslots * ncomp, 256)), dim3(256), 0, s, nslots, h->neigh_nodes.p,
                        ncomp, sn, sc, vec, h->sendbuf.p);
@@ -259,29 +322,25 @@ void halo_sum_allreduce(fem_mesh mesh, double* vec, int ncomp, size_t sn, size_t
     FEM_HIP(hipGetLastError());
 }
 
-void mesh_set_halo_impl(fem_mesh mesh, fem_comm comm, int nneigh, const int* neigh_rank, const int* neigh_ptr,
-                        const int* neigh_nodes)
+// interface lists -> Halo: pack list, canonical-order unpack lists, owner flags (lowest rank among the sharers)
+std::unique_ptr<Halo> halo_build(Comm* c, int nitems, int nneigh, const int* neigh_rank, const int* neigh_ptr, const int* neigh_nodes,
+                                 hipStream_t s, const char* who)
 {
-    FEM_CHECK(mesh && comm && comm->impl, 1, "fem_mesh_set_halo: null handle");
-    Comm* c = comm->impl;
-    mesh->ctx->bind();
-    hipStream_t s = mesh->ctx->stream;
     std::unique_ptr<Halo> h(new Halo);
     h->comm = c; h->nneigh = nneigh;
     h->neigh_rank.assign(neigh_rank, neigh_rank + nneigh);
     h->neigh_ptr.assign(neigh_ptr, neigh_ptr + nneigh + 1);
     const int nslots = neigh_ptr[nneigh];
     for (int i = 0; i < nneigh; i++) {
-        FEM_CHECK(neigh_rank[i] >= 0 && neigh_rank[i] < c->size && neigh_rank[i] != c->rank, 3,
-                  "fem_mesh_set_halo: bad neighbour rank");
-        FEM_CHECK(i == 0 || neigh_rank[i] > neigh_rank[i - 1], 3, "fem_mesh_set_halo: neighbour ranks must ascend");
+        FEM_CHECK(neigh_rank[i] >= 0 && neigh_rank[i] < c->size && neigh_rank[i] != c->rank, 3, std::string(who) + ": bad neighbour rank");
+        FEM_CHECK(i == 0 || neigh_rank[i] > neigh_rank[i - 1], 3, std::string(who) + ": neighbour ranks must ascend");
     }
-    std::vector<unsigned char> owned(mesh->nnds, 1);
-    std::map<int, std::vector<std::pair<int, int>>> contrib;  // node -> (rank, recv slot)
+    std::vector<unsigned char> owned((size_t)std::max(nitems, 1), 1);
+    std::map<int, std::vector<std::pair<int, int>>> contrib;  // item -> (rank, recv slot)
     for (int i = 0; i < nneigh; i++)
         for (int k = neigh_ptr[i]; k < neigh_ptr[i + 1]; k++) {
             const int v = neigh_nodes[k];
-            FEM_CHECK(v >= 0 && v < mesh->nnds, 3, "fem_mesh_set_halo: node id out of range");
+            FEM_CHECK(v >= 0 && v < nitems, 3, std::string(who) + ": id out of range");
             if (neigh_rank[i] < c->rank) owned[v] = 0;
             contrib[v].push_back({neigh_rank[i], k});
         }
@@ -300,11 +359,21 @@ void mesh_set_halo_impl(fem_mesh mesh, fem_comm comm, int nneigh, const int* nei
     h->inodes.alloc(std::max<size_t>(inodes.size(), 1)); h->inodes.upload(inodes.data(), inodes.size(), s);
     h->contrib_ptr.alloc(cptr.size()); h->contrib_ptr.upload(cptr.data(), cptr.size(), s);
     h->contrib_src.alloc(std::max<size_t>(csrc.size(), 1)); h->contrib_src.upload(csrc.data(), csrc.size(), s);
-    h->owned.alloc(mesh->nnds); h->owned.upload(owned.data(), owned.size(), s);
+    h->owned.alloc(owned.size()); h->owned.upload(owned.data(), owned.size(), s);
     h->sendbuf.alloc(std::max<size_t>((size_t)nslots * 6, 1));
     h->recvbuf.alloc(std::max<size_t>((size_t)nslots * 6, 1));
     FEM_HIP(hipStreamSynchronize(s));
-    mesh->halo = std::move(h);
+    return h;
+}
+
+void mesh_set_halo_impl(fem_mesh mesh, fem_comm comm, int nneigh, const int* neigh_rank, const int* neigh_ptr,
+                        const int* neigh_nodes)
+{
+    FEM_CHECK(mesh && comm && comm->impl, 1, "fem_mesh_set_halo: null handle");
+    Comm* c = comm->impl;
+    mesh->ctx->bind();
+    hipStream_t s = mesh->ctx->stream;
+    mesh->halo = halo_build(c, mesh->nnds, nneigh, neigh_rank, neigh_ptr, neigh_nodes, s, "fem_mesh_set_halo");
     // global valence (replaces the whole-mesh MPI_AllReduce of src/main.F90:270-275 by one halo sum)
     halo_sum(mesh, mesh->valence_d.p, 1, 1, 0);
     FEM_HIP(hipStreamSynchronize(s));
@@ -350,4 +419,17 @@ void comm_create_local_group_impl(int n, const fem_ctx* ctxs, fem_comm* out)
         auto* c = new LocalComm; c->ctx = ctxs[r]; c->rank = r; c->size = n; c->sh = sh;
         out[r] = new fem_comm_s; out[r]->impl = c;
     }
+}
+
+fem_comm comm_create_callbacks_impl(fem_ctx ctx, int nranks, int rank, void (*ar)(void*, double*, int),
+                                    void (*ex)(void*, int, const int*, const long long*, const double*, double*), void* user)
+{
+    FEM_CHECK(ctx, 1, "fem_comm_create_callbacks: null context");
+    FEM_CHECK(nranks >= 1 && rank >= 0 && rank < nranks, 2, "fem_comm_create_callbacks: bad rank/size");
+    FEM_CHECK(ar && ex, 2, "fem_comm_create_callbacks: both callbacks are needed");
+    ctx->bind();
+    auto* c = new CallbackComm;
+    c->ctx = ctx; c->rank = rank; c->size = nranks; c->ar = ar; c->ex = ex; c->user = user;
+    auto* h = new fem_comm_s; h->impl = c;
+    return h;
 }

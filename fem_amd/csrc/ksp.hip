@@ -371,7 +371,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-pc_mg_alpha") { is >> k->mg_alpha; }     // coarse-correction scaling (over-correction)
         else if (key == "-pc_mg_box") { is >> k->mg_box; FEM_CHECK(k->mg_box >= 2.0 && k->mg_box <= 16.0, 6, "-pc_mg_box must lie in [2, 16]"); }
         else if (key == "-pc_mg_omega") { is >> k->mg_omega; }
-        else if (key == "-pc_mg_slice_min") { is >> k->mg_slice_min; }   // partitioned meshes: see mg.h     // Jacobi damping of the smoother
+        else if (key == "-pc_mg_slice_min") { is >> k->mg_slice_min; }   // accepted and ignored (round 3's sliced level-1 residuals: the box levels are distributed now, mg.h)     // Jacobi damping of the smoother
         else if (key == "-mat_mult_type") {
             is >> val;
             FEM_CHECK(val == "assembled" || val == "ebe" || val == "ebe_gather", 6,
@@ -444,7 +444,6 @@ void ksp_set_up_impl(fem_ksp k)
         k->mg->alpha = (k->mg_alpha > 0.0) ? k->mg_alpha : (k->mg_additive ? 1.5 : 1.0);
         k->mg->omega = k->mg_omega;
         k->mg->box = k->mg_box;
-        k->mg->slice_min = k->mg_slice_min;
         k->mg->setup(A);
         k->z.alloc(n);
     }

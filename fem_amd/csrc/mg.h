@@ -10,15 +10,17 @@
 //   P     rigid-body modes of each box (translations + rotations about the box centre: 6 coarse
 //         dofs per box in 3-D, 3 in 2-D), zero on penalty dofs
 //   A_c   = P^T A P (Galerkin), exact dense inverse on the coarsest grid
-// Partitioned meshes: the boxes are cells of one grid over the global bounding box; the level-1
-// operator is the all-reduced sum of the domains' P_r^T K_r P_r, the whole box hierarchy is replicated
-// on every domain (identical arithmetic on identical data), each application all-reduces the level-1
-// residual once; restriction counts shared nodes at their owner, prolongation is local.
+// Partitioned meshes: the boxes are cells of one grid over the global bounding box.  Every domain keeps, per
+// level, the sub-grid its nodes reach and its own part P_r^T K_r P_r of the operator; a box holding nodes of
+// several domains is shared like an interface node (one neighbour exchange sums over the sharers, in ascending
+// rank order: all copies stay bitwise equal).  Only the coarsest level (<= 125 boxes) is replicated, through an
+// all-reduce of at most 750 numbers per application.  No collective grows with the mesh.
 //   cycle V(1,1), symmetric -> valid CG preconditioner; damped point Jacobi on the fine level, damped
 //         block Jacobi (one box = one block) on the box levels with omega = 4/(3*1.1*lambda_max estimate)
 #pragma once
 #include <vector>
 
+#include "comm.h"
 #include "objects.h"
 
 namespace fem {
@@ -29,6 +31,13 @@ struct MgLevel {
     DBuf<double> st;    // [27][cs*cs][nb]  stencil entries, box index fastest
     DBuf<double> dinv;  // [cs*cs][nb]  inverse of the diagonal block of every box (block-Jacobi smoother)
     DBuf<double> x, r, t;   // [nb*cs] iterate, right-hand side, residual
+    // partitioned mesh: nx x ny x nz is the sub-grid of the global box grid that this domain's nodes reach, `off` its origin in
+    // the global grid, `sh` what relates it to the next level's sub-grid (parent = (index + sh) >> 1); the boxes that also hold
+    // nodes of other domains are shared like interface nodes (one Halo per level), `st` is this domain's part of the operator and
+    // `diag` the diagonal blocks summed over the sharers.  Undivided mesh: off = sh = 0, no halo.
+    int off[3] = {0, 0, 0}, sh[3] = {0, 0, 0};
+    std::unique_ptr<Halo> halo;
+    DBuf<double> diag;
 };
 
 struct Multigrid {
@@ -37,7 +46,6 @@ struct Multigrid {
     double omega = 0.7, alpha = 1.5;   // upper bound of the fine-level Jacobi damping (V-cycle form); scaling of the coarse correction
     double omega_fine = 0.7, lambda_fine = 0.0;   // damping actually used: min(omega, 1.6 / lambda_max estimate)
     double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
-    int slice_min = 32768;          // partitioned mesh: split the level-1 residuals among the domains from this many boxes on (-pc_mg_slice_min)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     DBuf<int> agg;                  // [nn] level-1 box of every node

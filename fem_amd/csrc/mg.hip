@@ -21,6 +21,12 @@ struct Grid3 {
     int nx, ny, nz;
     __host__ __device__ int nb() const { return nx * ny * nz; }
 };
+// Between a box level and the next coarser one: parent index = (child index + shift) >> 1 per direction.  Zero on an undivided
+// mesh; on a partitioned mesh every domain keeps, per level, only the sub-grid of the global box grid its nodes reach, and the
+// shift is what is left of the sub-grid's origin (its parity -- or all of it below the replicated coarsest level).
+struct Shift3 {
+    int x, y, z;
+};
 
 // ---- set-up kernels (integer / one-off work) ----------------------------------------------------
 __global__ void __launch_bounds__(256) k_bbox_partial(size_t nn, int pd, const double* __restrict__ coords,
@@ -44,16 +50,19 @@ __global__ void __launch_bounds__(256) k_bbox_partial(size_t nn, int pd, const d
         }
 }
 
+// (gg: the global box grid, lo its corner -- every domain of a partitioned mesh evaluates the same expression on the same
+// coordinates, so all copies of a shared node land in the same box; g / off: this domain's sub-grid and its origin in gg)
 __global__ void __launch_bounds__(256) k_assign_boxes(int nn, int pd, const double* __restrict__ coords, double lo0,
-                                                      double lo1, double lo2, double invH, Grid3 g,
+                                                      double lo1, double lo2, double invH, Grid3 gg, Grid3 g, Shift3 off,
                                                       int* __restrict__ agg, int* __restrict__ cnt)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nn) return;
     const double lo[3] = {lo0, lo1, lo2};
-    const int dim[3] = {g.nx, g.ny, g.nz};
+    const int dim[3] = {gg.nx, gg.ny, gg.nz};
+    const int o[3] = {off.x, off.y, off.z};
     int idx[3] = {0, 0, 0};
-    for (int d = 0; d < pd; d++) idx[d] = min(max((int)floor((coords[(size_t)v * pd + d] - lo[d]) * invH), 0), dim[d] - 1);
+    for (int d = 0; d < pd; d++) idx[d] = min(max((int)floor((coords[(size_t)v * pd + d] - lo[d]) * invH), 0), dim[d] - 1) - o[d];
     const int b = idx[0] + g.nx * (idx[1] + g.ny * idx[2]);
     agg[v] = b;
     atomicAdd(&cnt[b], 1);
@@ -200,14 +209,17 @@ __device__ __forceinline__ void box_matrix(const double (&d)[3], double (&T)[CS 
     }
 }
 // geometry of a box level: centre of box b
+// (lo: corner of the GLOBAL grid; off: origin of this domain's sub-grid in it -- the centre of a box comes out of the same
+// expression on every domain that holds the box, bit for bit)
 struct BoxGeom {
     double lo[3], H;
+    int off[3];
 };
 __device__ __forceinline__ void box_centre(const Grid3& g, const BoxGeom& geo, int b, double (&c)[3])
 {
-    c[0] = geo.lo[0] + ((b % g.nx) + 0.5) * geo.H;
-    c[1] = geo.lo[1] + (((b / g.nx) % g.ny) + 0.5) * geo.H;
-    c[2] = geo.lo[2] + ((b / (g.nx * g.ny)) + 0.5) * geo.H;
+    c[0] = geo.lo[0] + ((b % g.nx + geo.off[0]) + 0.5) * geo.H;
+    c[1] = geo.lo[1] + (((b / g.nx) % g.ny + geo.off[1]) + 0.5) * geo.H;
+    c[2] = geo.lo[2] + ((b / (g.nx * g.ny) + geo.off[2]) + 0.5) * geo.H;
 }
 template <int PD>
 __device__ __forceinline__ void node_offset(const double* coords, int v, const double (&c)[3], double (&d)[3])
@@ -349,7 +361,7 @@ __global__ void __launch_bounds__(256) k_galerkin_mirror(Grid3 g, double* __rest
 
 // A_{l+1} = T^T A_l T between two box levels (children = 2x2x2 boxes), T = [I, R(d); 0, I]
 template <int CS>
-__global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc,
+__global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc, Shift3 sh,
                                                       const double* __restrict__ stf, double* __restrict__ stc)
 {
     constexpr int CC = CS * CS;
@@ -368,8 +380,8 @@ __global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, BoxGeom geof, Gr
         box_centre(gc, geoc, A, cA);
         box_centre(gc, geoc, T, cT);
         for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
-            const int fx = 2 * ax + cx, fy = 2 * ay + cy, fz = 2 * az + cz;
-            if (fx >= gf.nx || fy >= gf.ny || fz >= gf.nz) continue;
+            const int fx = 2 * ax + cx - sh.x, fy = 2 * ay + cy - sh.y, fz = 2 * az + cz - sh.z;
+            if (fx < 0 || fy < 0 || fz < 0 || fx >= gf.nx || fy >= gf.ny || fz >= gf.nz) continue;
             const int a = fx + gf.nx * (fy + gf.ny * fz);
             double ca[3], da[3], Ta[CC];
             box_centre(gf, geof, a, ca);
@@ -378,7 +390,7 @@ __global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, BoxGeom geof, Gr
             for (int s = 0; s < 27; s++) {
                 int b;
                 if (!neighbour_box(gf, a, s, b)) continue;
-                const int bx = (b % gf.nx) >> 1, by = ((b / gf.nx) % gf.ny) >> 1, bz = (b / (gf.nx * gf.ny)) >> 1;
+                const int bx = (b % gf.nx + sh.x) >> 1, by = ((b / gf.nx) % gf.ny + sh.y) >> 1, bz = (b / (gf.nx * gf.ny) + sh.z) >> 1;
                 if (bx + gc.nx * (by + gc.ny * bz) != T) continue;
                 double cb[3], db[3], Tb[CC], ST[CC];
                 box_centre(gf, geof, b, cb);
@@ -408,7 +420,8 @@ __global__ void __launch_bounds__(256) k_galerkin_box(Grid3 gf, BoxGeom geof, Gr
 // Rank-deficient blocks (boxes with fewer than three non-collinear free nodes, or none) get the
 // same relative shift as the coarsest matrix.
 template <int CS>
-__global__ void __launch_bounds__(256) k_level_dinv(int nb, const double* __restrict__ st, double* __restrict__ dinv)
+// (diag: the CS x CS diagonal blocks [CS*CS][nb] -- slot 13 of the stencil, or, on a partitioned mesh, its sum over the domains)
+__global__ void __launch_bounds__(256) k_level_dinv(int nb, const double* __restrict__ diag, double* __restrict__ dinv)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
@@ -417,7 +430,7 @@ __global__ void __launch_bounds__(256) k_level_dinv(int nb, const double* __rest
     for (int r = 0; r < CS; r++)
 #pragma unroll
         for (int c = 0; c < CS; c++) {
-            D[r][c] = st[((size_t)13 * CS * CS + r * CS + c) * nb + b];
+            D[r][c] = diag[((size_t)r * CS + c) * nb + b];
             D[r][CS + c] = (r == c) ? 1.0 : 0.0;
         }
     double tr = 0.0;
@@ -478,12 +491,29 @@ __global__ void __launch_bounds__(256) k_hash_fill(size_t n, double* __restrict_
         x[i] = 0.5 + (double)(h & 0xffffu) / 65536.0;
     }
 }
-// out = sum x_i^2 (single workgroup; coarse levels only, set-up time)
-__global__ void __launch_bounds__(1024) k_norm2_small(size_t n, const double* __restrict__ x, double* __restrict__ out)
+// the same on a box level of a partitioned mesh: the value of a box entry depends on the box's GLOBAL index only, so that every
+// domain holding the box starts the power iteration from the same number
+template <int CS>
+__global__ void __launch_bounds__(256) k_hash_fill_box(Grid3 g, Shift3 off, Grid3 gg, double* __restrict__ x)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= g.nb()) return;
+    const int ix = b % g.nx + off.x, iy = (b / g.nx) % g.ny + off.y, iz = b / (g.nx * g.ny) + off.z;
+    const size_t gb = (size_t)ix + (size_t)gg.nx * ((size_t)iy + (size_t)gg.ny * iz);
+    for (int q = 0; q < CS; q++) {
+        unsigned int h = (unsigned int)(gb * CS + q) * 2654435761u + 12345u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        x[(size_t)b * CS + q] = 0.5 + (double)(h & 0xffffu) / 65536.0;
+    }
+}
+// out = sum x_i^2 (single workgroup; coarse levels only, set-up time); own (may be null): [n / cs] 1 where the entry's box counts
+// (partitioned mesh: a shared box is counted by its owner, the sums are then all-reduced)
+__global__ void __launch_bounds__(1024) k_norm2_small(size_t n, const double* __restrict__ x, double* __restrict__ out,
+                                                      const unsigned char* __restrict__ own = nullptr, int cs = 1)
 {
     __shared__ double sh[16];
     double a = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) a += x[i] * x[i];
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) a += (!own || own[i / cs]) ? x[i] * x[i] : 0.0;
     for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
     __syncthreads();
@@ -504,9 +534,11 @@ __global__ void k_set_omega(const double* __restrict__ n2, double* __restrict__ 
 // ---- cycle kernels ------------------------------------------------------------------------------------
 // t = r - A x on a box level (27-point block stencil, thread per box)
 template <int CS>
+// (own, may be null: partitioned mesh -- st is this domain's sub-assembled part of the operator and r counts on the owner of a
+// shared box only, so that the halo sum of t over the domains is r - A x)
 __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, int b0, int b1, const double* __restrict__ st,
                                                       const double* __restrict__ x, const double* __restrict__ r,
-                                                      double* __restrict__ t)
+                                                      double* __restrict__ t, const unsigned char* __restrict__ own)
 {
     constexpr int CC = CS * CS;
     const int nb = g.nb();
@@ -514,7 +546,7 @@ __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, int b0, int b1, c
     if (b >= b1) return;
     double acc[CS];
 #pragma unroll
-    for (int q = 0; q < CS; q++) acc[q] = r[(size_t)b * CS + q];
+    for (int q = 0; q < CS; q++) acc[q] = (!own || own[b]) ? r[(size_t)b * CS + q] : 0.0;
     for (int s = 0; s < 27; s++) {
         int c;
         if (!neighbour_box(g, b, s, c)) continue;
@@ -532,7 +564,7 @@ __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, int b0, int b1, c
 template <int CS>
 __global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, int b0, int b1, const double* __restrict__ st,
                                                             const double* __restrict__ x, const double* __restrict__ r,
-                                                            double* __restrict__ t)
+                                                            double* __restrict__ t, const unsigned char* __restrict__ own)
 {
     constexpr int CC = CS * CS;
     const int nb = b1;   // boxes b0 .. b1-1 (the stencil arrays keep the stride of the whole level)
@@ -554,17 +586,8 @@ __global__ void __launch_bounds__(256) k_box_residual_slots(Grid3 g, int b0, int
         for (int o = 16; o > 0; o >>= 1) acc[q] += __shfl_down(acc[q], o, 32);
     if (b < nb && s == 0) {
 #pragma unroll
-        for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = r[(size_t)b * CS + q] + acc[q];
+        for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = ((!own || own[b]) ? r[(size_t)b * CS + q] : 0.0) + acc[q];
     }
-}
-
-// v[i] = 0 for the entries of the boxes outside b0 .. b1-1 (before the all-reduce that re-unites the slices)
-__global__ void __launch_bounds__(256) k_zero_outside(size_t n, size_t i0, size_t i1, double* __restrict__ v)
-{
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t st = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += st)
-        if (i < i0 || i >= i1) v[i] = 0.0;
 }
 
 // x = omega * dinv * r
@@ -679,7 +702,7 @@ __global__ void __launch_bounds__(256) k_additive_finish(int nn, Grid3 g, BoxGeo
 
 // r_{l+1}[A] = sum over the children a of A of T_a^T t_l[a]
 template <int CS>
-__global__ void __launch_bounds__(256) k_restrict_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc,
+__global__ void __launch_bounds__(256) k_restrict_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc, Shift3 sh,
                                                       const double* __restrict__ tf, double* __restrict__ rc)
 {
     const int A = blockIdx.x * blockDim.x + threadIdx.x;
@@ -690,8 +713,8 @@ __global__ void __launch_bounds__(256) k_restrict_box(Grid3 gf, BoxGeom geof, Gr
 #pragma unroll
     for (int q = 0; q < CS; q++) acc[q] = 0.0;
     for (int cz = 0; cz < 2; cz++) for (int cy = 0; cy < 2; cy++) for (int cx = 0; cx < 2; cx++) {
-        const int fx = 2 * ax + cx, fy = 2 * ay + cy, fz = 2 * az + cz;
-        if (fx >= gf.nx || fy >= gf.ny || fz >= gf.nz) continue;
+        const int fx = 2 * ax + cx - sh.x, fy = 2 * ay + cy - sh.y, fz = 2 * az + cz - sh.z;
+        if (fx < 0 || fy < 0 || fz < 0 || fx >= gf.nx || fy >= gf.ny || fz >= gf.nz) continue;
         const int a = fx + gf.nx * (fy + gf.ny * fz);
         double ca[3], d[3], F[CS];
         box_centre(gf, geof, a, ca);
@@ -706,12 +729,12 @@ __global__ void __launch_bounds__(256) k_restrict_box(Grid3 gf, BoxGeom geof, Gr
 
 // x_l[a] += alpha * T_a x_{l+1}[parent(a)]
 template <int CS>
-__global__ void __launch_bounds__(256) k_prolong_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc, double alpha,
+__global__ void __launch_bounds__(256) k_prolong_box(Grid3 gf, BoxGeom geof, Grid3 gc, BoxGeom geoc, Shift3 sh, double alpha,
                                                      const double* __restrict__ xc, double* __restrict__ xf)
 {
     const int a = blockIdx.x * blockDim.x + threadIdx.x;
     if (a >= gf.nb()) return;
-    const int px = (a % gf.nx) >> 1, py = ((a / gf.nx) % gf.ny) >> 1, pz = (a / (gf.nx * gf.ny)) >> 1;
+    const int px = (a % gf.nx + sh.x) >> 1, py = ((a / gf.nx) % gf.ny + sh.y) >> 1, pz = (a / (gf.nx * gf.ny) + sh.z) >> 1;
     const int A = px + gc.nx * (py + gc.ny * pz);
     double ca[3], cA[3], d[3], x[CS];
     box_centre(gf, geof, a, ca);
@@ -827,13 +850,14 @@ __global__ void __launch_bounds__(256) k_dense_apply(int n, const double* __rest
 static unsigned g1(size_t n) { return std::max(1u, cdiv(n, 256)); }
 static unsigned gs(size_t n) { return std::min<unsigned>(std::max(1u, cdiv(n, 256)), 2048); }
 static Grid3 grid_of(const MgLevel& L) { return Grid3{L.nx, L.ny, L.nz}; }
-static BoxGeom geom_of(const MgLevel& L) { return BoxGeom{{L.lo[0], L.lo[1], L.lo[2]}, L.H}; }
+static BoxGeom geom_of(const MgLevel& L) { return BoxGeom{{L.lo[0], L.lo[1], L.lo[2]}, L.H, {L.off[0], L.off[1], L.off[2]}}; }
+static Shift3 shift_of(const MgLevel& L) { return Shift3{L.sh[0], L.sh[1], L.sh[2]}; }
 
 // returns false when the box grid is too fine for the mesh (an element spans more than two boxes)
 template <int BS, int PD>
 static bool setup_t(Multigrid& mg)
 {
-    constexpr int CS = CoarseDofs<BS>::value;
+    constexpr int CS = CoarseDofs<BS>::value, CC = CS * CS;
     fem_mat A = mg.A;
     fem_mesh mesh = A->mesh;
     fem_ctx ctx = A->ctx;
@@ -841,8 +865,11 @@ static bool setup_t(Multigrid& mg)
     const int nn = mesh->nnds;
     const size_t ndof = (size_t)nn * BS;
     mg.cs = CS;
-    // partitioned mesh: the box grid is laid over the GLOBAL bounding box, so every domain sees the
-    // same boxes; the coarse hierarchy is replicated on every domain (see Multigrid::setup)
+    // Partitioned mesh: the boxes are cells of ONE grid over the global bounding box.  Every domain keeps, per level, the
+    // sub-grid its own nodes reach and its own part P_r^T K_r P_r of the operator (K_r sub-assembled, the same P on every
+    // copy of a shared node: the parts add up to the global Galerkin operator); a box that holds nodes of several domains is
+    // shared like an interface node of the fine level, and the box levels are applied like the fine one: local product with
+    // the own part + sum over the sharers (one neighbour exchange).  Only the coarsest level (<= 125 boxes) is replicated.
     Halo* halo = mesh->halo.get();
     Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
     // bounding box
@@ -856,13 +883,13 @@ static bool setup_t(Multigrid& mg)
     for (int b = 0; b < pg; b++)
         for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], hbb[b * 6 + d]); hi[d] = std::max(hi[d], hbb[b * 6 + 3 + d]); }
     double nn_global = nn;
+    const int nr = comm ? comm->size : 1, me = comm ? comm->rank : 0;
+    std::vector<double> tab((size_t)nr * 7, 0.0);   // every domain's bounding box (and its count of owned nodes)
+    for (int d = 0; d < 3; d++) { tab[(size_t)me * 7 + d] = lo[d]; tab[(size_t)me * 7 + 3 + d] = hi[d]; }
     if (comm) {
         // min / max / node count over the domains through the one collective there is: every domain
         // fills its own slot of a zeroed table, the sum of the tables is the table of all domains
-        const int nr = comm->size;
-        std::vector<double> tab((size_t)nr * 7, 0.0);
         DBuf<double> dtab(tab.size());
-        for (int d = 0; d < 3; d++) { tab[(size_t)comm->rank * 7 + d] = lo[d]; tab[(size_t)comm->rank * 7 + 3 + d] = hi[d]; }
         dtab.upload(tab.data(), tab.size(), s);
         hipLaunchKernelGGL(k_count_owned, dim3(64), dim3(256), 0, s, nn, halo->owned.p, dtab.p + (size_t)comm->rank * 7 + 6);
         comm->allreduce_sum(dtab.p, (int)tab.size(), s);
@@ -884,13 +911,57 @@ static bool setup_t(Multigrid& mg)
     for (int d = PD; d < 3; d++) lo[d] = -0.5 * H;   // flat direction: the single box layer is centred on z = 0
     FEM_CHECK((long long)g.nx * g.ny * g.nz < (1LL << 26), 9, "pc mg: box grid too large");
 
+    // the levels of the global grid: 2x2x2 boxes merge until the grid is at most 5 boxes per direction
+    // (<= 750 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
+    std::vector<Grid3> G{g};
+    while (std::max(G.back().nx, std::max(G.back().ny, G.back().nz)) > 5)
+        G.push_back(Grid3{(G.back().nx + 1) / 2, (G.back().ny + 1) / 2, (G.back().nz + 1) / 2});
+    const int nlev = (int)G.size();
+    // index range of every domain's boxes on level 1 (the same expression as k_assign_boxes, monotone in the coordinate);
+    // level l: both ends >> l; the coarsest level is the whole global grid on every domain
+    const double invH = 1.0 / H;
+    const int gdim[3] = {g.nx, g.ny, g.nz};
+    std::vector<int> ext((size_t)nr * 6, 0);
+    for (int r = 0; r < nr; r++)
+        for (int d = 0; d < PD; d++) {
+            ext[(size_t)r * 6 + d] = std::min(std::max((int)std::floor((tab[(size_t)r * 7 + d] - lo[d]) * invH), 0), gdim[d] - 1);
+            ext[(size_t)r * 6 + 3 + d] = std::min(std::max((int)std::floor((tab[(size_t)r * 7 + 3 + d] - lo[d]) * invH), 0), gdim[d] - 1);
+        }
+    auto range_of = [&](int r, int l, int d, int& a, int& b) {   // global index range of domain r on level l
+        const int gl[3] = {G[(size_t)l].nx, G[(size_t)l].ny, G[(size_t)l].nz};
+        if (l == nlev - 1 || !comm) { a = 0; b = gl[d] - 1; return; }
+        a = ext[(size_t)r * 6 + d] >> l; b = ext[(size_t)r * 6 + 3 + d] >> l;
+    };
+
+    DBuf<int> err(1);
+    err.zero(s);
+    mg.lev.clear();
+    double Hl = H;
+    for (int l = 0; l < nlev; l++, Hl *= 2.0) {
+        mg.lev.emplace_back();
+        MgLevel& L = mg.lev.back();
+        int dims[3];
+        for (int d = 0; d < 3; d++) { int a, b; range_of(me, l, d, a, b); L.off[d] = a; dims[d] = b - a + 1; }
+        L.nx = dims[0]; L.ny = dims[1]; L.nz = dims[2]; L.nb = L.nx * L.ny * L.nz;
+        for (int d = 0; d < 3; d++) L.lo[d] = lo[d];
+        if (PD == 2) L.lo[2] = -0.5 * Hl;   // keep the single layer centred on z = 0
+        L.H = Hl;
+        L.st.alloc((size_t)27 * CC * L.nb);
+        L.dinv.alloc((size_t)L.nb * CC); L.x.alloc((size_t)L.nb * CS); L.r.alloc((size_t)L.nb * CS);
+        L.t.alloc((size_t)L.nb * CS);
+    }
+    for (int l = 0; l + 1 < nlev; l++)
+        for (int d = 0; d < 3; d++) mg.lev[(size_t)l].sh[d] = mg.lev[(size_t)l].off[d] - 2 * mg.lev[(size_t)l + 1].off[d];
+
     // level-1 aggregates and their node lists
+    MgLevel& L1 = mg.lev[0];
+    const Grid3 g1l = grid_of(L1);
     mg.agg.alloc(nn);
-    int nb = g.nb();
+    const int nb = L1.nb;
     DBuf<int> cnt((size_t)nb), cursor((size_t)nb), tmp(exclusive_scan_tmp_ints((size_t)nb + 1));
     cnt.zero(s); cursor.zero(s);
-    hipLaunchKernelGGL(k_assign_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, PD, mesh->coords.p, lo[0], lo[1], lo[2], 1.0 / H,
-                       g, mg.agg.p, cnt.p);
+    hipLaunchKernelGGL(k_assign_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, PD, mesh->coords.p, lo[0], lo[1], lo[2], invH,
+                       g, g1l, Shift3{L1.off[0], L1.off[1], L1.off[2]}, mg.agg.p, cnt.p);
     mg.box_ptr.alloc((size_t)nb + 1);
     exclusive_scan_i32(cnt.p, mg.box_ptr.p, nb, tmp.p, s);
     mg.box_nodes.alloc((size_t)nn);
@@ -907,33 +978,13 @@ static bool setup_t(Multigrid& mg)
         hipLaunchKernelGGL(k_owner_weights, dim3(g1(nn)), dim3(256), 0, s, nn, BS, mg.w.p, halo->owned.p, mg.wr.p);
     }
 
-    DBuf<int> err(1);
-    err.zero(s);
-    mg.lev.clear();
-    auto new_level = [&](Grid3 gg, double Hl) {
-        mg.lev.emplace_back();
-        MgLevel& L = mg.lev.back();
-        L.nx = gg.nx; L.ny = gg.ny; L.nz = gg.nz; L.nb = gg.nb();
-        for (int d = 0; d < 3; d++) L.lo[d] = lo[d];
-        L.H = Hl;
-        L.st.alloc((size_t)27 * CS * CS * L.nb);
-        L.dinv.alloc((size_t)L.nb * CS * CS); L.x.alloc((size_t)L.nb * CS); L.r.alloc((size_t)L.nb * CS);
-        L.t.alloc((size_t)L.nb * CS);
-    };
-    new_level(g, H);
-    if (PD == 2) mg.lev[0].lo[2] = -0.5 * H;
-    hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g, geom_of(mg.lev[0]),
+    // this domain's part of the level-1 operator
+    hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g1l, geom_of(L1),
                        mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->values(),
-                       mg.w.p, mg.lev[0].st.p, err.p);
-    hipLaunchKernelGGL((k_galerkin_mirror<CS>), dim3(g1((size_t)13 * CS * CS * nb)), dim3(256), 0, s, g, mg.lev[0].st.p);
+                       mg.w.p, L1.st.p, err.p);
+    hipLaunchKernelGGL((k_galerkin_mirror<CS>), dim3(g1((size_t)13 * CC * nb)), dim3(256), 0, s, g1l, L1.st.p);
     if (comm) {
-        // A_1 = sum over the domains of P_r^T K_r P_r (sub-assembled matrices, same P on shared nodes);
-        // the flag travels along so that every domain raises the same error
-        {
-            const size_t total = (size_t)27 * CS * CS * nb, chunk = (size_t)1 << 28;   // 2 GiB of doubles per call
-            for (size_t o = 0; o < total; o += chunk)
-                comm->allreduce_sum(mg.lev[0].st.p + o, (int)std::min(chunk, total - o), s);
-        }
+        // the flag travels so that every domain raises the same error
         DBuf<double> derr(1);
         int herr0 = 0;
         err.download(&herr0, 1, s);
@@ -954,21 +1005,107 @@ static bool setup_t(Multigrid& mg)
         FEM_HIP(hipStreamSynchronize(s));
         if (herr) return false;
     }
-    hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(nb)), dim3(256), 0, s, nb, mg.lev[0].st.p, mg.lev[0].dinv.p);
-    // coarser levels: merge 2x2x2 boxes until the grid is at most 5 boxes per direction
-    // (<= 750 dofs: inverted densely; every extra tiny level would cost seven latency-bound launches)
-    double Hl = H;
-    while (std::max(g.nx, std::max(g.ny, g.nz)) > 5) {
-        Grid3 gc{(g.nx + 1) / 2, (g.ny + 1) / 2, (g.nz + 1) / 2};
-        Hl *= 2.0;
-        new_level(gc, Hl);
-        MgLevel& Lf = mg.lev[mg.lev.size() - 2];
+    // coarser levels: T^T A_l T of the domain's own part, level by level (Galerkin products are linear in the operator)
+    for (int l = 1; l < nlev; l++) {
+        MgLevel& Lf = mg.lev[(size_t)l - 1];
+        MgLevel& Lc = mg.lev[(size_t)l];
+        hipLaunchKernelGGL(k_galerkin_box<CS>, dim3(g1((size_t)27 * Lc.nb)), dim3(256), 0, s, grid_of(Lf), geom_of(Lf), grid_of(Lc),
+                           geom_of(Lc), shift_of(Lf), Lf.st.p, Lc.st.p);
+    }
+    if (comm) {
+        // the replicated coarsest operator: the sum of the parts (at most 27 * 36 * 125 numbers, whatever the mesh)
         MgLevel& Lc = mg.lev.back();
-        if (PD == 2) Lc.lo[2] = -0.5 * Hl;   // keep the single layer centred on z = 0
-        hipLaunchKernelGGL(k_galerkin_box<CS>, dim3(g1((size_t)27 * gc.nb())), dim3(256), 0, s, g, geom_of(Lf), gc,
-                           geom_of(Lc), Lf.st.p, Lc.st.p);
-        hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(gc.nb())), dim3(256), 0, s, gc.nb(), Lc.st.p, Lc.dinv.p);
-        g = gc;
+        comm->allreduce_sum(Lc.st.p, (int)((size_t)27 * CC * Lc.nb), s);
+    }
+    // shared boxes, level by level: a box is shared with every other domain that also holds a node in it (level 1) / a child of
+    // it (coarser levels).  The domains whose index ranges overlap exchange their occupancy of the overlap (one neighbour
+    // exchange per level, a few thousand numbers), the boxes occupied on both sides are the shared ones -- in the same
+    // (global lexicographic) order on both sides.
+    if (comm) {
+        std::vector<unsigned char> occ;
+        {
+            std::vector<int> hcnt((size_t)nb);
+            cnt.download(hcnt.data(), hcnt.size(), s);
+            FEM_HIP(hipStreamSynchronize(s));
+            occ.resize((size_t)nb);
+            for (int b = 0; b < nb; b++) occ[(size_t)b] = hcnt[(size_t)b] > 0;
+        }
+        for (int l = 0; l + 1 < nlev; l++) {
+            MgLevel& L = mg.lev[(size_t)l];
+            int a0[3], a1[3];
+            for (int d = 0; d < 3; d++) range_of(me, l, d, a0[d], a1[d]);
+            struct Cand { int q; int r0[3], r1[3]; size_t n; };
+            std::vector<Cand> cand;
+            std::vector<size_t> off{0};
+            for (int q = 0; q < nr; q++) {
+                if (q == me) continue;
+                Cand c; c.q = q; c.n = 1;
+                bool ov = true;
+                for (int d = 0; d < 3; d++) {
+                    int b0, b1;
+                    range_of(q, l, d, b0, b1);
+                    c.r0[d] = std::max(a0[d], b0); c.r1[d] = std::min(a1[d], b1);
+                    if (c.r0[d] > c.r1[d]) ov = false;
+                    else c.n *= (size_t)(c.r1[d] - c.r0[d] + 1);
+                }
+                if (!ov) continue;
+                cand.push_back(c);
+                off.push_back(off.back() + c.n);
+            }
+            std::vector<double> sb(std::max<size_t>(off.back(), 1), 0.0), rb(std::max<size_t>(off.back(), 1), 0.0);
+            for (size_t k = 0; k < cand.size(); k++) {
+                const Cand& c = cand[k];
+                size_t p = off[k];
+                for (int iz = c.r0[2]; iz <= c.r1[2]; iz++)
+                    for (int iy = c.r0[1]; iy <= c.r1[1]; iy++)
+                        for (int ix = c.r0[0]; ix <= c.r1[0]; ix++)
+                            sb[p++] = occ[(size_t)(ix - a0[0]) + (size_t)L.nx * ((size_t)(iy - a0[1]) + (size_t)L.ny * (size_t)(iz - a0[2]))] ? 1.0 : 0.0;
+            }
+            DBuf<double> dsb(sb.size()), drb(rb.size());
+            dsb.upload(sb.data(), sb.size(), s);
+            std::vector<int> cr;
+            for (auto& c : cand) cr.push_back(c.q);
+            comm->exchange((int)cand.size(), cr.data(), off.data(), dsb.p, drb.p, s);
+            drb.download(rb.data(), rb.size(), s);
+            FEM_HIP(hipStreamSynchronize(s));
+            std::vector<int> nrk, nptr{0}, nbox;
+            for (size_t k = 0; k < cand.size(); k++) {
+                const Cand& c = cand[k];
+                size_t p = off[k];
+                const size_t before = nbox.size();
+                for (int iz = c.r0[2]; iz <= c.r1[2]; iz++)
+                    for (int iy = c.r0[1]; iy <= c.r1[1]; iy++)
+                        for (int ix = c.r0[0]; ix <= c.r1[0]; ix++, p++)
+                            if (sb[p] != 0.0 && rb[p] != 0.0)
+                                nbox.push_back((ix - a0[0]) + L.nx * ((iy - a0[1]) + L.ny * (iz - a0[2])));
+                if (nbox.size() > before) { nrk.push_back(c.q); nptr.push_back((int)nbox.size()); }
+            }
+            L.halo = halo_build(comm, L.nb, (int)nrk.size(), nrk.data(), nptr.data(), nbox.data(), s, "pc mg (shared boxes)");
+            // occupancy of the next level: a box is occupied where one of its children is
+            if (l + 2 < nlev) {
+                MgLevel& C = mg.lev[(size_t)l + 1];
+                std::vector<unsigned char> oc((size_t)C.nb, 0);
+                for (int b = 0; b < L.nb; b++) {
+                    if (!occ[(size_t)b]) continue;
+                    const int px = (b % L.nx + L.sh[0]) >> 1, py = ((b / L.nx) % L.ny + L.sh[1]) >> 1, pz = (b / (L.nx * L.ny) + L.sh[2]) >> 1;
+                    oc[(size_t)px + (size_t)C.nx * ((size_t)py + (size_t)C.ny * (size_t)pz)] = 1;
+                }
+                occ.swap(oc);
+            }
+        }
+    }
+    // block-Jacobi smoother: inverse of the diagonal blocks -- of the whole operator, i.e. summed over the sharers of a box
+    for (int l = 0; l < nlev; l++) {
+        MgLevel& L = mg.lev[(size_t)l];
+        const double* diag = L.st.p + (size_t)13 * CC * L.nb;
+        if (L.halo) {
+            L.diag.alloc((size_t)CC * L.nb);
+            FEM_HIP(hipMemcpyAsync(L.diag.p, diag, sizeof(double) * CC * L.nb, hipMemcpyDeviceToDevice, s));
+            for (int e0 = 0; e0 < CC; e0 += 6)
+                halo_sum_h(L.halo.get(), L.diag.p + (size_t)e0 * L.nb, std::min(6, CC - e0), 1, (size_t)L.nb, s, true);
+            diag = L.diag.p;
+        }
+        hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(L.nb)), dim3(256), 0, s, L.nb, diag, L.dinv.p);
     }
     // damping of the block-Jacobi smoother on every smoothed level: power iteration on Dinv A
     mg.omega_l.alloc(mg.lev.size() + 2);
@@ -976,17 +1113,20 @@ static bool setup_t(Multigrid& mg)
         MgLevel& L = mg.lev[l];
         const Grid3 gl = grid_of(L);
         const size_t n = (size_t)L.nb * CS;
+        const unsigned char* own = L.halo ? L.halo->owned.p : nullptr;
         double* n2 = mg.omega_l.p + mg.lev.size();
         L.r.zero(s);
-        hipLaunchKernelGGL(k_hash_fill, dim3(gs(n)), dim3(256), 0, s, n, L.x.p);
+        hipLaunchKernelGGL(k_hash_fill_box<CS>, dim3(g1(L.nb)), dim3(256), 0, s, gl, Shift3{L.off[0], L.off[1], L.off[2]}, G[l], L.x.p);
         const int npow = 12;
         for (int it = 0; it < npow; it++) {
-            if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2);
-            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, gl, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p);
+            if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2, own, CS);
+            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, gl, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+            halo_sum_h(L.halo.get(), L.t.p, CS, CS, 1, s, true);
             hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, (const double*)nullptr,
                                L.dinv.p, L.t.p, L.x.p);
         }
-        hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2 + 1);
+        hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2 + 1, own, CS);
+        if (comm) comm->allreduce_sum(n2, 2, s);
         hipLaunchKernelGGL(k_set_omega, dim3(1), dim3(1), 0, s, n2, mg.omega_l.p + l);
     }
     // fine level of the V-cycle form: point Jacobi must stay below 2 / lambda_max(D^-1 K) or the cycle
@@ -999,12 +1139,12 @@ static bool setup_t(Multigrid& mg)
         hipLaunchKernelGGL(k_hash_fill, dim3(gs(ndof)), dim3(256), 0, s, ndof, xv.p);
         const int npow = 10;
         for (int it = 0; it < npow; it++) {
-            if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, ndof, xv.p, n2.p);
+            if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, ndof, xv.p, n2.p, (const unsigned char*)nullptr, 1);
             mat_mult_raw(A, xv.p, mg.t0.p, nullptr, nullptr);
             halo_sum(mesh, mg.t0.p, BS, BS, 1);
             hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, 1.0, mg.dinv0.p, mg.t0.p, xv.p);
         }
-        hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, ndof, xv.p, n2.p + 1);
+        hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, ndof, xv.p, n2.p + 1, (const unsigned char*)nullptr, 1);
         if (comm) comm->allreduce_sum(n2.p, 2, s);
         double h2[2] = {0.0, 0.0};
         n2.download(h2, 2, s);
@@ -1014,9 +1154,10 @@ static bool setup_t(Multigrid& mg)
         mg.omega_fine = std::min(mg.omega, 1.6 / std::max(lam, 1.0));   // 20 % below the stability bound
     }
     // coarsest: dense inverse
-    mg.ncoarse = g.nb() * CS;
+    const Grid3 gcoarse = grid_of(mg.lev.back());
+    mg.ncoarse = gcoarse.nb() * CS;
     mg.cinv.alloc((size_t)mg.ncoarse * 2 * mg.ncoarse);
-    hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, g, mg.lev.back().st.p, mg.cinv.p);
+    hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
     {
         const int n = mg.ncoarse;
         DBuf<double> rowk((size_t)CS * 2 * n), colk((size_t)CS * n);
@@ -1035,10 +1176,14 @@ static bool setup_t(Multigrid& mg)
         FEM_HIP(hipStreamSynchronize(s));
         if (!mg.fine_additive)
             fprintf(stderr, "[fem_amd mg] fine level: lambda_max(D^-1 K) ~ %g, omega = %g\n", mg.lambda_fine, mg.omega_fine);
-        for (size_t l = 0; l < mg.lev.size(); l++)
-            fprintf(stderr, "[fem_amd mg] level %zu: %d x %d x %d boxes, %d dofs/box, H = %g%s\n", l + 1, mg.lev[l].nx,
-                    mg.lev[l].ny, mg.lev[l].nz, CS, mg.lev[l].H,
-                    (l + 1 < mg.lev.size()) ? (", omega = " + std::to_string(om[l])).c_str() : ", dense inverse");
+        for (size_t l = 0; l < mg.lev.size(); l++) {
+            const MgLevel& L = mg.lev[l];
+            const int shared = L.halo ? L.halo->ninodes : 0;
+            fprintf(stderr, "[fem_amd mg] level %zu: %d x %d x %d boxes of the global %d x %d x %d (origin %d %d %d, %d shared with %d domains), "
+                            "%d dofs/box, H = %g%s\n", l + 1, L.nx, L.ny, L.nz, G[l].nx, G[l].ny, G[l].nz, L.off[0], L.off[1], L.off[2], shared,
+                    L.halo ? L.halo->nneigh : 0, CS, L.H,
+                    (l + 1 < mg.lev.size()) ? (", omega = " + std::to_string(om[l])).c_str() : ", dense inverse (replicated)");
+        }
     }
     return true;
 }
@@ -1054,45 +1199,37 @@ static void cycle_t(Multigrid& mg, size_t l)
         hipLaunchKernelGGL(k_dense_apply, dim3(g1(n * 64)), dim3(256), 0, s, (int)n, mg.cinv.p, L.r.p, L.x.p);
         return;
     }
-    // Partitioned mesh: the hierarchy is replicated, but the two residuals of level 1 -- its only expensive
-    // kernels -- are split among the domains (contiguous box ranges).  The pointwise kernels (smoothing
-    // from r, prolongation) stay replicated, so every domain has x on the neighbours of its slice without
-    // any exchange; the restricted residual of level 2 is all-reduced (1/8 of a level-1 vector), and one
-    // all-reduce of x (zero outside the slices) re-unites the last smoothing step.
+    // Partitioned mesh (L.halo): r and x are held for this domain's boxes, the same on every domain that shares a box; st is the
+    // domain's part of the operator.  t = [own] r - A_r x is a partial residual whose sum over the sharers is r - A x: before
+    // the restriction it need not be summed (the restriction is linear: the coarse right-hand side is summed instead, one
+    // exchange on a level with an eighth of the boxes), before the second smoothing step it is (one neighbour exchange).
     Halo* halo = mg.A->mesh->halo.get();
     Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
-    const bool sliced = comm && l == 0 && L.nb >= mg.slice_min;   // small levels: two more all-reduces cost more than they save
-    int b0 = 0, b1 = L.nb;
-    if (sliced) {
-        b0 = (int)((long long)L.nb * comm->rank / comm->size);
-        b1 = (int)((long long)L.nb * (comm->rank + 1) / comm->size);
-    }
-    const int nbs = b1 - b0;
+    const unsigned char* own = L.halo ? L.halo->owned.p : nullptr;
     auto residual = [&] {   // small levels: 32 lanes per box (latency), large ones: one thread per box (bandwidth)
-        if (nbs <= 16384)
-            hipLaunchKernelGGL(k_box_residual_slots<CS>, dim3(g1((size_t)std::max(nbs, 1) * 32)), dim3(256), 0, s, g, b0, b1,
-                               L.st.p, L.x.p, L.r.p, L.t.p);
+        if (L.nb <= 16384)
+            hipLaunchKernelGGL(k_box_residual_slots<CS>, dim3(g1((size_t)std::max(L.nb, 1) * 32)), dim3(256), 0, s, g, 0, L.nb,
+                               L.st.p, L.x.p, L.r.p, L.t.p, own);
         else
-            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(nbs)), dim3(256), 0, s, g, b0, b1, L.st.p, L.x.p, L.r.p, L.t.p);
+            hipLaunchKernelGGL(k_box_residual<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
     };
     MgLevel& C = mg.lev[l + 1];
     const Grid3 gc = grid_of(C);
     hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, mg.omega_l.p + l, L.dinv.p,
                        L.r.p, L.x.p);
-    if (sliced) L.t.zero(s);                 // the restriction below sums over all children: foreign ones count 0
     residual();
-    hipLaunchKernelGGL(k_restrict_box<CS>, dim3(g1(C.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), L.t.p, C.r.p);
-    if (sliced) comm->allreduce_sum(C.r.p, C.nb * CS, s);
+    hipLaunchKernelGGL(k_restrict_box<CS>, dim3(g1(C.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), shift_of(L), L.t.p, C.r.p);
+    if (comm) {
+        if (l + 2 == mg.lev.size()) comm->allreduce_sum(C.r.p, C.nb * CS, s);   // the replicated coarsest level: <= 750 numbers
+        else halo_sum_h(C.halo.get(), C.r.p, CS, CS, 1, s, true);
+    }
     cycle_t<CS>(mg, l + 1);
-    hipLaunchKernelGGL(k_prolong_box<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), mg.alpha, C.x.p,
+    hipLaunchKernelGGL(k_prolong_box<CS>, dim3(g1(L.nb)), dim3(256), 0, s, g, geom_of(L), gc, geom_of(C), shift_of(L), mg.alpha, C.x.p,
                        L.x.p);
     residual();
-    hipLaunchKernelGGL((k_block_smooth<CS, true>), dim3(g1(std::max(nbs, 1))), dim3(256), 0, s, L.nb, b0, b1, mg.omega_l.p + l,
+    if (comm) halo_sum_h(L.halo.get(), L.t.p, CS, CS, 1, s, true);
+    hipLaunchKernelGGL((k_block_smooth<CS, true>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, mg.omega_l.p + l,
                        L.dinv.p, L.t.p, L.x.p);
-    if (sliced) {
-        hipLaunchKernelGGL(k_zero_outside, dim3(gs(n)), dim3(256), 0, s, n, (size_t)b0 * CS, (size_t)b1 * CS, L.x.p);
-        comm->allreduce_sum(L.x.p, (int)n, s);
-    }
 }
 
 template <int BS, int PD>
@@ -1110,13 +1247,16 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     Halo* halo = A->mesh->halo.get();
     Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
     // partitioned mesh: r and z are consistent on every copy of a shared node; the restriction counts
-    // each node once (owner weights), one all-reduce makes the level-1 residual global, the coarse
-    // cycle then runs replicated and the prolongation is local again
+    // each node once (owner weights), the sum over the sharers of a box (one neighbour exchange) makes the
+    // level-1 residual whole on every domain that holds the box, and the prolongation is local again
     const unsigned char* wr = comm ? mg.wr.p : mg.w.p;
     auto restrict_to_level1 = [&](const double* kz) {
         hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
                            mg.box_ptr.p, mg.box_nodes.p, wr, r, kz, L1.r.p);
-        if (comm) comm->allreduce_sum(L1.r.p, L1.nb * CS, s);
+        if (comm) {
+            if (mg.lev.size() == 1) comm->allreduce_sum(L1.r.p, L1.nb * CS, s);   // (level 1 is the replicated coarsest one)
+            else halo_sum_h(L1.halo.get(), L1.r.p, CS, CS, 1, s, true);
+        }
     };
     if (mg.fine_additive) {
         // fine level additive (Jacobi + coarse-grid correction of the un-smoothed residual): the
@@ -1171,7 +1311,7 @@ bool Multigrid::fuses_dots() const { return fine_additive; }
 size_t Multigrid::device_bytes() const
 {
     size_t b = omega_l.bytes() + wr.bytes() + agg.bytes() + box_ptr.bytes() + box_nodes.bytes() + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
-    for (auto& L : lev) b += L.st.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes();
+    for (auto& L : lev) b += L.st.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes() + L.diag.bytes();
     return b;
 }
 

@@ -290,6 +290,21 @@ module fem_amd_capi
       type(c_ptr), intent(out) :: comms(*)
       integer(c_int) :: ierr
     end function
+    function fem_comm_create_callbacks(ctx, nranks, rank, allreduce, exchange, user, comm) &
+        bind(C, name="fem_comm_create_callbacks") result(ierr)
+      import :: c_int, c_ptr, c_funptr
+      type(c_ptr), value :: ctx, user
+      integer(c_int), value :: nranks, rank
+      type(c_funptr), value :: allreduce, exchange
+      type(c_ptr), intent(out) :: comm
+      integer(c_int) :: ierr
+    end function
+    function fem_comm_get_stats(comm, stats) bind(C, name="fem_comm_get_stats") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: comm
+      integer(c_long_long), intent(out) :: stats(6)
+      integer(c_int) :: ierr
+    end function
     function fem_comm_destroy(comm) bind(C, name="fem_comm_destroy") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: comm

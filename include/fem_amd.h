@@ -33,7 +33,7 @@ extern "C" {
 #endif
 
 typedef struct fem_ctx_s *fem_ctx;   /* device + stream                          */
-typedef struct fem_comm_s *fem_comm; /* domain communicator (self / local / RCCL) */
+typedef struct fem_comm_s *fem_comm; /* domain communicator (self / local / RCCL / host callbacks) */
 typedef struct fem_mesh_s *fem_mesh; /* device-resident SoA mesh of one domain   */
 typedef struct fem_mat_s *fem_mat;   /* Mat_K       (src/m_global.F90:26)        */
 typedef struct fem_vec_s *fem_vec;   /* Vec_F/Vec_U (src/m_global.F90:24)        */
@@ -335,6 +335,22 @@ int fem_comm_create_rccl(fem_ctx ctx, int nranks, int rank, const char unique_id
 /* In-process group of `n` domains driven by `n` host threads (one fem_ctx
  * each, any mix of GPUs): used to exercise the halo path on a single GPU. */
 int fem_comm_create_local_group(int n, const fem_ctx *ctxs, fem_comm *comms);
+/* Host-staged communicator: the library hands its two operations to the host program's own message passing (the reference
+ * is an MPI program: Makefile:6-10, MPI_AllReduce src/main.F90:274, MPI_Send/Recv src/m_io.F90:150-237) through pinned host
+ * buffers.  `allreduce(user, buf, n)` sums buf[0..n) over all ranks in place (MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE,
+ * MPI_SUM)); `exchange(user, nneigh, neigh_rank, off, send, recv)` sends send[off[i]..off[i+1]) to rank neigh_rank[i] and fills
+ * the same range of recv from it, for every i (MPI_Sendrecv per neighbour; offsets in doubles).  Both run on the calling thread;
+ * every rank calls the library in the same order, as with PETSc.  Slower than RCCL (two PCIe hops per operation): meant for
+ * hosts without RCCL peers and for rehearsing the multi-rank paths with several processes on one GPU (bench.py --rehearse). */
+typedef void (*fem_comm_allreduce_fn)(void *user, double *buf, int n);
+typedef void (*fem_comm_exchange_fn)(void *user, int nneigh, const int *neigh_rank, const long long *off, const double *send,
+                                     double *recv);
+int fem_comm_create_callbacks(fem_ctx ctx, int nranks, int rank, fem_comm_allreduce_fn allreduce, fem_comm_exchange_fn exchange,
+                              void *user, fem_comm *comm);
+/* What went through the communicator since its creation: stats[0..2] = all-reduce calls, largest count, total count (doubles);
+ * stats[3..5] = neighbour exchanges, largest and total number of doubles this domain sent.  The partitioned paths are tested on
+ * it: no collective may grow with the mesh (the reference's whole-mesh MPI_AllReduce, src/main.F90:274, is what they replace). */
+int fem_comm_get_stats(fem_comm comm, long long stats[6]);
 int fem_comm_destroy(fem_comm comm);
 int fem_comm_rank(fem_comm comm, int *rank, int *size);
 /* The neighbour exchange the halo sums are built on (replaces the MPI_Send/MPI_Recv pairs of

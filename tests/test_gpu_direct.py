@@ -181,15 +181,15 @@ def test_mat_set_values_semantics(gpu_ctx):
     prob = driver.Problem(gpu_ctx, m, "")
     prob.assemble()
     rp, ci, v0 = prob.K.get_csr()
-    prob.K.set_values([0, -1, 1], [1, 0, -3], 1e9 * np.arange(9.0).reshape(3, 3), "add")
+    prob.K.set_values([2, -1, 3], [3, 2, -3], 1e9 * np.arange(9.0).reshape(3, 3), "add")     # (node 1: not on the clamped edge)
     _, _, v1 = prob.K.get_csr()
     d = {(r, int(c)): v1[k] - v0[k] for r in range(len(rp) - 1) for k, c in zip(range(rp[r], rp[r + 1]), ci[rp[r]:rp[r + 1]])}
-    want = {(0, 1): 0.0, (0, 0): 1e9, (1, 1): 6e9, (1, 0): 7e9}
-    assert all(abs(d[k] - want.get(k, 0.0)) <= 1e-3 for k in d)
+    want = {(2, 3): 0.0, (2, 2): 1e9, (3, 3): 6e9, (3, 2): 7e9}
+    assert all(abs(d[k] - want.get(k, 0.0)) <= 1e-3 for k in d), {k: v for k, v in d.items() if v != 0.0}
     prob.K.set_values([2], [2], [5.5], "insert")
     _, _, v2 = prob.K.get_csr()
     k22 = rp[2] + list(ci[rp[2]:rp[3]]).index(2)
     assert v2[k22] == 5.5
     with pytest.raises(capi.FemError):
-        prob.K.set_values([0], [m.ndof - 1], [1.0], "add")            # node 0 and the last node share no element
+        prob.K.set_values([2], [m.ndof - 1], [1.0], "add")            # node 1 and the last node share no element
     prob.destroy()

@@ -344,15 +344,16 @@ def test_ebe_full_size_config3(gpu_ctx):
     assert np.abs(out["ebe"][0] - out["assembled"][0]).max() <= 1e-7 * np.abs(out["assembled"][0]).max()
 
 
-@pytest.mark.parametrize("opts", ["-pc_type jacobi", "-pc_type mg -pc_mg_type additive", "-pc_type mg -pc_mg_type additive -pc_mg_slice_min 1"])
+@pytest.mark.parametrize("opts", ["-pc_type jacobi", "-pc_type mg -pc_mg_type additive", "-pc_type mg -pc_mg_type multiplicative"])
 def test_ebe_eight_domains_medium_size(opts):
     """The layout of config 4 (2x2x2 bricks) at 32^3 elements per brick, element-by-element product, against
     the undivided mesh on one context: same iteration count (+-2) and the same field; interface copies
     bitwise identical."""
-    from tests.test_gpu_multidomain import _run_domains
+    from tests.test_gpu_multidomain import _run_domains, assert_no_collective_grows_with_the_mesh
     world, npr = 8, (32, 32, 32)
     full = f"-mat_mult_type ebe {opts} -ksp_rtol 1e-11"
     grid, out = _run_domains(world, npr, 0.1, full)
+    assert_no_collective_grows_with_the_mesh()
     g = structured_hex(*(grid[d] * npr[d] for d in range(3)), jitter=0.1)
     ctx = capi.Context(0)
     single = driver.run(g, full, ctx=ctx, recover_stress=False)

@@ -184,3 +184,72 @@ def test_config3_against_the_oracle_at_full_size(gpu_ctx, oracle, jitter):
         assert res.reasons[-1] == 2
         assert abs(res.its[-1] - ob["its"]) <= 2
         assert eu <= 1e-10 and es <= 1e-10
+
+
+def test_config4_in_its_own_partition_against_the_undivided_solve():
+    """BASELINE config 4 in its own shape on the one GPU of the box: 2 x 2 x 2 bricks of 149^3 hex8 each (the per-GPU brick of
+    `bench.py --gpus 8`: 150^2-node faces, 540 kB per face and exchange, the tile plan with the interface tiles first) as eight
+    in-process domains (fem_comm_create_local_group; everything but the RCCL transport is the code the 8-GPU run executes),
+    `-mat_mult_type ebe`, with CG/Jacobi, with the exchange beside the interior tiles (`-ksp_halo_overlap 1`) and with
+    `-pc_type mg`, against the undivided 298^3 solve (80.2 M DOF) on the same GPU: the same iteration counts (+-2), the same
+    field (rtol 1e-9: 1e-8 of the largest displacement), interface copies bitwise equal, the overlapped schedule bitwise equal
+    to the plain one, and no collective that grows with the mesh.  (src/main.F90:49-96,274,286-289.)"""
+    import time
+    from tests import test_gpu_multidomain as md
+    n, world = 149, 8
+    npr = (n, n, n)
+    runs = {}
+    log = []
+    for name, opts in (("cg_jacobi", "-mat_mult_type ebe"), ("cg_jacobi_overlap", "-mat_mult_type ebe -ksp_halo_overlap 1"),
+                       ("pc_mg", "-mat_mult_type ebe -pc_type mg -pc_mg_type additive")):
+        t0 = time.perf_counter()
+        grid, out = md._run_domains(world, npr, 0.0, opts, extras=False)
+        dt = time.perf_counter() - t0
+        st = list(md.LAST_STATS)
+        md.assert_no_collective_grows_with_the_mesh()
+        runs[name] = out
+        log.append(f"config 4 as 8 in-process domains of {n}^3 [{opts}]: iterations {sorted({o[2] for o in out})}, reasons "
+                   f"{sorted({o[3] for o in out})}, wall {dt:.1f} s (8 domains time-sharing one GPU, mesh generation and fem_mesh_create "
+                   f"included); largest all-reduce {max(s_['allreduce_max_doubles'] for s_ in st)} doubles, largest exchange "
+                   f"{max(s_['exchange_max_doubles'] for s_ in st)} doubles of {max(s_['interface_slots'] for s_ in st)} interface "
+                   f"node slots; exchanges per domain {st[0]['exchange_calls']}, all-reduces {st[0]['allreduce_calls']}")
+        print(log[-1], flush=True)
+        assert all(o[3] == 2 for o in out)
+        assert len({o[2] for o in out}) == 1                    # every domain stops at the same iteration
+        # interface copies bitwise equal (canonical-order halo sums)
+        for r in range(world):
+            for q in range(r + 1, world):
+                common, ir, iq = np.intersect1d(out[r][5], out[q][5], return_indices=True)
+                assert common.size                              # 2 x 2 x 2: every pair of bricks shares a face, an edge or the corner
+                assert np.array_equal(out[r][0].reshape(-1, 3)[ir], out[q][0].reshape(-1, 3)[iq])
+                assert np.array_equal(out[r][1][ir], out[q][1][iq])
+    # the exchange beside the interior tiles changes the schedule, not one bit of the result
+    for a, b in zip(runs["cg_jacobi"], runs["cg_jacobi_overlap"]):
+        assert a[2] == b[2] and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # face sizes: 150^2 nodes per face and neighbour
+    st0 = md.LAST_STATS[0]
+    assert st0["interface_slots"] == 3 * 150 * 150 + 3 * 150 + 1
+    # the undivided problem on the same GPU
+    g = structured_hex(2 * n)
+    ctx = capi.Context(0)
+    for name, opts, its_lo, its_hi in (("cg_jacobi", "-mat_mult_type ebe", 1405, 1420), ("pc_mg", "-mat_mult_type ebe -pc_type mg -pc_mg_type additive", 70, 85)):
+        t0 = time.perf_counter()
+        one = driver.run(g, opts, ctx=ctx)
+        dt = time.perf_counter() - t0
+        ug = one.aggregate_u.reshape(-1, 3)
+        sg = one.aggregate_stress
+        its = runs[name][0][2]
+        eu = max(np.abs(o[0].reshape(-1, 3) - ug[o[5]]).max() for o in runs[name]) / np.abs(ug).max()
+        es = max(np.abs(o[1] - sg[o[5]]).max() for o in runs[name]) / np.abs(sg).max()
+        log.append(f"undivided 298^3 [{opts}]: {one.its[-1]} iterations (8 domains: {its}), wall {dt:.1f} s; 8 domains vs undivided: "
+                   f"max rel diff u {eu:.2e}, nodal stress {es:.2e}")
+        print(log[-1], flush=True)
+        assert one.reasons[-1] == 2 and its_lo <= one.its[-1] <= its_hi
+        assert abs(its - one.its[-1]) <= 2
+        assert eu <= 1e-8 and es <= 1e-6          # two solves stopped at rtol 1e-9 (nodal stresses: differences of neighbouring displacements)
+    ctx.destroy()
+    import os
+    d = os.environ.get("FEM_AMD_TEST_LOG_DIR")
+    if d:
+        with open(os.path.join(d, "config4_partitioned_full_size.txt"), "w") as f:
+            f.write("\n".join(log) + "\n")

@@ -15,11 +15,15 @@ from fem_amd.mesh import structured_hex
 pytestmark = pytest.mark.gpu
 
 
-def _run_domains(world, npr, jitter, options):
+LAST_STATS = []      # per domain of the last _run_domains call: fem_comm_get_stats + the number of interface node slots
+
+
+def _run_domains(world, npr, jitter, options, extras=True):
     grid = partition.brick_grid(world)
     ctxs = [capi.Context(0) for _ in range(world)]
     comms = capi.Comm.local_group(ctxs)
     out = [None] * world
+    stats = [None] * world
     err = []
 
     def work(r):
@@ -32,14 +36,19 @@ def _run_domains(world, npr, jitter, options):
             prob.ksp.solve(prob.F, prob.U)
             u = prob.U.get_array()
             s = prob.dmesh.recover_nodal_stress(prob.U)
-            # MatMult through the public API (sub-assembled product + halo sum)
-            X, Y = capi.Vec(ctxs[r], m.ndof), capi.Vec(ctxs[r], m.ndof)
             gid = partition.global_node_ids(r, grid, npr)
-            xg = np.sin(0.37 * np.arange(3 * (gid.max() + 1) + 3))
-            X.set_array(np.stack([xg[3 * gid], xg[3 * gid + 1], xg[3 * gid + 2]], axis=1).ravel())
-            prob.K.mult(X, Y)
-            out[r] = (u, s, prob.ksp.get_iteration_number(), prob.ksp.get_converged_reason(), Y.get_array(), gid)
-            X.destroy(); Y.destroy(); prob.destroy()
+            y = None
+            if extras:
+                # MatMult through the public API (sub-assembled product + halo sum)
+                X, Y = capi.Vec(ctxs[r], m.ndof), capi.Vec(ctxs[r], m.ndof)
+                xg = np.sin(0.37 * np.arange(3 * (gid.max() + 1) + 3))
+                X.set_array(np.stack([xg[3 * gid], xg[3 * gid + 1], xg[3 * gid + 2]], axis=1).ravel())
+                prob.K.mult(X, Y)
+                y = Y.get_array()
+                X.destroy(); Y.destroy()
+            out[r] = (u, s, prob.ksp.get_iteration_number(), prob.ksp.get_converged_reason(), y, gid)
+            stats[r] = dict(comms[r].stats(), interface_slots=int(len(partition.brick_halo(r, grid, npr)[2])))
+            prob.destroy()
         except Exception as e:  # noqa: BLE001
             err.append((r, repr(e)))
 
@@ -47,14 +56,26 @@ def _run_domains(world, npr, jitter, options):
     for t in th:
         t.start()
     for t in th:
-        t.join(timeout=300)
+        t.join(timeout=1200)
     assert not err, err
     assert all(o is not None for o in out), "a domain thread hung"
     for c in comms:
         c.destroy()
     for c in ctxs:
         c.destroy()
+    LAST_STATS[:] = stats
     return grid, out
+
+
+def assert_no_collective_grows_with_the_mesh(max_components=6):
+    """On the communicators of the last _run_domains call: no all-reduce beyond the replicated coarsest multigrid level
+    (27 slots x 36 entries x 125 boxes at set-up, 750 numbers per application) and no neighbour exchange beyond the domain's
+    interface (its shared node slots x 6 components, the nodal-stress halo sum) -- SURVEY 2a: the reference's whole-mesh
+    MPI_AllReduce (src/main.F90:274) is what the partitioned paths replace."""
+    assert LAST_STATS and all(st is not None for st in LAST_STATS)
+    for st in LAST_STATS:
+        assert st["allreduce_max_doubles"] <= 27 * 36 * 125, st
+        assert st["exchange_max_doubles"] <= max_components * st["interface_slots"], st
 
 
 @pytest.mark.parametrize("world,npr", [(2, (5, 4, 3)), (4, (3, 3, 4)), (6, (2, 3, 3)), (8, (3, 2, 3))])   # 8 = 2x2x2: the layout of config 4

@@ -66,18 +66,18 @@ def test_mg_full_size_config3(gpu_ctx):
 
 
 @pytest.mark.parametrize("mgtype", ["additive", "multiplicative"])
-@pytest.mark.parametrize("world,npr", [(2, (9, 8, 7)), (4, (6, 6, 9))])
+@pytest.mark.parametrize("world,npr", [(2, (9, 8, 7)), (4, (6, 6, 9)), (8, (9, 10, 11)), (6, (14, 9, 12)), (3, (23, 8, 8))])
 def test_mg_on_a_partitioned_mesh(oracle, world, npr, mgtype):
     """Partitioned mesh (brick domains, in-process communicator on one GPU): the preconditioner is the
-    same operator as on the undivided mesh -- global box grid, all-reduced level-1 operator, replicated
-    coarse hierarchy -- so the solution matches the serial oracle, the iteration count matches the
-    single-domain multigrid run, and interface copies stay bitwise identical."""
-    from tests.test_gpu_multidomain import _run_domains
+    same operator as on the undivided mesh -- one box grid over the global bounding box, every domain holding its sub-grid and
+    its part of the Galerkin operators, shared boxes summed by neighbour exchanges, only the coarsest level replicated -- so
+    the solution matches the serial oracle, the iteration count matches the single-domain multigrid run, interface copies
+    stay bitwise identical, and no collective grows with the mesh."""
+    from tests.test_gpu_multidomain import _run_domains, assert_no_collective_grows_with_the_mesh
     from fem_amd import partition
-    # -pc_mg_slice_min 1: split the level-1 residuals among the domains although the level is tiny
-    # (the production threshold is 32768 boxes), so that the two extra all-reduces are exercised
-    opts = f"-pc_type mg -pc_mg_type {mgtype} -ksp_rtol 1e-12 -pc_mg_slice_min {1 if world == 4 else 32768}"
+    opts = f"-pc_type mg -pc_mg_type {mgtype} -ksp_rtol 1e-12"
     grid, out = _run_domains(world, npr, 0.15, opts)
+    assert_no_collective_grows_with_the_mesh()
     gn = tuple(grid[d] * npr[d] for d in range(3))
     g = structured_hex(*gn, jitter=0.15)
     ug, sg, _ = oracle.run(g, "cg", rtol=1e-13)

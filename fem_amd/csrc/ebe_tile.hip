@@ -180,14 +180,15 @@ __device__ __forceinline__ void tile_finish(double dot, int t, double* sh, doubl
         if (threadIdx.x == 0) partial[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
         return;
     }
-    // No fences (a release would write back this XCD's whole L2 -- the kernel's own y -- once per workgroup: measured 3x the
-    // kernel time): the partial is stored write-through (agent-scope store = sc1), the lane waits for it, then counts; the
-    // workgroup whose count came last reads every partial with agent-scope loads (sc1: past this CU's L1), nothing else.
+    // Experimental (FEM_AMD_SELF_REDUCE=1, off by default).  Release / acquire at agent scope as the HIP memory model asks: the
+    // counter's acq_rel read-modify-write publishes this workgroup's partial and, in the workgroup whose count comes last, makes
+    // every other partial visible.  The release writes back this XCD's L2 -- the kernel's own y -- once per workgroup: measured at
+    // 3x the kernel time, which is why the separate reduction kernel (8 us) is the default.  (Round 3 had relaxed atomics with an
+    // s_waitcnt and sc1 accesses here: faster, but correct only by this part's cache behaviour, not by the model.)
     __shared__ int s_last;
     if (threadIdx.x == 0) {
         __hip_atomic_store(&partial[t], (sh[0] + sh[1]) + (sh[2] + sh[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        s_last = atomicAdd(rcount, 1u) == (unsigned)(rtotal - 1);
+        s_last = __hip_atomic_fetch_add(rcount, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(rtotal - 1);
     }
     __syncthreads();
     if (!s_last) return;

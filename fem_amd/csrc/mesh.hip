@@ -12,6 +12,9 @@
 
 #include "objects.h"
 
+#include <cstdlib>
+#include <string>
+
 using namespace fem;
 
 namespace {
@@ -22,14 +25,18 @@ void host_ranges(long long n, F f)
     const int hc = (int)std::thread::hardware_concurrency();
     const int nt = (int)std::max<long long>(1, std::min<long long>(std::min(16, hc > 0 ? hc : 1), n / 65536));
     std::vector<std::thread> th;
-    // (a worker inherits the CPU mask of the calling thread, which an OpenMP runtime with OMP_PROC_BIND may have pinned to one
-    // core -- bench.py's process is such a case: give it every CPU the process may use)
+    // A worker inherits the CPU mask of the calling thread: a pinning chosen by the user or the launcher (taskset, numactl, per-rank
+    // binding under mpirun / torchrun) is respected.  FEM_AMD_HOST_AFFINITY=widen gives the workers every CPU instead -- for a
+    // caller whose own thread an OpenMP runtime has pinned to one core (OMP_PROC_BIND; bench.py is such a case and sets it).
+    static const bool widen = std::getenv("FEM_AMD_HOST_AFFINITY") && std::string(std::getenv("FEM_AMD_HOST_AFFINITY")) == "widen";
     for (int i = 1; i < nt; i++)
         th.emplace_back([=] {
-            cpu_set_t all;
-            CPU_ZERO(&all);
-            for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &all);
-            (void)sched_setaffinity(0, sizeof(all), &all);
+            if (widen) {
+                cpu_set_t all;
+                CPU_ZERO(&all);
+                for (int c = 0; c < CPU_SETSIZE; c++) CPU_SET(c, &all);
+                (void)sched_setaffinity(0, sizeof(all), &all);
+            }
             f(n * i / nt, n * (i + 1) / nt);
         });
     f(0LL, n / nt);

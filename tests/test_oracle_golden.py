@@ -271,3 +271,32 @@ def test_newton_cohesive_current_deck_runs_and_inner_solvers_agree(oracle):
     # the second increment starts from a state that solves it: the direct solve confirms it (an empty Newton step), the
     # iterative one, whose first increment carries its own 1e-12 of error into 1e30-weighted rows, moves a little
     assert np.abs(a["u"] - b["u"]).max() <= 1e-5 * np.abs(a["u"]).max()
+
+
+def test_el_test_deck_is_a_uniform_stress_state(oracle):
+    """examples/el_test.inp (the reference's only traction deck, re-typed: tests/golden/decks/el_test.inp): the three tractions
+    and three nodal forces are in equilibrium with sigma_xx = sigma_yy = tau_xy = -1000 -- ApplyTraction's side numbering and
+    sign (src/m_global.F90:343-368, src/m_elems.F90:286-288) pinned by an exact solution; LU and CG agree."""
+    m = read_inp(os.path.join(HERE, "golden", "decks", "el_test.inp"))
+    u, s, _ = oracle.run(m, "lu")
+    assert np.abs(s + 1000.0).max() <= 1e-9 * 1000.0
+    u2, s2, _ = oracle.run(m, "cg", rtol=1e-14)
+    assert np.abs(u - u2).max() <= 1e-12 * np.abs(u).max()
+    # plane strain, E = 3e6, nu = 0.3: eps_xx = eps_yy = (1 + nu)(1 - 2 nu) sigma / E ... gamma_xy = tau / G
+    E, nu = 3.0e6, 0.3
+    exx = (1 + nu) * ((1 - nu) * -1000.0 - nu * -1000.0) / E
+    gxy = -1000.0 * 2 * (1 + nu) / E
+    U = u.reshape(-1, 2)
+    assert abs((U[1, 0] - U[0, 0]) / 2.0 - exx) <= 1e-12 * abs(exx)            # node 2 is 2.0 to the right of node 1
+    assert abs((U[3, 1] - U[0, 1]) / 1.0 - exx) <= 1e-12 * abs(exx)
+    assert abs((U[3, 0] - U[0, 0]) / 1.0 + (U[1, 1] - U[0, 1]) / 2.0 - gxy) <= 1e-12 * abs(gxy)
+
+
+def test_two_quads_qs_deck_reads_as_the_reference_wrote_it(oracle):
+    """examples/two_quads_qs.inp verbatim (current 8-integer header): 4 tri + 2 qua + 2 coh sharing nodes 5 / 8, one
+    separation law, three BC records of which one has free flags, two nodal forces; the oracle's Newton loop runs it."""
+    m = read_inp(os.path.join(HERE, "golden", "decks", "two_quads_qs.inp"))
+    assert (m.nels, m.nnds, len(m.cohmats), len(m.fnode), len(m.bcnode)) == (8, 12, 1, 2, 3)
+    assert list(m.bcnode[2]) == [1, 1, 1] and m.cohmats[0] == (1, [100.0, 0.01, 0.01, 1.0, 0.0, 0.0])
+    r = oracle.snes_run(m, rels_mode=0)
+    assert list(r["its"]) == [1, 1] and all(x > 0 for x in r["reasons"])

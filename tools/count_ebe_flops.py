@@ -82,10 +82,13 @@ lines = asm_of("fem_amd/csrc/ebe_tile.hip")
 i = 0
 while i < len(lines):
     m = re.match(r"^(_ZN3fem(?:10k_ebe_tile|12k_ebe_tile_x)ILi([012])E(?:Li(\d)E)?\w+):", lines[i])
-    if not m or (m.group(3) and m.group(3) != "0"):   # (the stress passes <0,1>, <0,2> are not products)
+    mq = re.match(r"^(_ZN3fem14k_ebe_tile_q4xILb([01])E\w+):", lines[i])     # quad4, x and coordinates in LDS (config 2)
+    if mq:
+        m = mq
+    if not m or (not mq and m.group(3) and m.group(3) != "0"):   # (the stress passes <0,1>, <0,2> are not products)
         i += 1
         continue
-    xk = "k_ebe_tile_x" in m.group(1)
+    xk = "k_ebe_tile_x" in m.group(1) or bool(mq)
     j = i
     while not lines[j].startswith(".Lfunc_end"):
         j += 1
@@ -117,6 +120,9 @@ while i < len(lines):
             else:
                 cur = 0
         weight[k] = cur
-    report("%s<%s> per element visit" % ("k_ebe_tile_x" if xk else "k_ebe_tile", {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)]),
-           count(body, weight))
+    if mq:
+        report("k_ebe_tile_q4x<%s> per element visit" % ("fused CG opening" if m.group(2) == "1" else "plain"), count(body, weight))
+    else:
+        report("%s<%s> per element visit" % ("k_ebe_tile_x" if xk else "k_ebe_tile", {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)]),
+               count(body, weight))
     i = j

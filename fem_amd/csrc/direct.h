@@ -51,6 +51,7 @@ struct BandLU {
     int kl = 0;                 // half bandwidth in dofs after renumbering (kl = ku)
     int wb = 0;                 // stored row width: 3 kl + 1
     bool failed = false;        // a NaN reached a pivot column
+    bool wave = false;          // factorised (and solved) by one wavefront with the window of a step in registers (3 kl + 1 <= 64)
     int null_pivots = 0;        // pivots below 1e-6 of the largest entry, fixed to zero
     DBuf<int> perm_dof;         // [n] new position of every dof
     DBuf<double> ab;            // [n*wb] row i holds columns i-kl .. i+2kl

@@ -2,6 +2,7 @@
 #include "direct.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <string>
@@ -603,6 +604,212 @@ __global__ void __launch_bounds__(256) k_band_lu_solve(long long n, int kl, int 
     }
 }
 
+// ---- the same factorisation and solve by ONE wavefront with the active window in registers (narrow bands) -------------------
+// k_band_lu spends 1.7-3.5 us per column -- a pivot search by one thread, three workgroup barriers and a chain of dependent global
+// accesses -- whatever the band: 28 ms for the 8,008 columns of BASELINE config 5 as one connected strip (half bandwidth 9),
+// all of a Newton step's time.  A window of an LU step is small there: rows k .. k + kl, columns k .. k + 3 kl.  Lane l of one
+// wavefront holds the column j = l (mod 64) of that window, one register per row (3 kl + 1 <= 64, kl <= KL): the pivot column is
+// one lane's registers (v_readlane with a uniform index: no LDS, no barrier), the row exchange a register exchange, the rank-1
+// update one fma per row and lane; the finished row streams out, the rows that enter the window were asked for sixteen steps
+// earlier.  Same arithmetic as k_band_lu (dgbtf2: partial pivoting inside the band, a pivot below 1e-6 of the largest non-penalty
+// entry fixed to zero), same storage (the two solve kernels read either's factors).
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+constexpr int WAVE_LU_DEPTH = 16;   // rows asked for ahead of their step
+// (KL = the half bandwidth the band was stored with: the host rounds the true one up to the next instantiated value, the extra
+// rows and columns are zeros -- a compile-time band keeps every register index static and needs no guard inside a step)
+template <int KL>
+__global__ void __launch_bounds__(64) k_band_lu_wave(long long n, double* __restrict__ ab, int* __restrict__ ipiv,
+                                                     const double* __restrict__ amax, int* __restrict__ flag)
+{
+    static_assert(3 * KL + 1 <= 64, "the window of a step must fit one wavefront");
+    constexpr int D = WAVE_LU_DEPTH, kl = KL, wb = 3 * KL + 1, ku2 = 2 * KL;
+    const int lane = threadIdx.x;
+    const double tiny = 1e-6 * (*amax);
+    // entry (row i, column j) of the band, 0 outside it (and outside the matrix); j = the lane's column in the window that starts at k0
+    auto entry = [&](long long i, long long k0) -> double {
+        const long long j = k0 + ((lane - (int)(k0 & 63)) & 63);
+        const long long o = j - i + kl;
+        return (i < n && j < n && o >= 0 && o < wb) ? ab[i * wb + o] : 0.0;
+    };
+    double W[KL + 1];
+#pragma unroll
+    for (int r = 0; r <= KL; r++) W[r] = entry(r, 0);
+    double nxt[D], fut[D];
+    // the row that enters the window behind step k is row k + 1 + kl, seen from the window that starts at k + 1
+#pragma unroll
+    for (int d = 0; d < D; d++) nxt[d] = entry((long long)d + 1 + kl, (long long)d + 1);
+    for (long long kb = 0; kb < n; kb += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) fut[d] = entry(kb + D + d + 1 + kl, kb + D + d + 1);
+        auto step = [&](long long k, double entering) {
+            const int c0 = (int)(k & 63);
+            const int km = (int)min((long long)kl, n - 1 - k), nc = (int)min((long long)ku2, n - 1 - k);
+            const int rel = (lane - c0) & 63;            // the lane's column is k + rel
+            // pivot: the largest of column k's entries in rows k .. k + kl (rows beyond the matrix are zeros).  Every lane looks at
+            // its own column, one lane is asked; the diagonal is the largest almost always: the search proper is the rare path
+            const double a0 = fabs(W[0]);
+            double mx = fabs(W[1]);
+#pragma unroll
+            for (int r = 2; r <= KL; r++) mx = fmax(mx, fabs(W[r]));
+            int p = 0;
+            double best = readlane_f64(a0, c0);
+            if (readlane_f64(mx, c0) > best) {
+                int pl = 0;
+                double bl = a0;
+#pragma unroll
+                for (int r = 1; r <= KL; r++) { const double a = fabs(W[r]); if (a > bl) { bl = a; pl = r; } }
+                p = __builtin_amdgcn_readlane(pl, c0);
+                best = readlane_f64(bl, c0);
+            }
+            double lcol = 0.0;                              // what this lane stores of column k: lane r the multiplier of row k + r
+            if (!(best > tiny)) {                           // null pivot (or a NaN): the unknown is fixed to zero, row and column dropped
+                if (lane == 0) { ipiv[k] = -1 - (int)k; atomicAdd(flag, 1); if (isnan(best)) atomicExch(flag + 1, 1); }
+                if (rel == 0) {
+#pragma unroll
+                    for (int r = 1; r <= KL; r++) W[r] = 0.0;
+                    W[0] = 1.0;
+                } else W[0] = 0.0;
+            } else {
+                if (lane == 0) ipiv[k] = (int)(k + p);
+                if (p != 0) {                               // (uniform)
+#pragma unroll
+                    for (int r = 1; r <= KL; r++)
+                        if (p == r) { const double t = W[0]; W[0] = W[r]; W[r] = t; }
+                }
+                const double rp = 1.0 / readlane_f64(W[0], c0);
+#pragma unroll
+                for (int r = 1; r <= KL; r++) {
+                    const double l = readlane_f64(W[r], c0) * rp;
+                    W[r] = fma(-l, W[0], W[r]);             // (the pivot column's own lane ends next to zero: cleared with the shift below)
+                    if (lane == r) lcol = l;
+                }
+            }
+            // row k is final: columns k .. k + nc; the multipliers of column k go to their rows
+            if (rel <= nc) ab[k * wb + kl + rel] = W[0];
+            if (lane >= 1 && lane <= km) ab[(k + lane) * wb + (kl - lane)] = lcol;
+            // the window moves on: rows shift, the retired column's lane becomes column k + 64 (nothing there yet), row k + 1 + kl enters
+#pragma unroll
+            for (int r = 0; r < KL; r++) W[r] = (rel == 0) ? 0.0 : W[r + 1];
+            W[KL] = entering;
+        };
+#pragma unroll
+        for (int d = 0; d < D; d++)
+            if (kb + d < n) step(kb + d, nxt[d]);
+#pragma unroll
+        for (int d = 0; d < D; d++) nxt[d] = fut[d];
+    }
+}
+
+// dgbtrs by one wavefront: lane l holds x of the row i = l (mod 64) of the window k .. k + 63; the factor entries a step needs
+// (the multipliers of column k in the forward sweep, column k of U in the backward one) are asked for sixteen steps ahead; a lane
+// whose row is done keeps the result and takes its next row from a register -- results are stored and the rows after next loaded
+// 64 at a time, every 64 steps
+__global__ void __launch_bounds__(64) k_band_solve_wave(long long n, int kl, int wb, const double* __restrict__ ab,
+                                                        const int* __restrict__ ipiv, double* __restrict__ x)
+{
+    constexpr int D = WAVE_LU_DEPTH;
+    const int lane = threadIdx.x;
+    const int ku2 = 2 * kl;
+    // ---- forward: row exchanges and L
+    {
+        // multiplier L(i, k) for the lane's row i in the window that starts at k (0 where i is not in k+1 .. k+kl)
+        auto mult = [&](long long k) -> double {
+            const int rel = (lane - (int)(k & 63)) & 63;
+            const long long i = k + rel;
+            return (rel >= 1 && rel <= kl && i < n) ? ab[i * wb + (kl - rel)] : 0.0;
+        };
+        double xv = (lane < n) ? x[lane] : 0.0, xn = (64 + lane < n) ? x[64 + lane] : 0.0, xd = 0.0;
+        int pv = (lane < n) ? ipiv[lane] : 0, pn = (64 + lane < n) ? ipiv[64 + lane] : 0;
+        double nxt[D], fut[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) nxt[d] = mult(d);
+        for (long long kb = 0; kb < n; kb += D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) fut[d] = mult(kb + D + d);
+            auto step = [&](long long k, double mk) {
+                const int c0 = (int)(k & 63);
+                const int pk = __builtin_amdgcn_readlane(pv, c0);
+                double xk = 0.0;                            // (a fixed unknown stays 0)
+                if (pk >= 0) {
+                    const int cp = pk & 63;                 // row exchange k <-> pk (pk <= k + kl: inside the window)
+                    const double va = readlane_f64(xv, c0);
+                    xk = readlane_f64(xv, cp);
+                    if (lane == cp) xv = va;
+                    xv = fma(-mk, xk, xv);                  // rows k + 1 .. k + kl
+                }
+                if (lane == c0) { xd = xk; xv = xn; pv = pn; }   // x[k] is final for this sweep; the lane takes row k + 64
+                if (c0 == 63) {                             // (uniform) 64 rows done: out they go, the rows after next come in
+                    const long long b0 = k - 63;
+                    x[b0 + lane] = xd;
+                    xn = (b0 + 128 + lane < n) ? x[b0 + 128 + lane] : 0.0;
+                    pn = (b0 + 128 + lane < n) ? ipiv[b0 + 128 + lane] : 0;
+                }
+            };
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if (kb + d < n) step(kb + d, nxt[d]);
+#pragma unroll
+            for (int d = 0; d < D; d++) nxt[d] = fut[d];
+        }
+        // the last, partial block of 64
+        const long long b0 = n & ~63LL;
+        if (b0 < n && b0 + lane < n) x[b0 + lane] = xd;
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // (one wavefront: its own stores are visible to its later loads once they have completed)
+    // ---- backward: U.  The window runs down: lane l holds the row i = l (mod 64) of k - 63 .. k
+    {
+        auto uent = [&](long long k) -> double {   // U(i, k) for the lane's row i in k - 2 kl .. k - 1; the diagonal for i = k
+            if (k < 0) return 0.0;
+            const int rel = ((int)(k & 63) - lane) & 63;   // i = k - rel
+            const long long i = k - rel;
+            return (rel <= ku2 && i >= 0) ? ab[i * wb + kl + rel] : 0.0;
+        };
+        const long long top = n - 1;
+        const long long irow = top - (((int)(top & 63) - lane) & 63);   // the lane's row in the first window
+        double xv = (irow >= 0) ? x[irow] : 0.0, xn = (irow - 64 >= 0) ? x[irow - 64] : 0.0, xd = 0.0;
+        int pv = (irow >= 0) ? ipiv[irow] : 0, pn = (irow - 64 >= 0) ? ipiv[irow - 64] : 0;
+        double nxt[D], fut[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) nxt[d] = uent(top - d);
+        const int cend = (int)((top + 1) & 63);            // the lane that holds the lowest row of a full window of 64
+        for (long long kb = top; kb >= 0; kb -= D) {
+#pragma unroll
+            for (int d = 0; d < D; d++) fut[d] = uent(kb - D - d);
+            auto step = [&](long long k, double uk) {
+                const int c0 = (int)(k & 63);
+                const int pk = __builtin_amdgcn_readlane(pv, c0);
+                if (pk >= 0) {
+                    const double xk = readlane_f64(xv, c0) / readlane_f64(uk, c0);
+                    if (lane == c0) xv = xk;
+                    else xv = fma(-uk, xk, xv);             // rows k - 1 .. k - 2 kl (0 elsewhere)
+                }
+                if (lane == c0) { xd = xv; xv = xn; pv = pn; }
+                if (c0 == cend) {                           // (uniform) rows k .. k + 63 are done
+                    const long long r1 = k + 63 - (((int)((k + 63) & 63) - lane) & 63);   // the lane's row among them
+                    x[r1] = xd;
+                    xn = (r1 - 128 >= 0) ? x[r1 - 128] : 0.0;
+                    pn = (r1 - 128 >= 0) ? ipiv[r1 - 128] : 0;
+                }
+            };
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if (kb - d >= 0) step(kb - d, nxt[d]);
+#pragma unroll
+            for (int d = 0; d < D; d++) nxt[d] = fut[d];
+        }
+        // the rows of the last, partial window (row 0 upward, fewer than 64 of them)
+        const long long rem = (top + 1) % 64;
+        if (rem) {
+            const long long r1 = (rem - 1) - (((int)((rem - 1) & 63) - lane) & 63);
+            if (r1 >= 0) x[r1] = xd;
+        }
+    }
+}
+
 // ---- a matrix that falls apart into small independent blocks (BASELINE config 5: a thousand copies of the reference's
 // cohesive deck side by side share no node) is factorised block by block: one wavefront per connected component of the node
 // graph, dense LU with partial pivoting in LDS -- instead of one workgroup walking all 16,000 columns of the band one after the
@@ -797,6 +1004,16 @@ void BandLU::setup(fem_mat A_)
         }
     if (bw_nat <= bwn) { for (int v = 0; v < nn; v++) perm[v] = v; bwn = bw_nat; }
     kl = (int)std::min<long long>(bwn * bs + bs - 1, std::max<long long>(n - 1, 0));
+    // narrow bands: one wavefront with the window of a step in registers (k_band_lu_wave; the half bandwidth is rounded up to the
+    // next instantiated one, the extra diagonals are zeros); FEM_AMD_LU_WAVE=0: the column walk of one workgroup.  The two write the
+    // same factors up to the order of roundings inside an fma.
+    const char* we = std::getenv("FEM_AMD_LU_WAVE");
+    wave = !(we && std::atoi(we) == 0) && kl <= 21;
+    const int kl_true = kl;
+    if (wave) kl = kl <= 5 ? 5 : kl <= 9 ? 9 : kl <= 13 ? 13 : kl <= 17 ? 17 : 21;
+    if (std::getenv("FEM_AMD_DIRECT_VERBOSE"))
+        fprintf(stderr, "[fem_amd lu] band LU: n = %lld, half bandwidth %d%s, %s\n", n, kl_true, wave ? (" (stored as " + std::to_string(kl) + ")").c_str() : "",
+                wave ? "one wavefront, window in registers" : "one workgroup, column walk");
     wb = 3 * kl + 1;
     size_t free_b = 0, total_b = 0;
     const double need = (double)n * wb * sizeof(double);
@@ -821,8 +1038,20 @@ void BandLU::setup(fem_mat A_)
                            A->rowlen.p, dperm.p, kl, wb, ab.p);
     ipiv.alloc((size_t)n); v0.alloc((size_t)n + 1); flag.alloc(2);
     flag.zero(s);
-    hipLaunchKernelGGL(k_band_amax, dim3(1), dim3(256), 0, s, (size_t)n * wb, ab.p, v0.p + n);
-    hipLaunchKernelGGL(k_band_lu, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p + n, flag.p);
+    // (the largest non-penalty entry: non-negative doubles order like their bits -- many workgroups and one atomic max each)
+    FEM_HIP(hipMemsetAsync(v0.p + n, 0, sizeof(double), s));
+    hipLaunchKernelGGL(k_val_amax, dim3(64), dim3(256), 0, s, (size_t)n * wb, ab.p, reinterpret_cast<unsigned long long*>(v0.p + n));
+    if (wave) {
+        double* am = v0.p + n;
+        switch (kl) {
+        case 5: hipLaunchKernelGGL(k_band_lu_wave<5>, dim3(1), dim3(64), 0, s, n, ab.p, ipiv.p, am, flag.p); break;
+        case 9: hipLaunchKernelGGL(k_band_lu_wave<9>, dim3(1), dim3(64), 0, s, n, ab.p, ipiv.p, am, flag.p); break;
+        case 13: hipLaunchKernelGGL(k_band_lu_wave<13>, dim3(1), dim3(64), 0, s, n, ab.p, ipiv.p, am, flag.p); break;
+        case 17: hipLaunchKernelGGL(k_band_lu_wave<17>, dim3(1), dim3(64), 0, s, n, ab.p, ipiv.p, am, flag.p); break;
+        default: hipLaunchKernelGGL(k_band_lu_wave<21>, dim3(1), dim3(64), 0, s, n, ab.p, ipiv.p, am, flag.p); break;
+        }
+    } else
+        hipLaunchKernelGGL(k_band_lu, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p + n, flag.p);
     FEM_HIP(hipGetLastError());
     int hflag[2] = {0, 0};
     flag.download(hflag, 2, s);
@@ -844,7 +1073,9 @@ void BandLU::solve(const double* b, double* x)
     }
     const unsigned g = cdiv((size_t)n, 256);
     hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);
-    hipLaunchKernelGGL(k_band_lu_solve, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
+    if (wave) hipLaunchKernelGGL(k_band_solve_wave, dim3(1), dim3(64), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
+    else
+        hipLaunchKernelGGL(k_band_lu_solve, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
     hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, v0.p, x);
     FEM_HIP(hipGetLastError());
 }

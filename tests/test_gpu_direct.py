@@ -144,7 +144,11 @@ def _overwrite_with(prob, rng, scale_diag):
     ("one_quad", lambda: structured_quad(1, 1)),                      # 8 dofs: one component block (k_comp_lu)
     ("one_hex", lambda: structured_hex(1, 1, 1)),                     # 24 dofs, block size 3
     ("quad3x2", lambda: structured_quad(3, 2, jitter=0.1)),           # 24 dofs
-    ("quad12x9", lambda: structured_quad(12, 9, jitter=0.1)),         # 260 dofs > 64: the band LU (k_band_lu)
+    ("quad12x9", lambda: structured_quad(12, 9, jitter=0.1)),         # 260 dofs > 64: the band LU, half bandwidth > 21: k_band_lu
+    ("quad90x2", lambda: structured_quad(90, 2, jitter=0.1)),         # narrow bands: one wavefront, window in registers (k_band_lu_wave<8|14>)
+    ("quad300x1", lambda: structured_quad(300, 1, jitter=0.1)),       # 1,204 dofs, half bandwidth ~ 5
+    ("quad70x5", lambda: structured_quad(70, 5, jitter=0.1)),         # half bandwidth ~ 15-17: k_band_lu_wave<21>
+    ("hex40x1x1", lambda: structured_hex(40, 1, 1, jitter=0.1)),      # block size 3
 ])
 def test_lu_with_row_exchanges_against_numpy(gpu_ctx, name, mesh):
     """Partial pivoting that really exchanges rows (round-3 advice: the batched block LU swapped whole rows, multipliers
@@ -193,3 +197,43 @@ def test_mat_set_values_semantics(gpu_ctx):
     with pytest.raises(capi.FemError):
         prob.K.set_values([2], [m.ndof - 1], [1.0], "add")            # node 1 and the last node share no element
     prob.destroy()
+
+
+@pytest.mark.parametrize("name,mesh,opts", [
+    ("quad_strip_2000", lambda: structured_quad(2000, 1, jitter=0.1), "-ksp_type preonly -pc_type lu"),
+    ("quad_90x2", lambda: structured_quad(90, 2, jitter=0.1), "-ksp_type preonly -pc_type lu"),
+])
+def test_band_lu_by_one_wavefront_equals_the_column_walk(gpu_ctx, monkeypatch, capfd, name, mesh, opts):
+    """Narrow bands (3 kl + 1 <= 64) are factorised and solved by one wavefront with the window of a step in registers
+    (k_band_lu_wave / k_band_solve_wave); FEM_AMD_LU_WAVE=0 selects the column walk of one workgroup (k_band_lu).  Same pivots,
+    same multipliers: on an unsymmetric matrix that exchanges rows at every step the two answers agree to round-off, and both
+    satisfy the system."""
+    m = mesh()
+    rng = np.random.default_rng(3)
+    monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    xs = {}
+    for wave in ("1", "0"):
+        monkeypatch.setenv("FEM_AMD_LU_WAVE", wave)
+        prob = driver.Problem(gpu_ctx, m, opts)
+        prob.create_matrix()
+        prob.K.zero_entries(); prob.K.assemble_elements()
+        rng2 = np.random.default_rng(5)
+        rp, ci, _ = prob.K.get_csr()
+        import scipy.sparse as sp
+        vals = rng2.uniform(-1.0, 1.0, len(ci))
+        vals[ci == np.repeat(np.arange(len(rp) - 1), np.diff(rp))] *= 1e-3      # small diagonal: a row exchange at every step
+        for r in range(len(rp) - 1):
+            prob.K.set_values([r], ci[rp[r]:rp[r + 1]], vals[rp[r]:rp[r + 1]], "insert")
+        prob.ksp.set_operators(prob.K); prob.ksp.set_up()
+        b = rng.uniform(-1.0, 1.0, m.ndof) if "b" not in xs else xs["b"]
+        xs["b"] = b
+        prob.F.set_array(b)
+        prob.ksp.solve(prob.F, prob.U)
+        assert prob.ksp.get_converged_reason() == 4
+        xs[wave] = prob.U.get_array()
+        A = sp.csr_matrix((vals, ci, rp))
+        assert np.abs(A @ xs[wave] - b).max() <= 1e-8 * np.abs(b).max() * max(1.0, np.abs(xs[wave]).max())
+        prob.destroy()
+        log = capfd.readouterr().err
+        assert ("one wavefront" in log) == (wave == "1"), log
+    assert np.abs(xs["1"] - xs["0"]).max() <= 1e-9 * np.abs(xs["0"]).max()

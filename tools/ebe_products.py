@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""tools/ebe_products.py [n] [reps] -- assembles config 3 once and runs `reps` element-by-element
-products and three nodal stress recoveries (for rocprofv3 --pmc passes over the tile kernels)."""
+"""tools/ebe_products.py [n] [reps] [jitter] -- assembles config 3 once (jitter > 0: its distorted variant, the general tile
+kernel) and runs `reps` element-by-element products and three nodal stress recoveries (for rocprofv3 --pmc passes over the tile
+kernels)."""
 import os
 import sys
 
@@ -12,8 +13,9 @@ from fem_amd.mesh import structured_hex  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 149
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+jitter = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
 ctx = capi.Context(0)
-m = structured_hex(n)
+m = structured_hex(n, jitter=jitter)
 prob = driver.Problem(ctx, m, "-mat_mult_type ebe")
 prob.assemble(); prob.ksp.set_up()
 X, Y = capi.Vec(ctx, m.ndof), capi.Vec(ctx, m.ndof)

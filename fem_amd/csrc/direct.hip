@@ -941,7 +941,7 @@ void BandLU::setup(fem_mat A_)
     // independent blocks?  connected components of the node graph (the pattern is symmetric), small ones only
     batched = false;
     {
-        static const bool comp_env = !(std::getenv("FEM_AMD_LU_COMPONENTS") && std::atoi(std::getenv("FEM_AMD_LU_COMPONENTS")) == 0);
+        const bool comp_env = !(std::getenv("FEM_AMD_LU_COMPONENTS") && std::atoi(std::getenv("FEM_AMD_LU_COMPONENTS")) == 0);   // (read at every set-up: the tests switch it)
         std::vector<int> comp((size_t)nn, -1), stack, cptr{0}, cnodes;
         int nc = 0, biggest = 0;
         for (int v0_ = 0; v0_ < nn && comp_env; v0_++) {

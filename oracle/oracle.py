@@ -278,20 +278,21 @@ class Oracle:
     # ---- nonlinear increment around the cohesive element (oracle/snes_oracle.c) ----
     class Cohesive(C.Structure):
         _fields_ = [("nlmat", _ip), ("ncohmats", C.c_int), ("props", _dp), ("rels_mode", C.c_int),
-                    ("rels_nodes", C.c_int * 4), ("bc_legacy", C.c_int)]
+                    ("rels_nodes", C.c_int * 4), ("bc_legacy", C.c_int), ("variant", C.c_int)]
 
-    def _cohesive(self, m, rels_mode=0, rels_nodes=(0, 1, 2, 3), bc_legacy=False):
+    def _cohesive(self, m, rels_mode=0, rels_nodes=(0, 1, 2, 3), bc_legacy=False, variant=0):
         nlmat = np.ascontiguousarray(m.nlmat if m.nlmat is not None else np.zeros(m.nels), dtype=np.int32)
         props = np.ascontiguousarray([pr for _, pr in m.cohmats], dtype=np.float64).reshape(-1, 6)
         c = self.Cohesive(_i(nlmat), props.shape[0], _d(props), int(rels_mode), (C.c_int * 4)(*[int(v) for v in rels_nodes]),
-                          int(bool(bc_legacy)))
+                          int(bool(bc_legacy)), int(variant))
         return c, [nlmat, props]
 
     def snes_run(self, m, rels_mode=0, rels_nodes=(0, 1, 2, 3), bc_legacy=False, inner="lu", ksp_rtol=1e-12, ksp_abstol=1e-50,
-                 maxsteps=1000):
-        """main.F90:216-296 on a deck with cohesive elements.  Returns dict(u, stress, U_hist, its, reasons, fnorms)."""
+                 maxsteps=1000, variant=0):
+        """main.F90:216-296 on a deck with cohesive elements.  Returns dict(u, stress, U_hist, its, reasons, fnorms).
+        variant: 0 = the current sources; bits of dm_cohesive.variant for tools/snes_log_variants.py."""
         p, keep = make_problem(m)
-        c, keep2 = self._cohesive(m, rels_mode, rels_nodes, bc_legacy)
+        c, keep2 = self._cohesive(m, rels_mode, rels_nodes, bc_legacy, variant)
         N = p.nnds * p.pdim
         nst = min(int(m.nsteps), maxsteps)
         u = np.zeros(N); s = np.zeros(p.nnds * 3); hist = np.zeros((nst, N))

@@ -43,6 +43,7 @@ typedef struct {
     double *agg;            /* aggregate_u */
     double dt;
     int nfuncs;
+    int step;               /* increment number, 0-based (variant 8 of dm_cohesive) */
 } snes_ctx;
 
 static int find_col(const int *colind, int lo, int hi, int c)
@@ -77,7 +78,8 @@ static void bc_force(const snes_ctx *s, double *R)
             if (p->bcnode[(size_t)i * (1 + p->pdim) + 1 + d] == 0) {
                 const double v = p->bcval[(size_t)i * p->pdim + d];
                 R[(size_t)p->pdim * p->bcnode[(size_t)i * (1 + p->pdim)] + d] =
-                    s->c->bc_legacy ? DM_PENALTY_PARAM * v * s->dt : DM_PENALTY_PARAM * v * s->dt / p->t;
+                    (s->c->bc_legacy ? DM_PENALTY_PARAM * v * s->dt : DM_PENALTY_PARAM * v * s->dt / p->t) *
+                    ((s->c->variant & 8) ? (double)(s->step + 1) : 1.0);
             }
 }
 
@@ -88,7 +90,7 @@ static void calc_jacobian(snes_ctx *s, const double *du)
     double *utot = (double *)malloc(sizeof(double) * (size_t)s->N);
     int e, i;
     memcpy(s->J, s->K, sizeof(double) * (size_t)s->nnz);               /* MatCopy(Mat_K, Jacobian) */
-    for (i = 0; i < s->N; i++) utot[i] = du[i] + s->agg[i];            /* uu = uu + aggregate_u */
+    for (i = 0; i < s->N; i++) utot[i] = du[i] + ((s->c->variant & 1) ? 0.0 : s->agg[i]);   /* uu = uu + aggregate_u */
     for (e = 0; e < p->nels; e++) {
         double ec[8], u8[8], st[64];
         const double *props;
@@ -113,7 +115,7 @@ static void calc_residual(snes_ctx *s, const double *du, double *R)
     double *cur = (double *)malloc(sizeof(double) * (size_t)s->N);
     int e, i, j, k;
     s->nfuncs++;
-    for (i = 0; i < s->N; i++) cur[i] = du[i] + s->agg[i];
+    for (i = 0; i < s->N; i++) cur[i] = du[i] + ((s->c->variant & 2) ? 0.0 : s->agg[i]);
     memcpy(R, s->F, sizeof(double) * (size_t)s->N);                     /* VecCopy(Vec_F, Residual) */
     for (e = 0; e < p->nels; e++) {
         double ec[8], u8[8], tr[8];
@@ -380,9 +382,11 @@ int dm_snes_run(const dm_problem *p, const dm_cohesive *c, int inner, double ksp
         int it = 0, reason, lin = 0;
         double fn = 0.0;
         if (t_init >= p->t || step >= maxsteps) break;
+        s.step = step;
+        if (c->variant & 4) memset(U, 0, sizeof(double) * (size_t)N);
         dm_form_rhs(p, t_init, p->dt, s.F);                              /* FormRHS :236 */
         bc_force(&s, s.F);                                               /* (the legacy scaling, when asked for) */
-        calc_jacobian(&s, U);                                            /* :241 */
+        if (!(c->variant & 16) || step == 0) calc_jacobian(&s, U);       /* :241 */
         reason = snes_solve(&s, U, inner, ksp_rtol, ksp_abstol, &it, &fn, &lin);     /* SNESSolve :242 */
         if (its) its[step] = it;
         if (reasons) reasons[step] = reason;

@@ -118,9 +118,12 @@ def test_config5_tiling(gpu_ctx, oracle):
     # search accepts it -- reason 4 -- or gives up on it -- reason -6 -- depends on that round-off, here as in the oracle; what
     # is compared is the first increment's verdict and the displacements after both)
     assert big.snes_reasons[0] == one.snes_reasons[0] == 3 and big.snes_its[0] == one.snes_its[0] == 1 and len(big.snes_its) == 2
-    assert all(r > 0 or r == -6 for r in big.snes_reasons)
+    assert big.snes_reasons[1] in (4, -6) and one.snes_reasons[1] in (4, -6)
     U = big.aggregate_u.reshape(1000, -1)
     assert np.abs(U - one.aggregate_u[None]).max() <= 1e-10 * np.abs(one.aggregate_u).max()
+    # whichever verdict the second increment gets, its step is round-off: the increment's displacement is the first one's again
+    for r in (big, one):
+        assert np.abs(r.U_hist[1] - r.U_hist[0]).max() <= 1e-9 * np.abs(r.U_hist[0]).max()
     m40 = tile_deck(m1, 40)
     a = driver.run_nonlinear(m40, "", ctx=gpu_ctx, recover_stress=False)
     b = oracle.snes_run(m40)
@@ -128,6 +131,27 @@ def test_config5_tiling(gpu_ctx, oracle):
     # gives on a direction made of round-off differs between the two factorizations; the increments do not)
     assert a.snes_its[0] == b["its"][0] == 1 and a.snes_reasons[0] == b["reasons"][0] == 3 and min(a.snes_reasons) > 0
     assert np.abs(a.aggregate_u - b["u"]).max() <= 1e-9 * np.abs(b["u"]).max()
+
+
+def test_config5_the_two_factorisations_agree(gpu_ctx, monkeypatch):
+    """Round-3 advice: the batched block LU (one wavefront per connected component, the default on the x1000 tiling) replaced the
+    band LU there in the same change that loosened test_config5_tiling.  Both factorisations on the same decks (FEM_AMD_LU_COMPONENTS
+    is read at every set-up): the same verdict and iteration count in the first increment, the same displacements after both, and in
+    the second increment -- whose Newton direction is round-off -- a verdict from the same pair and a step below 1e-9 of the field."""
+    m1 = read_inp(DECK)
+    for m in (m1, tile_deck(m1, 40), tile_deck(m1, 1000)):
+        runs = {}
+        for comp in ("1", "0"):
+            monkeypatch.setenv("FEM_AMD_LU_COMPONENTS", comp)
+            runs[comp] = driver.run_nonlinear(m, "", ctx=gpu_ctx, recover_stress=False)
+        a, b = runs["1"], runs["0"]
+        assert a.snes_reasons[0] == b.snes_reasons[0] == 3 and a.snes_its[0] == b.snes_its[0] == 1
+        assert len(a.snes_its) == len(b.snes_its) == 2
+        assert a.snes_reasons[1] in (4, -6) and b.snes_reasons[1] in (4, -6)
+        assert np.abs(a.U_hist[0] - b.U_hist[0]).max() <= 1e-11 * np.abs(b.U_hist[0]).max()
+        assert np.abs(a.aggregate_u - b.aggregate_u).max() <= 1e-9 * np.abs(b.aggregate_u).max()
+        for r in (a, b):
+            assert np.abs(r.U_hist[1] - r.U_hist[0]).max() <= 1e-9 * np.abs(r.U_hist[0]).max()
 
 
 @pytest.mark.parametrize("rels_mode", [0, 1])

@@ -327,6 +327,26 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     raw_of(r2, 2);
     constexpr int NG = KIND == 2 ? 5 : 11;
     if constexpr (AFFINE) tile_fetch_data<NG, STREAM>(d0, i0, pos_of(0), geo, geo_stride, x);
+    // the general kernel: coordinates and values of the elements of step s + 1 are asked for at the END of step s -- behind the
+    // arithmetic, in front of the hand-over, the LDS adds and the barrier -- so that their way through L2 / the Infinity Cache runs
+    // under those instead of in front of the next step's arithmetic (round-4 counters: 30 % of the wave time parked at s_waitcnt with
+    // the gathers at the top of the step).  No register is added at the peak: inside the Gauss pairs these 48 doubles are dead.
+    double Xn[8][3], un[8][3];
+    auto gather_general = [&](const TileIdx& in) {
+#pragma unroll
+        for (int a = 0; a < 8; a++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) { Xn[a][d] = 0.0; un[a][d] = 0.0; }
+        if (in.valid) {
+#pragma unroll
+            for (int a = 0; a < 8; a++) {
+                if ((in.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
+                load_node3(Xn[a], coords, in.v[a]);
+                load_node3(un[a], x, in.v[a]);
+            }
+        }
+    };
+    if constexpr (!AFFINE) gather_general(i0);
     auto do_step = [&](int s, TileData& dcur, TileData& dnext) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
@@ -353,21 +373,14 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 #pragma unroll
             for (int a = 0; a < 8; a++)
 #pragma unroll
-                for (int d = 0; d < 3; d++) { X[a][d] = 0.0; u[a][d] = 0.0; }
-            if (i0.valid) {
-#pragma unroll
-                for (int a = 0; a < 8; a++) {
-                    if ((i0.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
-                    load_node3(X[a], coords, i0.v[a]);
-                    load_node3(u[a], x, i0.v[a]);
-                }
-            }
+                for (int d = 0; d < 3; d++) { X[a][d] = Xn[a][d]; u[a][d] = un[a][d]; }
             tile_complete<3>(X, i0.fl);
             tile_complete<3>(u, i0.fl);
             if constexpr (OP == 0) {
                 const DCoef D = dmat_coef(i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25);
                 hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
             } else hex_nodal_stress<OP - 1>(X, u, g, i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25, fe);
+            gather_general(i1);   // step s + 1 (an invalid record beyond the last step: nothing is loaded)
         }
         // +x face forces of a linked lane go to the next lane's -x face nodes
         {
@@ -613,7 +626,10 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
 // stored diagonal and the Lame factor): no coordinate is read.  sigma = D eps (DMat, src/m_local.F90:204-228; Voigt order xx yy zz xy yz zx of BMat :160-168), summed
 // per node over the elements (src/main.F90:258-268) in LDS -- colour by colour, +x face values handed along the 16-lane rows
 // as in the product, so every sum has one writer and a fixed order -- and divided by the valence on the way out (:277-279).
-template <int KIND>
+// UNI: every tile of the plan has one geometry record (lhdr[7], k_tile_geo_uniform: a brick of one spacing and one material) -- the
+// record and the material of its element are read once per tile instead of 48 B per lane slot plus a gather of E and nu behind
+// the element id (round 3: 0.63 GB of traffic for 0.43 GB of nodal data, 0.19 GB of it these records)
+template <int KIND, bool UNI = false>
 __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
                                                           const int* __restrict__ tnodes, const int* __restrict__ telems,
                                                           const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
@@ -628,6 +644,8 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
     if (lb >= (unsigned)nlist) return;
     const int* hd = lhdr + 8 * (size_t)lb;
     const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5];
+    const int uref = UNI ? hd[7] : 0;
+    const int eref = (UNI && uref > 0) ? telems[uref - 1] : -1;
     double* xs = lds;              // xs[d * MN + i]: u of the tile's nodes
     double* acc = lds + 3 * MN;    // acc[c * MO + i]: six stress sums of the owned nodes
     int nv[NPT];
@@ -665,10 +683,11 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
         const size_t k = (size_t)elem_off + first + threadIdx.x;
         q.c16 = tconn[k];
         q.fl = tflags[k];
-        const int e = telems[k];
+        const size_t kg = UNI ? (size_t)(uref - 1) : k;     // (UNI: the same address in every lane and step)
+        const int e = UNI ? eref : telems[k];
 #pragma unroll
-        for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + k];
-        q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + k];
+        for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + kg];
+        q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + kg];
         q.E = (e >= 0) ? Ev[e] : 1.0; q.nu = (e >= 0) ? nuv[e] : 0.25;
     };
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
@@ -1873,14 +1892,16 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
         constexpr size_t shs = (size_t)(3 * TILE_X_LDS_NODES + 6 * TILE_X_MAX_OWN) * sizeof(double);
         static OncePerDevice sonce;
         if (sonce.first(m->ctx->device))
-            for (const void* f : {reinterpret_cast<const void*>(k_tile_stress_cart<1>), reinterpret_cast<const void*>(k_tile_stress_cart<2>)})
+            for (const void* f : {reinterpret_cast<const void*>(k_tile_stress_cart<1, false>), reinterpret_cast<const void*>(k_tile_stress_cart<2, false>),
+                                  reinterpret_cast<const void*>(k_tile_stress_cart<1, true>), reinterpret_cast<const void*>(k_tile_stress_cart<2, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs));
-        if (P.n_cart)
-            hipLaunchKernelGGL(k_tile_stress_cart<2>, dim3((P.n_cart + 7) / 8 * 8), dim3(256), shs, s, P.n_cart, P.lhdr_cart.p, P.steps.p,
-                               P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U, P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);
-        if (P.n_aff)
-            hipLaunchKernelGGL(k_tile_stress_cart<1>, dim3((P.n_aff + 7) / 8 * 8), dim3(256), shs, s, P.n_aff, P.lhdr_aff.p, P.steps.p,
-                               P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U, P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);
+        const bool uni = P.n_uniform == (long long)P.n_cart + P.n_aff;    // (as the product: every tile has one record)
+        auto launch = [&](auto kern, int n, const int* list) {
+            hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shs, s, n, list, P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U,
+                               P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);
+        };
+        if (P.n_cart) { if (uni) launch(k_tile_stress_cart<2, true>, P.n_cart, P.lhdr_cart.p); else launch(k_tile_stress_cart<2, false>, P.n_cart, P.lhdr_cart.p); }
+        if (P.n_aff) { if (uni) launch(k_tile_stress_cart<1, true>, P.n_aff, P.lhdr_aff.p); else launch(k_tile_stress_cart<1, false>, P.n_aff, P.lhdr_aff.p); }
     }
     for (int half = 0; half < 2; half++) {
         double* out = S + (size_t)(3 * half) * nn;

@@ -52,6 +52,13 @@ struct BandLU {
     int wb = 0;                 // stored row width: 3 kl + 1
     bool failed = false;        // a NaN reached a pivot column
     bool wave = false;          // factorised (and solved) by one wavefront with the window of a step in registers (3 kl + 1 <= 64)
+    // narrow bands with many columns: block cyclic reduction (direct.hip), used where set-up met no small pivot; every solve checks its
+    // backward error and falls back to the band LU (factorised then, `band_ready`)
+    bool bcr = false, band_ready = false;
+    int nbk = 0;                // blocks of kl rows
+    DBuf<double> cL0, cD0, cU0, cL, cD, cU, cr;   // the block tridiagonal form (pristine / work copies), right-hand side and solution by blocks
+    void factor_band();
+    bool bcr_reduce(bool with_rhs);   // the levels down (and, with a right-hand side, up); false: a small pivot was met
     int null_pivots = 0;        // pivots below 1e-6 of the largest entry, fixed to zero
     DBuf<int> perm_dof;         // [n] new position of every dof
     DBuf<double> ab;            // [n*wb] row i holds columns i-kl .. i+2kl

@@ -810,6 +810,159 @@ __global__ void __launch_bounds__(64) k_band_solve_wave(long long n, int kl, int
     }
 }
 
+// ---- narrow bands with many columns: block cyclic reduction ----------------------------------------------------------------
+// A band of half bandwidth <= B is block tridiagonal in blocks of B rows: L_i x_{i-1} + D_i x_i + U_i x_{i+1} = r_i.  One level of
+// cyclic reduction removes every second active block -- x_j = D_j^-1 (r_j - L_j x_{j-s} - U_j x_{j+s}) put into the rows of its two
+// neighbours -- and leaves a block tridiagonal system of half the size and twice the stride; log2(nb) levels down one block is
+// left, log2(nb) levels up every x_j follows from its two neighbours.  Every level is a few hundred independent B x B problems:
+// one wavefront each (lane = column of [D | L U r], one register per row, Gauss-Jordan with partial pivoting INSIDE the block,
+// v_readlane for the pivot column), about 3 log2(nb) small launches instead of the chain of n dependent column steps of an LU
+// (config 5 as a connected strip, n = 8,008, B = 13: 0.3 ms against 5.6 + 3.2 ms for the band LU and its solve by one wavefront).
+// What it gives up is pivoting ACROSS blocks: exact for the matrices it is meant for (Mat_K with its penalties plus the cohesive
+// tangents: every reduced diagonal block stays a well-conditioned Schur complement), not for any band matrix.  So it is used
+// only where set-up has run the reduction of the matrix once without meeting a small pivot, and every solve checks the
+// componentwise backward error of its answer (max_i |b - A x|_i / (|A| |x| + |b|)_i <= 1e-10) -- a solve that fails either
+// test goes to the band LU, for this matrix from then on.  FEM_AMD_LU_BCR=0 switches it off.
+template <int B>
+__global__ void __launch_bounds__(256) k_bcr_blocks(long long n, int nbk, const double* __restrict__ ab, const double* __restrict__ amax,
+                                                    double* __restrict__ L, double* __restrict__ D, double* __restrict__ U)
+{
+    constexpr int kl = B, wb = 3 * B + 1, BB = B * B;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)nbk * BB) return;
+    const int I = (int)(t / BB), r = (int)(t % BB) / B, c = (int)(t % BB) % B;
+    const long long i = (long long)I * B + r;
+    auto at = [&](long long j) -> double {     // A(i, j), 0 outside the band and the matrix
+        const long long o = j - i + kl;
+        return (i < n && j >= 0 && j < n && o >= 0 && o < wb) ? ab[i * wb + o] : 0.0;
+    };
+    const long long j0 = (long long)I * B + c;
+    L[t] = at(j0 - B);
+    U[t] = at(j0 + B);
+    D[t] = (i < n) ? at(j0) : (r == c ? *amax : 0.0);   // (rows past the matrix in the last block: a diagonal of the matrix's own scale)
+}
+// one wavefront per eliminated block j = j0 + t jstep: [L_j U_j r_j] <- D_j^-1 [L_j U_j r_j]
+template <int B>
+__global__ void __launch_bounds__(64) k_bcr_eliminate(int count, int j0, int jstep, double* __restrict__ L, const double* __restrict__ D,
+                                                      double* __restrict__ U, double* __restrict__ rv, const double* __restrict__ amax,
+                                                      int* __restrict__ flag)
+{
+    constexpr int BB = B * B;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= count) return;
+    const size_t j = (size_t)j0 + (size_t)t * jstep;
+    const double tiny = 1e-6 * (*amax);
+    // lane c: column c of [D | L | U | r]
+    const int kind = lane < B ? 0 : lane < 2 * B ? 1 : lane < 3 * B ? 2 : lane == 3 * B ? 3 : 4, cc = lane - B * (kind < 3 ? kind : 3);
+    double M[B];
+#pragma unroll
+    for (int r = 0; r < B; r++)
+        M[r] = kind == 0 ? D[j * BB + r * B + cc] : kind == 1 ? L[j * BB + r * B + cc] : kind == 2 ? U[j * BB + r * B + cc] : kind == 3 ? rv[j * B + r] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        int pl = k;
+        double bl = fabs(M[k]);
+#pragma unroll
+        for (int r = k + 1; r < B; r++) { const double a = fabs(M[r]); if (a > bl) { bl = a; pl = r; } }
+        const int p = __builtin_amdgcn_readlane(pl, k);
+        const double best = readlane_f64(bl, k);
+        if (!(best > tiny)) bad = true;                    // (uniform) a small pivot or a NaN: the caller falls back to the band LU
+        if (p != k) {
+#pragma unroll
+            for (int r = k + 1; r < B; r++)
+                if (p == r) { const double tt = M[k]; M[k] = M[r]; M[r] = tt; }
+        }
+        const double rp = 1.0 / readlane_f64(M[k], k);
+        M[k] *= rp;
+#pragma unroll
+        for (int r = 0; r < B; r++)
+            if (r != k) { const double f = readlane_f64(M[r], k); M[r] = fma(-f, M[k], M[r]); }
+    }
+    if (bad && lane == 0) atomicAdd(flag, 1);
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        if (kind == 1) L[j * BB + r * B + cc] = M[r];
+        else if (kind == 2) U[j * BB + r * B + cc] = M[r];
+        else if (kind == 3) rv[j * B + r] = M[r];
+    }
+}
+// one wavefront per surviving block i = t istep: its rows take in the two eliminated neighbours i - s, i + s
+template <int B>
+__global__ void __launch_bounds__(64) k_bcr_update(int count, int istep, int s, int nbk, double* __restrict__ L, double* __restrict__ D,
+                                                   double* __restrict__ U, double* __restrict__ rv)
+{
+    constexpr int BB = B * B;
+    __shared__ double Ls[BB], Us[BB];
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= count) return;
+    const long long i = (long long)t * istep, jl = i - s, jr = i + s;
+    const bool hl = jl >= 0, hr = jr < nbk;
+    for (int e = lane; e < BB; e += 64) { Ls[e] = hl ? L[(size_t)i * BB + e] : 0.0; Us[e] = hr ? U[(size_t)i * BB + e] : 0.0; }
+    const int kind = lane < B ? 0 : lane < 2 * B ? 1 : lane < 3 * B ? 2 : lane == 3 * B ? 3 : 4, cc = lane - B * (kind < 3 ? kind : 3);
+    double Wl[B], Wr[B], out[B];
+#pragma unroll
+    for (int q = 0; q < B; q++) {
+        // from the left neighbour: D^-1 U (into D_i), D^-1 L (the new L_i), D^-1 r; from the right one: D^-1 L (into D_i), D^-1 U (the new U_i), D^-1 r
+        Wl[q] = !hl ? 0.0 : kind == 0 ? U[(size_t)jl * BB + q * B + cc] : kind == 1 ? L[(size_t)jl * BB + q * B + cc] : kind == 3 ? rv[(size_t)jl * B + q] : 0.0;
+        Wr[q] = !hr ? 0.0 : kind == 0 ? L[(size_t)jr * BB + q * B + cc] : kind == 2 ? U[(size_t)jr * BB + q * B + cc] : kind == 3 ? rv[(size_t)jr * B + q] : 0.0;
+        out[q] = kind == 0 ? D[(size_t)i * BB + q * B + cc] : kind == 3 ? rv[(size_t)i * B + q] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        double a = out[r];
+#pragma unroll
+        for (int q = 0; q < B; q++) a = fma(-Ls[r * B + q], Wl[q], fma(-Us[r * B + q], Wr[q], a));
+        out[r] = a;
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        if (kind == 0) D[(size_t)i * BB + r * B + cc] = out[r];
+        else if (kind == 1) L[(size_t)i * BB + r * B + cc] = out[r];
+        else if (kind == 2) U[(size_t)i * BB + r * B + cc] = out[r];
+        else if (kind == 3) rv[(size_t)i * B + r] = out[r];
+    }
+}
+// the way up: x_j = (D^-1 r)_j - (D^-1 L)_j x_{j-s} - (D^-1 U)_j x_{j+s}, one wavefront per block eliminated at this stride
+template <int B>
+__global__ void __launch_bounds__(64) k_bcr_back(int count, int j0, int jstep, int s, int nbk, const double* __restrict__ L,
+                                                 const double* __restrict__ U, double* __restrict__ rv)
+{
+    constexpr int BB = B * B;
+    const int t = blockIdx.x, lane = threadIdx.x;
+    if (t >= count) return;
+    const long long j = (long long)j0 + (long long)t * jstep, jl = j - s, jr = j + s;
+    const double xl = (lane < B && jl >= 0) ? rv[(size_t)jl * B + lane] : 0.0, xr = (lane < B && jr < nbk) ? rv[(size_t)jr * B + lane] : 0.0;
+    const int r = lane < B ? lane : 0;
+    double a = rv[(size_t)j * B + r];
+#pragma unroll
+    for (int q = 0; q < B; q++)
+        a = fma(-L[(size_t)j * BB + r * B + q], readlane_f64(xl, q), fma(-U[(size_t)j * BB + r * B + q], readlane_f64(xr, q), a));
+    if (lane < B) rv[(size_t)j * B + lane] = a;
+}
+// componentwise backward error of x for the band matrix (renumbered system): max_i |b - A x|_i / (|A| |x| + |b|)_i
+__global__ void __launch_bounds__(256) k_band_backward_error(long long n, int kl, int wb, const double* __restrict__ ab,
+                                                             const double* __restrict__ x, const double* __restrict__ b,
+                                                             unsigned long long* __restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double e = 0.0;
+    if (i < n) {
+        double sum = b[i], den = fabs(b[i]);
+        for (int o = 0; o < wb; o++) {
+            const long long j = i - kl + o;
+            if (j < 0 || j >= n) continue;
+            const double a = ab[i * wb + o];
+            sum = fma(-a, x[j], sum); den = fma(fabs(a), fabs(x[j]), den);
+        }
+        e = (den > 0.0) ? fabs(sum) / den : 0.0;
+        if (isnan(e)) e = 1.0;
+    }
+    for (int o = 32; o > 0; o >>= 1) e = fmax(e, __shfl_down(e, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(e));
+}
+
 // ---- a matrix that falls apart into small independent blocks (BASELINE config 5: a thousand copies of the reference's
 // cohesive deck side by side share no node) is factorised block by block: one wavefront per connected component of the node
 // graph, dense LU with partial pivoting in LDS -- instead of one workgroup walking all 16,000 columns of the band one after the
@@ -1036,11 +1189,100 @@ void BandLU::setup(fem_mat A_)
     else
         hipLaunchKernelGGL(k_bandfull_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
                            A->rowlen.p, dperm.p, kl, wb, ab.p);
-    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 1); flag.alloc(2);
+    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 2); flag.alloc(2);
     flag.zero(s);
     // (the largest non-penalty entry: non-negative doubles order like their bits -- many workgroups and one atomic max each)
     FEM_HIP(hipMemsetAsync(v0.p + n, 0, sizeof(double), s));
     hipLaunchKernelGGL(k_val_amax, dim3(64), dim3(256), 0, s, (size_t)n * wb, ab.p, reinterpret_cast<unsigned long long*>(v0.p + n));
+    band_ready = false; bcr = false;
+    const char* be = std::getenv("FEM_AMD_LU_BCR");
+    if (wave && !(be && std::atoi(be) == 0) && n >= 32LL * kl) {
+        // block cyclic reduction (see k_bcr_*): the matrix alone is reduced once; no small pivot on the way -> the solves use it
+        nbk = (int)((n + kl - 1) / kl);
+        const size_t nb2 = (size_t)nbk * kl * kl;
+        for (DBuf<double>* a : {&cL0, &cD0, &cU0, &cL, &cD, &cU}) if (a->n != nb2) a->alloc(nb2);
+        if (cr.n != (size_t)nbk * kl) cr.alloc((size_t)nbk * kl);
+        const unsigned gb = cdiv(nb2, 256);
+        switch (kl) {
+        case 5: hipLaunchKernelGGL(k_bcr_blocks<5>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
+        case 9: hipLaunchKernelGGL(k_bcr_blocks<9>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
+        case 13: hipLaunchKernelGGL(k_bcr_blocks<13>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
+        case 17: hipLaunchKernelGGL(k_bcr_blocks<17>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
+        default: hipLaunchKernelGGL(k_bcr_blocks<21>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
+        }
+        bcr = bcr_reduce(false);
+        if (std::getenv("FEM_AMD_DIRECT_VERBOSE"))
+            fprintf(stderr, "[fem_amd lu] block cyclic reduction: %d blocks of %d rows: %s\n", nbk, kl, bcr ? "used" : "a small pivot on the way: band LU");
+        if (bcr) { null_pivots = 0; failed = false; return; }
+        flag.zero(s);
+    }
+    factor_band();
+}
+
+// levels of the block cyclic reduction on the work copies; with_rhs: cr holds the right-hand side by blocks and receives the solution
+bool BandLU::bcr_reduce(bool with_rhs)
+{
+    fem_ctx ctx = A->ctx;
+    hipStream_t s = ctx->stream;
+    const size_t nb2 = (size_t)nbk * kl * kl;
+    FEM_HIP(hipMemcpyAsync(cL.p, cL0.p, nb2 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    FEM_HIP(hipMemcpyAsync(cD.p, cD0.p, nb2 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    FEM_HIP(hipMemcpyAsync(cU.p, cU0.p, nb2 * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (!with_rhs) cr.zero(s);
+    flag.zero(s);
+    const double* am = v0.p + n;
+    auto elim = [&](int count, int j0, int jstep) {
+        if (count <= 0) return;
+        switch (kl) {
+        case 5: hipLaunchKernelGGL(k_bcr_eliminate<5>, dim3(count), dim3(64), 0, s, count, j0, jstep, cL.p, cD.p, cU.p, cr.p, am, flag.p); break;
+        case 9: hipLaunchKernelGGL(k_bcr_eliminate<9>, dim3(count), dim3(64), 0, s, count, j0, jstep, cL.p, cD.p, cU.p, cr.p, am, flag.p); break;
+        case 13: hipLaunchKernelGGL(k_bcr_eliminate<13>, dim3(count), dim3(64), 0, s, count, j0, jstep, cL.p, cD.p, cU.p, cr.p, am, flag.p); break;
+        case 17: hipLaunchKernelGGL(k_bcr_eliminate<17>, dim3(count), dim3(64), 0, s, count, j0, jstep, cL.p, cD.p, cU.p, cr.p, am, flag.p); break;
+        default: hipLaunchKernelGGL(k_bcr_eliminate<21>, dim3(count), dim3(64), 0, s, count, j0, jstep, cL.p, cD.p, cU.p, cr.p, am, flag.p); break;
+        }
+    };
+    auto update = [&](int count, int istep, int st) {
+        if (count <= 0) return;
+        switch (kl) {
+        case 5: hipLaunchKernelGGL(k_bcr_update<5>, dim3(count), dim3(64), 0, s, count, istep, st, nbk, cL.p, cD.p, cU.p, cr.p); break;
+        case 9: hipLaunchKernelGGL(k_bcr_update<9>, dim3(count), dim3(64), 0, s, count, istep, st, nbk, cL.p, cD.p, cU.p, cr.p); break;
+        case 13: hipLaunchKernelGGL(k_bcr_update<13>, dim3(count), dim3(64), 0, s, count, istep, st, nbk, cL.p, cD.p, cU.p, cr.p); break;
+        case 17: hipLaunchKernelGGL(k_bcr_update<17>, dim3(count), dim3(64), 0, s, count, istep, st, nbk, cL.p, cD.p, cU.p, cr.p); break;
+        default: hipLaunchKernelGGL(k_bcr_update<21>, dim3(count), dim3(64), 0, s, count, istep, st, nbk, cL.p, cD.p, cU.p, cr.p); break;
+        }
+    };
+    auto back = [&](int count, int j0, int jstep, int st) {
+        if (count <= 0) return;
+        switch (kl) {
+        case 5: hipLaunchKernelGGL(k_bcr_back<5>, dim3(count), dim3(64), 0, s, count, j0, jstep, st, nbk, cL.p, cU.p, cr.p); break;
+        case 9: hipLaunchKernelGGL(k_bcr_back<9>, dim3(count), dim3(64), 0, s, count, j0, jstep, st, nbk, cL.p, cU.p, cr.p); break;
+        case 13: hipLaunchKernelGGL(k_bcr_back<13>, dim3(count), dim3(64), 0, s, count, j0, jstep, st, nbk, cL.p, cU.p, cr.p); break;
+        case 17: hipLaunchKernelGGL(k_bcr_back<17>, dim3(count), dim3(64), 0, s, count, j0, jstep, st, nbk, cL.p, cU.p, cr.p); break;
+        default: hipLaunchKernelGGL(k_bcr_back<21>, dim3(count), dim3(64), 0, s, count, j0, jstep, st, nbk, cL.p, cU.p, cr.p); break;
+        }
+    };
+    int smax = 0;
+    for (int st = 1; st < nbk; st *= 2) {
+        elim((nbk - st + 2 * st - 1) / (2 * st), st, 2 * st);          // blocks st, 3 st, 5 st, ...
+        update((nbk + 2 * st - 1) / (2 * st), 2 * st, st);             // blocks 0, 2 st, 4 st, ...
+        smax = st;
+    }
+    elim(1, 0, 0);                                                     // the one block left
+    if (with_rhs)
+        for (int st = smax; st >= 1; st /= 2) back((nbk - st + 2 * st - 1) / (2 * st), st, 2 * st, st);
+    FEM_HIP(hipGetLastError());
+    int hflag = 0;
+    flag.download(&hflag, 1, s);
+    FEM_HIP(hipStreamSynchronize(s));
+    return hflag == 0;
+}
+
+// the band LU proper: at set-up, or when a solve by block cyclic reduction has failed its backward-error test
+void BandLU::factor_band()
+{
+    fem_ctx ctx = A->ctx;
+    hipStream_t s = ctx->stream;
+    flag.zero(s);
     if (wave) {
         double* am = v0.p + n;
         switch (kl) {
@@ -1058,6 +1300,7 @@ void BandLU::setup(fem_mat A_)
     FEM_HIP(hipStreamSynchronize(s));
     null_pivots = hflag[0];      // (MUMPS ICNTL(24) = 1 fixes them the same way, src/main.F90:368)
     failed = hflag[1] != 0;      // a NaN reached a pivot column: KSP_DIVERGED_PC_FAILED
+    band_ready = true;
 }
 
 void BandLU::solve(const double* b, double* x)
@@ -1072,6 +1315,30 @@ void BandLU::solve(const double* b, double* x)
         return;
     }
     const unsigned g = cdiv((size_t)n, 256);
+    if (bcr) {
+        cr.zero(s);                                                     // (the rows past the matrix in the last block)
+        hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, cr.p);
+        hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);   // (b in the band's numbering, for the test)
+        bool ok = bcr_reduce(true);
+        if (ok) {
+            unsigned long long* eb = reinterpret_cast<unsigned long long*>(v0.p + n + 1);
+            FEM_HIP(hipMemsetAsync(eb, 0, sizeof(double), s));
+            hipLaunchKernelGGL(k_band_backward_error, dim3(g), dim3(256), 0, s, n, kl, wb, ab.p, cr.p, v0.p, eb);
+            double err = 1.0;
+            FEM_HIP(hipMemcpyAsync(&err, eb, sizeof(double), hipMemcpyDeviceToHost, s));
+            FEM_HIP(hipStreamSynchronize(s));
+            ok = err <= 1e-10;
+            if (!ok && std::getenv("FEM_AMD_DIRECT_VERBOSE"))
+                fprintf(stderr, "[fem_amd lu] block cyclic reduction: backward error %.2e: band LU from here on\n", err);
+        }
+        if (ok) {
+            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, cr.p, x);
+            FEM_HIP(hipGetLastError());
+            return;
+        }
+        bcr = false;
+        if (!band_ready) factor_band();
+    }
     hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);
     if (wave) hipLaunchKernelGGL(k_band_solve_wave, dim3(1), dim3(64), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
     else

@@ -237,3 +237,52 @@ def test_band_lu_by_one_wavefront_equals_the_column_walk(gpu_ctx, monkeypatch, c
         log = capfd.readouterr().err
         assert ("one wavefront" in log) == (wave == "1"), log
     assert np.abs(xs["1"] - xs["0"]).max() <= 1e-9 * np.abs(xs["0"]).max()
+
+
+@pytest.mark.parametrize("name,mesh", [("quad_400x1", lambda: structured_quad(400, 1, jitter=0.1)),      # half bandwidth 7 (blocks of 9 rows)
+                                       ("quad_300x2", lambda: structured_quad(300, 2, jitter=0.1)),      # 11 (13)
+                                       ("quad_320x3", lambda: structured_quad(320, 3, jitter=0.1))])     # 15 (17)
+def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, capfd, name, mesh):
+    """Narrow bands with many columns go through block cyclic reduction (k_bcr_*): Mat_K with its penalties plus a small unsymmetric
+    perturbation (what a cohesive tangent does to the Newton Jacobian) -- the set-up's trial reduction meets no small pivot, the
+    solve passes its backward-error test, and the answer agrees with scipy's sparse LU and with the band LU (FEM_AMD_LU_BCR=0)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as sla
+    m = mesh()
+    monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    xs = {}
+    for bcr in ("1", "0"):
+        monkeypatch.setenv("FEM_AMD_LU_BCR", bcr)
+        prob = driver.Problem(gpu_ctx, m, LU)
+        prob.assemble()
+        rp, ci, v = prob.K.get_csr()
+        # an unsymmetric term of the size of the entries themselves on one off-diagonal pair per tenth row
+        rows = np.arange(3, m.ndof - 3, 10)
+        scale = np.abs(v[v < 1e29]).max()
+        for r in rows:
+            cols = ci[rp[r]:rp[r + 1]]
+            c = int(cols[cols != r][0])
+            prob.K.set_values([r], [c], [0.05 * scale], "add")
+        rp, ci, v = prob.K.get_csr()
+        prob.ksp.set_operators(prob.K); prob.ksp.set_up()
+        prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+        b = prob.F.get_array()
+        prob.ksp.solve(prob.F, prob.U)
+        assert prob.ksp.get_converged_reason() == 4
+        xs[bcr] = prob.U.get_array()
+        log = capfd.readouterr().err
+        if bcr == "1":
+            assert "block cyclic reduction" in log and "used" in log and "backward error" not in log, log
+        else:
+            assert "block cyclic reduction" not in log
+        A = sp.csr_matrix((v, ci, rp))
+        d = A.diagonal()
+        ref = sla.spsolve(sp.diags(1.0 / d) @ A, b / d)          # (rows scaled: the penalties are 1e30)
+        # a slender cantilever (cond ~ (L / h)^4 ~ 1e9 ... 1e10): the answer is judged by its componentwise backward error; two
+        # backward-stable solvers agree in the forward error only to cond x eps
+        x = xs[bcr]
+        bwd = np.abs(b - A @ x) / (abs(A) @ np.abs(x) + np.abs(b) + 1e-300)
+        assert bwd.max() <= 1e-10, bwd.max()
+        assert np.abs(x - ref).max() <= 1e-5 * np.abs(ref).max()
+        prob.destroy()
+    assert np.abs(xs["1"] - xs["0"]).max() <= 1e-5 * np.abs(xs["0"]).max()

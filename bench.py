@@ -643,6 +643,16 @@ def main():
                 out["config3_distorted"]["roofline"]["bound"] = "fp64 vector issue (the kernel recomputes the geometry of every element: no stored records)"
             pd_.destroy()
             del md
+        if hex_case and args.jitter == 0.0 and args.mult == "ebe" and args.pc == "jacobi" and not args.no_distorted:
+            # ... and what a mesh that also holds other element types gets (tet / mixed decks: no one-pass tile plan): the two-kernel
+            # element-by-element product (element forces to a buffer + ordered per-node gather), here on the same brick
+            pg_ = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} -pc_type jacobi -mat_mult_type ebe_gather")
+            tg, itg, rg, _, _ = steady_steps(pg_, mesh, 2)
+            out["config3_two_kernel_product"] = {
+                "workload": f"config 3 with -mat_mult_type ebe_gather (the product of meshes that are not hex8 / quad4 alone: k_ebe_apply + k_ebe_gather)",
+                "value": mesh.ndof / tg, "unit": "DOF/s", "ms_per_step": tg * 1e3, "cg_iterations": itg, "converged_reason": rg,
+                "ms_per_cg_iteration": tg * 1e3 / max(itg, 1), "steps": 2}
+            pg_.destroy()
         if hex_case and not args.no_c2:
             # config 2 of BASELINE.json (707^2 quad4 plate, 1.0 M DOF) in the same line: steady-state steps as above, the kernel that
             # is timed priced against its own bytes and flops, the CPU leg and the multigrid run of the same plate

@@ -512,18 +512,6 @@ __global__ void __launch_bounds__(256) k_bandfull_fill(int nn, const int* __rest
     }
 }
 
-// largest entry that is not a penalty (scale of the null-pivot test)
-__global__ void __launch_bounds__(256) k_band_amax(size_t n, const double* __restrict__ ab, double* __restrict__ out)
-{
-    __shared__ double sh[256];
-    double m = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += 256) { const double a = fabs(ab[i]); if (a < 1e29 && a > m) m = a; }
-    sh[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + o]); __syncthreads(); }
-    if (threadIdx.x == 0) *out = sh[0];
-}
-
 // dgbtf2: one workgroup, column by column
 __global__ void __launch_bounds__(256) k_band_lu(long long n, int kl, int wb, double* __restrict__ ab, int* __restrict__ ipiv,
                                                  const double* __restrict__ amax, int* __restrict__ flag)

@@ -97,6 +97,24 @@ def test_fortran_driver_mixed_deck_matches_oracle(tmp_path, oracle):
     assert np.abs(full[:, 2:] - so).max() <= 1e-9 * np.abs(so).max()
 
 
+def test_fortran_driver_on_the_traction_deck(tmp_path, oracle):
+    """examples/el_test.inp (the reference's only deck with tractions; element record re-typed) through the Fortran driver: the
+    Fortran reader's traction records, ApplyTraction inside fem_form_rhs -- the uniform stress state sigma_xx = sigma_yy = tau_xy =
+    -1000 of that deck, and the oracle's displacements."""
+    _need(EXE)
+    deck = os.path.join(ROOT, "tests", "golden", "decks", "el_test.inp")
+    for extra in ([], ["-ksp_type", "preonly", "-pc_type", "lu"], ["-mat_mult_type", "ebe"]):
+        p = subprocess.run([EXE, "-f", deck, "-ksp_rtol", "1e-14", "-o", str(tmp_path / "0_output")] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        full = np.loadtxt(tmp_path / "0_output_000000.full.txt", skiprows=1)
+        from fem_amd.inp import read_inp
+        uo, so, _ = oracle.run(read_inp(deck), "lu")
+        free = np.abs(uo) > 1e-20
+        assert np.abs(full[:, :2].ravel()[free] - uo[free]).max() <= 1e-10 * np.abs(uo).max()
+        assert np.abs(full[:, 2:] + 1000.0).max() <= 1e-8 * 1000.0
+
+
 def test_fortran_driver_with_the_reference_solver_options(tmp_path, oracle):
     """`-ksp_type preonly -pc_type lu` (what src/main.F90:355-358 selects) through the Fortran driver:
     ten increments re-use one factorisation and give the golden numbers of the elastic deck."""

@@ -286,3 +286,49 @@ def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, c
         assert np.abs(x - ref).max() <= 1e-5 * np.abs(ref).max()
         prob.destroy()
     assert np.abs(xs["1"] - xs["0"]).max() <= 1e-5 * np.abs(xs["0"]).max()
+
+
+def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkeypatch, capfd):
+    """A free-floating strip (no Dirichlet condition: three rigid-body modes) with a self-equilibrated load: the factorisation
+    meets pivots below 1e-6 of the largest entry and fixes those unknowns to zero (what MUMPS does under ICNTL(24) = 1,
+    src/main.F90:368).  The band LU by one wavefront, the column walk of one workgroup and the way through block cyclic
+    reduction (whose trial reduction must notice the small pivot and hand over to the band LU) give the same field, and it
+    satisfies the equations it did not drop."""
+    import scipy.sparse as sp
+    m = structured_quad(120, 2, jitter=0.1)
+    m.bcnode = np.zeros((0, 3), dtype=np.int32); m.bcval = np.zeros((0, 2))
+    # two opposite forces along x on the two ends (in equilibrium: no net force, no net moment)
+    left = int(np.argmin(m.coords[:, 0] + 1e-3 * np.abs(m.coords[:, 1] - 1.0)))
+    right = int(np.argmax(m.coords[:, 0] - 1e-3 * np.abs(m.coords[:, 1] - 1.0)))
+    m.fnode = np.array([left, right], dtype=np.int32)
+    m.fval = np.array([[-1e6, 0.0, 0.0, m.t], [1e6, 0.0, 0.0, m.t]])
+    monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    xs = {}
+    for name, env in (("wave", {"FEM_AMD_LU_WAVE": "1", "FEM_AMD_LU_BCR": "0"}), ("walk", {"FEM_AMD_LU_WAVE": "0", "FEM_AMD_LU_BCR": "0"}),
+                      ("bcr", {"FEM_AMD_LU_WAVE": "1", "FEM_AMD_LU_BCR": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        prob = driver.Problem(gpu_ctx, m, LU)
+        prob.assemble()
+        rp, ci, v = prob.K.get_csr()
+        r0 = m.ndof // 2
+        cols = ci[rp[r0]:rp[r0 + 1]]
+        prob.K.set_values([r0], [int(cols[cols != r0][0])], [1e-3 * np.abs(v).max()], "add")     # (flags the Mat unsymmetric: LU, not Cholesky)
+        rp, ci, v = prob.K.get_csr()
+        prob.ksp.set_operators(prob.K); prob.ksp.set_up()
+        prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+        b = prob.F.get_array()
+        prob.ksp.solve(prob.F, prob.U)
+        xs[name] = prob.U.get_array()
+        log = capfd.readouterr().err
+        if name == "bcr":
+            assert "a small pivot on the way: band LU" in log, log
+        A = sp.csr_matrix((v, ci, rp))
+        res = np.abs(A @ xs[name] - b)
+        # all equations but those of the (at most three, plus the perturbed row's neighbourhood) dropped unknowns hold
+        assert np.sort(res)[:-6].max() <= 1e-6 * np.abs(b).max(), np.sort(res)[-8:]
+        assert np.isfinite(xs[name]).all()
+        prob.destroy()
+    scale = np.abs(xs["walk"]).max()
+    assert np.abs(xs["wave"] - xs["walk"]).max() <= 1e-6 * scale
+    assert np.abs(xs["bcr"] - xs["walk"]).max() <= 1e-6 * scale

@@ -1069,81 +1069,98 @@ void BandLU::setup(fem_mat A_)
     fem_ctx ctx = A->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
-    std::vector<int> hc((size_t)A->padded_blocks);
-    A->bcol.download(hc.data(), hc.size(), s);
-    FEM_HIP(hipStreamSynchronize(s));
-    std::vector<int> ptr(nn + 1, 0), adj;
-    for (int v = 0; v < nn; v++) ptr[v + 1] = ptr[v] + A->h_rowlen[v];
-    adj.resize((size_t)ptr[nn]);
-    for (int v = 0; v < nn; v++) {
-        const size_t o0 = (size_t)A->h_boff[v >> 6];
-        for (int j = 0; j < A->h_rowlen[v]; j++) adj[(size_t)ptr[v] + j] = hc[(o0 + j) * 64 + (v & 63)];
-    }
-    // independent blocks?  connected components of the node graph (the pattern is symmetric), small ones only
-    batched = false;
-    {
-        const bool comp_env = !(std::getenv("FEM_AMD_LU_COMPONENTS") && std::atoi(std::getenv("FEM_AMD_LU_COMPONENTS")) == 0);   // (read at every set-up: the tests switch it)
-        std::vector<int> comp((size_t)nn, -1), stack, cptr{0}, cnodes;
-        int nc = 0, biggest = 0;
-        for (int v0_ = 0; v0_ < nn && comp_env; v0_++) {
-            if (comp[(size_t)v0_] >= 0) continue;
-            const size_t first = cnodes.size();
-            stack.assign(1, v0_); comp[(size_t)v0_] = nc;
-            while (!stack.empty()) {
-                const int v = stack.back(); stack.pop_back();
-                cnodes.push_back(v);
-                for (int e = ptr[v]; e < ptr[v + 1]; e++) {
-                    const int u = adj[(size_t)e];
-                    if (comp[(size_t)u] < 0) { comp[(size_t)u] = nc; stack.push_back(u); }
+    const bool comp_env = !(std::getenv("FEM_AMD_LU_COMPONENTS") && std::atoi(std::getenv("FEM_AMD_LU_COMPONENTS")) == 0);   // (read at every set-up: the tests switch it)
+    // the host-side symbolic work depends on the sparsity alone: done once per pattern (a Newton loop comes here at every iteration)
+    if (!A->pat->lu_sym || A->pat->lu_sym->comp_env != comp_env) {
+        auto sym = std::make_shared<LuSymbolic>();
+        sym->comp_env = comp_env;
+        std::vector<int> hc((size_t)A->padded_blocks);
+        A->bcol.download(hc.data(), hc.size(), s);
+        FEM_HIP(hipStreamSynchronize(s));
+        std::vector<int> ptr(nn + 1, 0), adj;
+        for (int v = 0; v < nn; v++) ptr[v + 1] = ptr[v] + A->h_rowlen[v];
+        adj.resize((size_t)ptr[nn]);
+        for (int v = 0; v < nn; v++) {
+            const size_t o0 = (size_t)A->h_boff[v >> 6];
+            for (int j = 0; j < A->h_rowlen[v]; j++) adj[(size_t)ptr[v] + j] = hc[(o0 + j) * 64 + (v & 63)];
+        }
+        // independent blocks?  connected components of the node graph (the pattern is symmetric), small ones only
+        {
+            std::vector<int> comp((size_t)nn, -1), stack, cptr{0}, cnodes;
+            int nc = 0, biggest = 0;
+            for (int v0_ = 0; v0_ < nn && comp_env; v0_++) {
+                if (comp[(size_t)v0_] >= 0) continue;
+                const size_t first = cnodes.size();
+                stack.assign(1, v0_); comp[(size_t)v0_] = nc;
+                while (!stack.empty()) {
+                    const int v = stack.back(); stack.pop_back();
+                    cnodes.push_back(v);
+                    for (int e = ptr[v]; e < ptr[v + 1]; e++) {
+                        const int u = adj[(size_t)e];
+                        if (comp[(size_t)u] < 0) { comp[(size_t)u] = nc; stack.push_back(u); }
+                    }
                 }
+                std::sort(cnodes.begin() + (long)first, cnodes.end());
+                biggest = std::max(biggest, (int)(cnodes.size() - first));
+                cptr.push_back((int)cnodes.size());
+                nc++;
             }
-            std::sort(cnodes.begin() + (long)first, cnodes.end());
-            biggest = std::max(biggest, (int)(cnodes.size() - first));
-            cptr.push_back((int)cnodes.size());
-            nc++;
-        }
-        if (comp_env && nc >= 1 && biggest * bs <= COMP_MAX) {   // (also a single small deck: the same arithmetic as its tilings)
-            batched = true;
-            ncomp = nc;
-            std::vector<int> loc((size_t)nn);
-            std::vector<long long> foff((size_t)nc + 1, 0);
-            for (int c = 0; c < nc; c++) {
-                for (int k = cptr[c]; k < cptr[c + 1]; k++) loc[(size_t)cnodes[(size_t)k]] = k - cptr[c];
-                const long long mm = (long long)(cptr[c + 1] - cptr[c]) * bs;
-                foff[(size_t)c + 1] = foff[(size_t)c] + mm * mm;
+            if (comp_env && nc >= 1 && biggest * bs <= COMP_MAX) {   // (also a single small deck: the same arithmetic as its tilings)
+                sym->batched = true;
+                sym->nc = nc;
+                sym->loc.resize((size_t)nn);
+                sym->foff.assign((size_t)nc + 1, 0);
+                for (int c = 0; c < nc; c++) {
+                    for (int k = cptr[c]; k < cptr[c + 1]; k++) sym->loc[(size_t)cnodes[(size_t)k]] = k - cptr[c];
+                    const long long mm = (long long)(cptr[c + 1] - cptr[c]) * bs;
+                    sym->foff[(size_t)c + 1] = sym->foff[(size_t)c] + mm * mm;
+                }
+                sym->cptr = std::move(cptr); sym->cnodes = std::move(cnodes);
             }
-            comp_ptr.alloc(cptr.size()); comp_ptr.upload(cptr.data(), cptr.size(), s);
-            comp_nodes.alloc(cnodes.size()); comp_nodes.upload(cnodes.data(), cnodes.size(), s);
-            node_loc.alloc(loc.size()); node_loc.upload(loc.data(), loc.size(), s);
-            fac_off.alloc(foff.size()); fac_off.upload(foff.data(), foff.size(), s);
-            fac.alloc((size_t)std::max<long long>(foff[(size_t)nc], 1));
-            ipiv.alloc((size_t)n); flag.alloc(2); flag.zero(s);
-            DBuf<unsigned long long> amax(1);
-            amax.zero(s);
-            hipLaunchKernelGGL(k_val_amax, dim3(std::min<unsigned>(cdiv(A->val.n, 256), 1024)), dim3(256), 0, s, A->val.n, A->values(), amax.p);
-            if (bs == 3)
-                hipLaunchKernelGGL(k_comp_lu<3>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
-                                   A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
-            else
-                hipLaunchKernelGGL(k_comp_lu<2>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
-                                   A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
-            FEM_HIP(hipGetLastError());
-            int hflag[2] = {0, 0};
-            flag.download(hflag, 2, s);
-            FEM_HIP(hipStreamSynchronize(s));
-            null_pivots = hflag[0];
-            failed = hflag[1] != 0;
-            return;
         }
+        if (!sym->batched) {
+            sym->perm = rcm_order(nn, ptr, adj);
+            long long bwn = 0, bw_nat = 0;
+            for (int v = 0; v < nn; v++)
+                for (int e = ptr[v]; e < ptr[v + 1]; e++) {
+                    bwn = std::max(bwn, (long long)std::abs(sym->perm[v] - sym->perm[adj[e]]));
+                    bw_nat = std::max(bw_nat, (long long)std::abs(v - adj[e]));
+                }
+            if (bw_nat <= bwn) { for (int v = 0; v < nn; v++) sym->perm[v] = v; bwn = bw_nat; }
+            sym->bwn = bwn;
+        }
+        A->pat->lu_sym = sym;
     }
-    std::vector<int> perm = rcm_order(nn, ptr, adj);
-    long long bwn = 0, bw_nat = 0;
-    for (int v = 0; v < nn; v++)
-        for (int e = ptr[v]; e < ptr[v + 1]; e++) {
-            bwn = std::max(bwn, (long long)std::abs(perm[v] - perm[adj[e]]));
-            bw_nat = std::max(bw_nat, (long long)std::abs(v - adj[e]));
-        }
-    if (bw_nat <= bwn) { for (int v = 0; v < nn; v++) perm[v] = v; bwn = bw_nat; }
+    const LuSymbolic& sym = *A->pat->lu_sym;
+    batched = sym.batched;
+    if (batched) {
+        const int nc = sym.nc;
+        ncomp = nc;
+        comp_ptr.alloc(sym.cptr.size()); comp_ptr.upload(sym.cptr.data(), sym.cptr.size(), s);
+        comp_nodes.alloc(sym.cnodes.size()); comp_nodes.upload(sym.cnodes.data(), sym.cnodes.size(), s);
+        node_loc.alloc(sym.loc.size()); node_loc.upload(sym.loc.data(), sym.loc.size(), s);
+        fac_off.alloc(sym.foff.size()); fac_off.upload(sym.foff.data(), sym.foff.size(), s);
+        fac.alloc((size_t)std::max<long long>(sym.foff[(size_t)nc], 1));
+        ipiv.alloc((size_t)n); flag.alloc(2); flag.zero(s);
+        DBuf<unsigned long long> amax(1);
+        amax.zero(s);
+        hipLaunchKernelGGL(k_val_amax, dim3(std::min<unsigned>(cdiv(A->val.n, 256), 1024)), dim3(256), 0, s, A->val.n, A->values(), amax.p);
+        if (bs == 3)
+            hipLaunchKernelGGL(k_comp_lu<3>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
+                               A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
+        else
+            hipLaunchKernelGGL(k_comp_lu<2>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
+                               A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
+        FEM_HIP(hipGetLastError());
+        int hflag[2] = {0, 0};
+        flag.download(hflag, 2, s);
+        FEM_HIP(hipStreamSynchronize(s));
+        null_pivots = hflag[0];
+        failed = hflag[1] != 0;
+        return;
+    }
+    const std::vector<int>& perm = sym.perm;
+    const long long bwn = sym.bwn;
     kl = (int)std::min<long long>(bwn * bs + bs - 1, std::max<long long>(n - 1, 0));
     // narrow bands: one wavefront with the window of a step in registers (k_band_lu_wave; the half bandwidth is rounded up to the
     // next instantiated one, the extra diagonals are zeros); FEM_AMD_LU_WAVE=0: the column walk of one workgroup.  The two write the

@@ -69,6 +69,18 @@ struct fem_vec_s {
 namespace fem {
 
 struct EbeTilePlan;   // ebe_tile.hip
+// what the direct solve of an unsymmetric Mat (BandLU::setup, direct.hip) derives from the sparsity alone, on the host: the connected
+// components of the node graph (small independent blocks are factorised one wavefront each) or the reverse Cuthill-McKee numbering and
+// its bandwidth.  Kept on the pattern: a Newton loop sets the solver up again at every iteration, on the same sparsity.
+struct LuSymbolic {
+    bool comp_env = true;                     // FEM_AMD_LU_COMPONENTS at the time it was built
+    bool batched = false;
+    int nc = 0;
+    std::vector<int> cptr, cnodes, loc;
+    std::vector<long long> foff;
+    std::vector<int> perm;
+    long long bwn = 0;
+};
 
 // Everything about Mat_K that depends on the connectivity alone (the product of MatCreateAIJ's
 // preallocation, src/main.F90:153-156, and of the implicit pattern growth of MatSetValues): built once
@@ -101,6 +113,7 @@ struct MatPattern {
     };
     std::vector<EbePlan> ebe_plan;     // per group
     std::shared_ptr<EbeTilePlan> ebe_tile;   // one-pass product by tiles (ebe_tile.hip); null: not built or not applicable
+    std::shared_ptr<LuSymbolic> lu_sym;      // BandLU's host-side symbolic work (direct.hip); null: not built yet
     bool ebe_tile_tried = false;
     DBuf<int> ebe_ptr;
     DBuf<unsigned> ebe_lst;

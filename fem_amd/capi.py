@@ -119,6 +119,9 @@ _SIGS = {
     "fem_snes_get_ksp": [_h, C.POINTER(_h)],
     "fem_snes_set_function": [_h, _h, C.c_void_p, C.c_void_p],
     "fem_snes_set_jacobian": [_h, _h, _h, C.c_void_p, C.c_void_p],
+    "fem_snes_set_defmod_callbacks": [_h, _h, _h, _h, _h, _h, _h, _h, C.c_int, _ip, _dp, C.c_double, C.c_double, C.c_int, _ip, C.POINTER(C.c_void_p)],
+    "fem_snes_calc_defmod_jacobian": [C.c_void_p, _h],
+    "fem_snes_free_defmod_callbacks": [C.c_void_p],
     "fem_snes_set_from_options": [_h, C.c_char_p],
     "fem_snes_solve": [_h, _h],
     "fem_snes_get_iteration_number": [_h, _ip],
@@ -745,6 +748,21 @@ class SNES:
         self._keep.append(cb)
         _ck(_lib.fem_snes_set_jacobian(self.h, J.h, J.h, C.cast(cb, C.c_void_p), None))
 
+    def set_defmod_callbacks(self, dmesh, K: Mat, J: Mat, R: Vec, F: Vec, agg: Vec, work: Vec, dt: float, rels_mode: int = 0, rels_nodes=None):
+        """The reference's CalcJacobian / CalcResidual as the library's own callbacks (fem_snes_set_defmod_callbacks): the same
+        primitives as driver.NonlinearProblem's hand-written pair, without the interpreter between them."""
+        m = dmesh.mesh
+        bn, bv = _i32(m.bcnode), _f64(m.bcval)
+        rn = _i32(rels_nodes) if rels_nodes is not None else None
+        st = C.c_void_p(0)
+        _ck(_lib.fem_snes_set_defmod_callbacks(self.h, dmesh.h, K.h, J.h, R.h, F.h, agg.h, work.h, bn.shape[0], _i(bn), _d(bv), float(dt),
+                                               float(m.t), int(rels_mode), _i(rn) if rn is not None else None, C.byref(st)))
+        self._defmod = st
+
+    def calc_defmod_jacobian(self, du: Vec):
+        """CalcJacobian(Solver, Vec_U, Jacobian, Jacobian) in front of SNESSolve (src/main.F90:241)."""
+        _ck(_lib.fem_snes_calc_defmod_jacobian(self._defmod, du.h))
+
     def set_from_options(self, options: str):
         _ck(_lib.fem_snes_set_from_options(self.h, options.encode()))
 
@@ -781,3 +799,6 @@ class SNES:
         if self.h:
             _ck(_lib.fem_snes_destroy(self.h))
             self.h = _h()
+            if getattr(self, "_defmod", None):
+                _ck(_lib.fem_snes_free_defmod_callbacks(self._defmod))
+                self._defmod = None

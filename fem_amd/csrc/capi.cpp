@@ -822,6 +822,71 @@ int fem_snes_set_jacobian(fem_snes sn, fem_mat J, fem_mat P, fem_snes_jacobian_c
     snes_set_jacobian(sn, J, P, j, c);
     FEM_CATCH
 }
+// The reference's two SNES callbacks as the library's own (src/m_global.F90:98-158 CalcJacobian, :161-235 CalcResidual): the same
+// sequence of primitives a host writes by hand (fem_amd/driver.py keeps that hand-written form as well), issued
+// from here -- for a host that does not want a round trip through its own language between two device calls (a Python host pays
+// about 0.1 ms per call: a third of config 5's time once the inner solve takes 0.3 ms).
+struct fem_defmod_callbacks_s {
+    fem_mesh mesh; fem_mat K, J; fem_vec F, agg, utot;
+    std::vector<int> bcnode; std::vector<double> bcval;
+    int nbcs; double dt, t; int rels_mode; int rels_nodes[4]; bool have_nodes;
+};
+static int defmod_calc_jacobian(fem_snes, fem_vec du, fem_mat J, fem_mat, void* c)
+{
+    auto* d = static_cast<fem_defmod_callbacks_s*>(c);
+    int rc;
+    if ((rc = fem_mat_copy(d->K, J))) return rc;                                                     /* MatCopy(Mat_K, Jacobian) :123 */
+    if ((rc = fem_vec_copy(du, d->utot))) return rc;
+    if ((rc = fem_vec_axpy(d->utot, 1.0, d->agg))) return rc;                                        /* uu = uu + aggregate_u :127 */
+    if ((rc = fem_mat_add_cohesive(J, d->utot, d->dt, d->rels_mode, d->have_nodes ? d->rels_nodes : nullptr))) return rc;   /* :129-147 */
+    return fem_mat_apply_kbc(J, d->nbcs, d->bcnode.data());                                          /* ApplyKBC(Jacobian) :153 */
+}
+static int defmod_calc_residual(fem_snes, fem_vec du, fem_vec R, void* c)
+{
+    auto* d = static_cast<fem_defmod_callbacks_s*>(c);
+    int rc;
+    if ((rc = fem_vec_copy(du, d->utot))) return rc;
+    if ((rc = fem_vec_axpy(d->utot, 1.0, d->agg))) return rc;                                        /* current_u = current_u + aggregate_u :182 */
+    if ((rc = fem_vec_copy(d->F, R))) return rc;                                                     /* VecCopy(Vec_F, Residual) :184 */
+    if ((rc = fem_vec_add_cohesive_traction(d->mesh, d->utot, d->dt, d->rels_mode, d->have_nodes ? d->rels_nodes : nullptr, R))) return rc;   /* :186-205 */
+    if ((rc = fem_enforce_bc_force(d->mesh, d->nbcs, d->bcnode.data(), d->bcval.data(), d->dt, d->t, R))) return rc;   /* :210 */
+    if ((rc = fem_vec_scale(R, -1.0))) return rc;                                                    /* VecScale(Residual, MINUS) :223 */
+    return fem_mat_mult_add(d->J, du, R, R);                                                         /* MatMultAdd(Jacobian, du, Residual, Residual) :224 */
+}
+int fem_snes_set_defmod_callbacks(fem_snes sn, fem_mesh mesh, fem_mat K, fem_mat J, fem_vec R, fem_vec F, fem_vec aggregate_u, fem_vec work,
+                                  int nbcs, const int* bcnode, const double* bcval, double dt, double t_total, int rels_mode,
+                                  const int* rels_nodes, void** state)
+{
+    FEM_TRY
+    FEM_CHECK(sn && mesh && K && J && R && F && aggregate_u && work && state, 1, "fem_snes_set_defmod_callbacks: null argument");
+    FEM_CHECK(nbcs >= 0 && (nbcs == 0 || (bcnode && bcval)), 2, "fem_snes_set_defmod_callbacks: bad boundary-condition list");
+    auto* d = new fem_defmod_callbacks_s;
+    d->mesh = mesh; d->K = K; d->J = J; d->F = F; d->agg = aggregate_u; d->utot = work;
+    d->nbcs = nbcs;
+    d->bcnode.assign(bcnode, bcnode + (size_t)nbcs * (1 + mesh->pdim));
+    d->bcval.assign(bcval, bcval + (size_t)nbcs * mesh->pdim);
+    d->dt = dt; d->t = t_total; d->rels_mode = rels_mode; d->have_nodes = rels_nodes != nullptr;
+    for (int i = 0; i < 4; i++) d->rels_nodes[i] = rels_nodes ? rels_nodes[i] : i;
+    snes_set_function(sn, R, defmod_calc_residual, d);
+    snes_set_jacobian(sn, J, J, defmod_calc_jacobian, d);
+    *state = d;
+    FEM_CATCH
+}
+int fem_snes_calc_defmod_jacobian(void* state, fem_vec du)
+{
+    FEM_TRY
+    FEM_CHECK(state && du, 1, "null argument");
+    auto* d = static_cast<fem_defmod_callbacks_s*>(state);
+    const int rc = defmod_calc_jacobian(nullptr, du, d->J, d->J, d);
+    if (rc) return rc;
+    FEM_CATCH
+}
+int fem_snes_free_defmod_callbacks(void* state)
+{
+    FEM_TRY
+    delete static_cast<fem_defmod_callbacks_s*>(state);
+    FEM_CATCH
+}
 int fem_snes_set_from_options(fem_snes sn, const char* options)
 {
     FEM_TRY

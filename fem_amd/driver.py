@@ -72,8 +72,9 @@ class NonlinearProblem(Problem):
     """The reference's state for a deck with cohesive elements: Mat_K, its duplicate Jacobian, Residual, the SNES with
     its two callbacks (src/main.F90:197-206) and the running total aggregate_u the callbacks add to the iterate."""
 
-    def __init__(self, ctx: capi.Context, mesh: Mesh, options: str = "", rels_mode: int = 0, rels_nodes=None):
+    def __init__(self, ctx: capi.Context, mesh: Mesh, options: str = "", rels_mode: int = 0, rels_nodes=None, builtin_callbacks: bool = False):
         super().__init__(ctx, mesh, "")
+        self.builtin_callbacks = builtin_callbacks
         self.rels_mode, self.rels_nodes = rels_mode, rels_nodes
         self.dmesh.set_cohesive()                          # before MatCreateAIJ: the sparsity holds the cohesive pairs
         self.create_matrix()
@@ -86,8 +87,12 @@ class NonlinearProblem(Problem):
         self.snes_ksp = self.snes.get_ksp()                # SNESGetKSP + SetupKSPSolver :201-202
         self.snes_ksp.set_type("preonly"); self.snes_ksp.set_pc_type("lu")          # KSPPREONLY + PCLU (MUMPS), :355-358
         self.snes_ksp.set_tolerances(rtol=capi.REFERENCE_RTOL)                       # :349-351
-        self.snes.set_function(self.R, self.calc_residual)                           # :204
-        self.snes.set_jacobian(self.J, self.calc_jacobian)                           # :205
+        if builtin_callbacks:
+            # the same two callbacks, issued by the library itself (fem_snes_set_defmod_callbacks): no interpreter between the primitives
+            self.snes.set_defmod_callbacks(self.dmesh, self.K, self.J, self.R, self.F, self.agg, self.utot, mesh.dt, rels_mode, rels_nodes)
+        else:
+            self.snes.set_function(self.R, self.calc_residual)                       # :204
+            self.snes.set_jacobian(self.J, self.calc_jacobian)                       # :205
         if options:
             self.snes.set_from_options(options)                                      # SNESSetFromOptions :206
 
@@ -115,11 +120,11 @@ class NonlinearProblem(Problem):
 
 
 def run_nonlinear(mesh: Mesh, options: str = "", ctx: capi.Context | None = None, rels_mode: int = 0, rels_nodes=None,
-                  recover_stress: bool = True) -> RunResult:
+                  recover_stress: bool = True, builtin_callbacks: bool = False) -> RunResult:
     """The increment loop of src/main.F90:216-296 on a deck with cohesive elements (the `ncohmats /= 0` branch)."""
     own = ctx is None
     ctx = ctx or capi.Context(0)
-    prob = NonlinearProblem(ctx, mesh, options, rels_mode, rels_nodes)
+    prob = NonlinearProblem(ctx, mesh, options, rels_mode, rels_nodes, builtin_callbacks)
     res = RunResult(np.zeros(mesh.ndof), np.zeros((mesh.nnds, mesh.cpdim)))
     res.snes_its, res.snes_reasons, res.fnorms, res.U_hist = [], [], [], []
     step = 0
@@ -129,7 +134,10 @@ def run_nonlinear(mesh: Mesh, options: str = "", ctx: capi.Context | None = None
             break
         ta = time.perf_counter()
         prob.dmesh.form_rhs(prob.F, t_init, mesh.dt)       # FormRHS :236
-        prob.calc_jacobian(prob.U, prob.J)                 # CalcJacobian(.., Vec_U, Jacobian, Jacobian) :241
+        if builtin_callbacks:
+            prob.snes.calc_defmod_jacobian(prob.U)
+        else:
+            prob.calc_jacobian(prob.U, prob.J)             # CalcJacobian(.., Vec_U, Jacobian, Jacobian) :241
         prob.snes.solve(prob.U)                            # SNESSolve :242 (Vec_U keeps the previous increment)
         ctx.synchronize()
         res.t_solve += time.perf_counter() - ta

@@ -609,6 +609,28 @@ module fem_amd_capi
       type(c_funptr), value :: jf
       integer(c_int) :: ierr
     end function
+    function fem_snes_set_defmod_callbacks(snes, mesh, K, J, R, F, aggregate_u, work, nbcs, bcnode, bcval, dt, t_total, &
+                                           rels_mode, rels_nodes, state) bind(C, name="fem_snes_set_defmod_callbacks") result(ierr)
+      import :: c_int, c_ptr, c_double
+      type(c_ptr), value :: snes, mesh, K, J, R, F, aggregate_u, work
+      integer(c_int), value :: nbcs, rels_mode
+      integer(c_int), intent(in) :: bcnode(*)
+      real(c_double), intent(in) :: bcval(*)
+      real(c_double), value :: dt, t_total
+      type(c_ptr), value :: rels_nodes          ! c_loc of four 0-based node ids, or c_null_ptr
+      type(c_ptr), intent(out) :: state
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_calc_defmod_jacobian(state, du) bind(C, name="fem_snes_calc_defmod_jacobian") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: state, du
+      integer(c_int) :: ierr
+    end function
+    function fem_snes_free_defmod_callbacks(state) bind(C, name="fem_snes_free_defmod_callbacks") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: state
+      integer(c_int) :: ierr
+    end function
     function fem_snes_set_from_options(snes, options) bind(C, name="fem_snes_set_from_options") result(ierr)
       import :: c_int, c_ptr, c_char
       type(c_ptr), value :: snes

@@ -304,6 +304,17 @@ int fem_snes_destroy(fem_snes snes);
 int fem_snes_get_ksp(fem_snes snes, fem_ksp *ksp);                                  /* SNESGetKSP :201 (owned by snes) */
 int fem_snes_set_function(fem_snes snes, fem_vec r, fem_snes_function_cb f, void *ctx);             /* :204 */
 int fem_snes_set_jacobian(fem_snes snes, fem_mat J, fem_mat P, fem_snes_jacobian_cb j, void *ctx);  /* :205 */
+/* The reference's own two callbacks (CalcJacobian src/m_global.F90:98-158, CalcResidual :161-235) installed as the library's:
+ * the sequence of primitives above, issued without a round trip through the host's language.  K = Mat_K with ApplyKBC, J = its
+ * duplicate (Jacobian), R = Residual, F = Vec_F of the increment (the host refreshes it with fem_form_rhs), aggregate_u = the
+ * running total the host keeps, work = a scratch Vec; bcnode / bcval as for fem_enforce_bc_force; rels_mode / rels_nodes as for
+ * fem_mat_add_cohesive.  *state is freed with fem_snes_free_defmod_callbacks after fem_snes_destroy;
+ * fem_snes_calc_defmod_jacobian(state, Vec_U) is the CalcJacobian call of src/main.F90:241 in front of SNESSolve. */
+int fem_snes_set_defmod_callbacks(fem_snes snes, fem_mesh mesh, fem_mat K, fem_mat J, fem_vec R, fem_vec F, fem_vec aggregate_u,
+                                  fem_vec work, int nbcs, const int *bcnode, const double *bcval, double dt, double t_total,
+                                  int rels_mode, const int *rels_nodes, void **state);
+int fem_snes_calc_defmod_jacobian(void *state, fem_vec du);
+int fem_snes_free_defmod_callbacks(void *state);
 /* SNESSetFromOptions :206: -snes_rtol -snes_atol -snes_stol -snes_max_it -snes_max_funcs -snes_linesearch_type bt|basic
  * -snes_linesearch_alpha|maxstep|minlambda|max_it; any other option goes to the KSP (KSPSetFromOptions). */
 int fem_snes_set_from_options(fem_snes snes, const char *options);

@@ -178,3 +178,20 @@ def test_config5_connected_strip(gpu_ctx, oracle, rels_mode):
     X.destroy(); prob.destroy()
     big = driver.run_nonlinear(tile_deck_connected(m1, 1000), "", ctx=gpu_ctx, rels_mode=rels_mode, recover_stress=False)
     assert big.snes_reasons[0] == 3 and np.isfinite(big.aggregate_u).all()
+
+
+@pytest.mark.parametrize("rels", [(0, None), (0, (1, 2, 4, 5)), (1, None)])
+def test_builtin_callbacks_are_the_hand_written_ones(gpu_ctx, rels):
+    """fem_snes_set_defmod_callbacks installs the reference's CalcJacobian / CalcResidual as the library's own callbacks: the same
+    primitives in the same order as the hand-written pair of driver.NonlinearProblem -- the same bits, increment by increment, on
+    the reference deck, on two_quads_qs.inp (shared cohesive nodes) and on a connected strip."""
+    from fem_amd.mesh import tile_deck_connected
+    mode, nodes = rels
+    m1 = read_inp(DECK)
+    decks = [m1, read_inp(os.path.join(HERE, "golden", "decks", "two_quads_qs.inp")), tile_deck_connected(m1, 40)]
+    for m in decks:
+        a = driver.run_nonlinear(m, "", ctx=gpu_ctx, rels_mode=mode, rels_nodes=nodes)
+        b = driver.run_nonlinear(m, "", ctx=gpu_ctx, rels_mode=mode, rels_nodes=nodes, builtin_callbacks=True)
+        assert list(a.snes_its) == list(b.snes_its) and list(a.snes_reasons) == list(b.snes_reasons)
+        assert len(a.U_hist) == len(b.U_hist) and all(np.array_equal(x, y) for x, y in zip(a.U_hist, b.U_hist))
+        assert np.array_equal(a.aggregate_u, b.aggregate_u) and np.array_equal(a.aggregate_stress, b.aggregate_stress)

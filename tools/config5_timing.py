@@ -31,12 +31,20 @@ for opts in ("-ksp_type preonly -pc_type lu", "-ksp_type bcgs -pc_type jacobi -k
 mc = tile_deck_connected(m1, copies)
 print(f"config 5, connected strip: {mc.nels} elements, {mc.nnds} nodes, {mc.ndof} dofs")
 for opts in ("-ksp_type preonly -pc_type lu",):
-    for rep in range(2):
-        t0 = time.perf_counter()
-        r = driver.run_nonlinear(mc, opts, ctx=ctx, rels_mode=1, recover_stress=True)
-        dt = time.perf_counter() - t0
-    print(f"  [{opts}, rels_mode 1] {dt * 1e3:.1f} ms for {len(r.snes_its)} increments (second run); SNES iterations {list(r.snes_its)}, "
-          f"reasons {list(r.snes_reasons)}, linear iterations {list(r.its)}")
+    for builtin in (False, True):
+        for rep in range(3):
+            t0 = time.perf_counter()
+            r = driver.run_nonlinear(mc, opts, ctx=ctx, rels_mode=1, recover_stress=True, builtin_callbacks=builtin)
+            dt = time.perf_counter() - t0
+        print(f"  [{opts}, rels_mode 1, callbacks {'issued by the library (fem_snes_set_defmod_callbacks)' if builtin else 'in the host language (Python)'}] "
+              f"{dt * 1e3:.1f} ms for {len(r.snes_its)} increments (third run); SNES iterations {list(r.snes_its)}, "
+              f"reasons {list(r.snes_reasons)}, linear iterations {list(r.its)}")
+# ... and the disjoint copies with the library's callbacks
+for rep in range(3):
+    t0 = time.perf_counter()
+    r = driver.run_nonlinear(m, "-ksp_type preonly -pc_type lu", ctx=ctx, recover_stress=True, builtin_callbacks=True)
+    dt = time.perf_counter() - t0
+print(f"config 5, disjoint copies, callbacks issued by the library: {dt * 1e3:.1f} ms for {len(r.snes_its)} increments; SNES iterations {list(r.snes_its)}")
 try:
     from oracle.oracle import Oracle
     o = Oracle()

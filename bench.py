@@ -66,6 +66,18 @@ def spmv_algorithmic_bytes(nnz: int, nrows: int) -> float:
     return nnz * 12.0 + (nrows + 1) * 4.0 + nrows * 16.0
 
 
+def same_problem_on_one_gpu(value: float) -> dict:
+    """The >= 6x target read the other way (N = 8 line only): the SAME global problem (config 4's 298^3 cube, 80.2 M DOF) solved by
+    one GPU that holds all of it (288 GB of HBM3E), measured in round 3 (profiles/r03_c4_on_one_gpu.txt, rtol 1e-9,
+    -mat_mult_type ebe)."""
+    return {"source": "profiles/r03_c4_on_one_gpu.txt (one MI355X holding the whole 298^3 problem; builder-run, round 3)",
+            "cg_jacobi": {"value": 25.94e6, "unit": "DOF/s", "cg_iterations": 1413},
+            "pc_mg": {"value": 116.0e6, "unit": "DOF/s", "cg_iterations": 79},
+            "speedup_cg_jacobi": value / 25.94e6,
+            "note": "strong-scaling reading of the N = 8 line: value / same_problem_on_one_gpu.cg_jacobi.value (ideal 8); the "
+                    "weak-scaling reading value / value(N=1) is capped at cg_jacobi_weak_scaling_ceiling by the iteration count"}
+
+
 def host_cores() -> dict:
     """Physical cores this process may use: distinct (socket, core) pairs among the CPUs of its affinity mask (as
     it was when the process started), capped by the cgroup CPU quota when there is one (the GPU boxes of this pool
@@ -706,15 +718,7 @@ def main():
             p2.destroy()
 
     if rank == 0 and world == 8 and args.n == 149 and args.jitter == 0.0 and hex_case:
-        # the >= 6x target read the other way: the SAME global problem (config 4's 298^3 cube, 80.2 M DOF) solved by one GPU that
-        # holds all of it (288 GB of HBM3E), measured in round 3 (profiles/r03_c4_on_one_gpu.txt, rtol 1e-9, -mat_mult_type ebe)
-        out["config"]["same_problem_on_one_gpu"] = {
-            "source": "profiles/r03_c4_on_one_gpu.txt (one MI355X holding the whole 298^3 problem; builder-run, round 3)",
-            "cg_jacobi": {"value": 25.94e6, "unit": "DOF/s", "cg_iterations": 1413},
-            "pc_mg": {"value": 116.0e6, "unit": "DOF/s", "cg_iterations": 79},
-            "speedup_cg_jacobi": value / 25.94e6,
-            "note": "strong-scaling reading of the N = 8 line: value / same_problem_on_one_gpu.cg_jacobi.value (ideal 8); the "
-                    "weak-scaling reading value / value(N=1) is capped at cg_jacobi_weak_scaling_ceiling by the iteration count"}
+        out["config"]["same_problem_on_one_gpu"] = same_problem_on_one_gpu(value)
 
     # second measurement: the same step with the box-aggregation multigrid preconditioner
     # behind the same KSP surface -- reported beside the CG/Jacobi headline as config.pc_mg.  At N>1 the

@@ -356,3 +356,20 @@ def test_connected_tiling_of_the_cohesive_deck_shares_its_edge_nodes():
     build(ref=False)
     r = Oracle().snes_run(tile_deck_connected(m1, 5), rels_mode=1)
     assert r["its"][0] == 1 and r["reasons"][0] == 3 and np.isfinite(r["u"]).all()
+
+
+def test_bench_helpers_that_only_an_eight_gpu_run_reaches():
+    """bench.py's N = 8 line carries `config.same_problem_on_one_gpu`; no run of this repository's own can reach that branch (the
+    rehearsals stop at four ranks: the box allows six processes on the card), so the helper is exercised here, with the line's
+    JSON serialisation."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    d = b.same_problem_on_one_gpu(1.0e8)
+    assert abs(d["speedup_cg_jacobi"] - 1.0e8 / 25.94e6) < 1e-12 and d["cg_jacobi"]["cg_iterations"] == 1413
+    json.dumps(d)
+    assert b.spmv_algorithmic_bytes(809238528, 10125000) == 809238528 * 12.0 + 10125001 * 4.0 + 10125000 * 16.0
+    hc = b.host_cores()
+    assert hc["use"] >= 1 and hc["logical"] >= hc["use"]

@@ -138,6 +138,7 @@ _SIGS = {
     "fem_comm_destroy": [_h],
     "fem_comm_rank": [_h, _ip, _ip],
     "fem_comm_exchange": [_h, C.c_int, _ip, C.POINTER(C.c_longlong), _h, _h],
+    "fem_comm_exchange_allreduce": [_h, C.c_int, _ip, C.POINTER(C.c_longlong), _h, _h, _h, C.c_int],
 }
 EXPORTED = sorted(_SIGS) + ["fem_last_error"]
 for _n, _a in _SIGS.items():
@@ -386,6 +387,12 @@ class Comm:
         nr = _i32(neigh_rank)
         o = np.ascontiguousarray(off, dtype=np.int64)
         _ck(_lib.fem_comm_exchange(self.h, len(nr), _i(nr), o.ctypes.data_as(C.POINTER(C.c_longlong)), send.h, recv.h))
+
+    def exchange_allreduce(self, neigh_rank, off, send: "Vec", recv: "Vec", red: "Vec", nred: int):
+        """exchange() together with the in-place sum of red[:nred] over all domains (one RCCL group on that back end)."""
+        nr = _i32(neigh_rank)
+        o = np.ascontiguousarray(off, dtype=np.int64)
+        _ck(_lib.fem_comm_exchange_allreduce(self.h, len(nr), _i(nr), o.ctypes.data_as(C.POINTER(C.c_longlong)), send.h, recv.h, red.h, int(nred)))
 
     def rank_size(self):
         r, s = C.c_int(0), C.c_int(0)

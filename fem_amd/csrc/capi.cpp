@@ -1037,4 +1037,27 @@ int fem_comm_exchange(fem_comm c, int nneigh, const int* neigh_rank, const long 
     FEM_CATCH
 }
 
+// the same with the sum of red[0 .. nred) over all domains in the same call (Comm::exchange_allreduce: on the RCCL back end the
+// all-reduce sits inside the group of the sends and receives -- what `-ksp_fuse_allreduce 1` issues once per CG iteration)
+int fem_comm_exchange_allreduce(fem_comm c, int nneigh, const int* neigh_rank, const long long* off, fem_vec send, fem_vec recv,
+                                fem_vec red, int nred)
+{
+    FEM_TRY
+    FEM_CHECK(c && c->impl && send && recv && red, 1, "fem_comm_exchange_allreduce: null handle");
+    FEM_CHECK(nneigh >= 0 && (nneigh == 0 || (neigh_rank && off)), 2, "fem_comm_exchange_allreduce: bad neighbour list");
+    FEM_CHECK(nred >= 1 && nred <= red->n, 8, "fem_comm_exchange_allreduce: bad reduction length");
+    std::vector<size_t> o((size_t)nneigh + 1, 0);
+    for (int i = 0; i <= nneigh && nneigh > 0; i++) {
+        FEM_CHECK(off[i] >= 0 && (i == 0 || off[i] >= off[i - 1]), 2, "fem_comm_exchange_allreduce: offsets must ascend");
+        o[i] = (size_t)off[i];
+    }
+    FEM_CHECK((long long)o[nneigh] <= send->n && (long long)o[nneigh] <= recv->n, 8, "fem_comm_exchange_allreduce: vectors too short");
+    for (int i = 0; i < nneigh; i++)
+        FEM_CHECK(neigh_rank[i] >= 0 && neigh_rank[i] < c->impl->size, 3, "fem_comm_exchange_allreduce: bad neighbour rank");
+    send->ctx->bind();
+    c->impl->exchange_allreduce(nneigh, neigh_rank, o.data(), send->d.p, recv->d.p, red->d.p, nred, send->ctx->stream);
+    FEM_HIP(hipStreamSynchronize(send->ctx->stream));
+    FEM_CATCH
+}
+
 }  // extern "C"

@@ -316,6 +316,15 @@ module fem_amd_capi
       integer(c_int), intent(out) :: rank, nranks
       integer(c_int) :: ierr
     end function
+    function fem_comm_exchange_allreduce(comm, nneigh, neigh_rank, off, send, recv, red, nred) &
+        bind(C, name="fem_comm_exchange_allreduce") result(ierr)
+      import :: c_int, c_ptr, c_long_long
+      type(c_ptr), value :: comm, send, recv, red
+      integer(c_int), value :: nneigh, nred
+      integer(c_int), intent(in) :: neigh_rank(*)
+      integer(c_long_long), intent(in) :: off(*)
+      integer(c_int) :: ierr
+    end function
     function fem_comm_exchange(comm, nneigh, neigh_rank, off, send, recv) bind(C, name="fem_comm_exchange") result(ierr)
       import :: c_int, c_ptr, c_long_long
       type(c_ptr), value :: comm, send, recv

@@ -369,6 +369,10 @@ int fem_comm_rank(fem_comm comm, int *rank, int *size);
  * same range of recv is filled from it; one grouped ncclSend/ncclRecv per call on the RCCL back end.
  * Blocking (returns when recv is complete). */
 int fem_comm_exchange(fem_comm comm, int nneigh, const int *neigh_rank, const long long *off, fem_vec send, fem_vec recv);
+/* The same together with the in-place sum of red[0 .. nred) over all domains (the CG's p.Kp all-reduce inside the RCCL group of the
+ * halo exchange that follows it, `-ksp_fuse_allreduce 1`: one RCCL launch per iteration less). */
+int fem_comm_exchange_allreduce(fem_comm comm, int nneigh, const int *neigh_rank, const long long *off, fem_vec send, fem_vec recv,
+                                fem_vec red, int nred);
 
 #ifdef __cplusplus
 }

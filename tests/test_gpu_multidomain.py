@@ -162,6 +162,39 @@ print("SENDRECV_OK")
     assert p.returncode == 0 and "SENDRECV_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
+def test_rccl_grouped_allreduce_and_send_recv_on_one_rank():
+    """RcclComm::exchange_allreduce -- ncclAllReduce inside the ncclGroup of the halo exchange's sends and receives, what
+    `-ksp_fuse_allreduce 1` issues once per CG iteration -- on real RCCL with the one rank (itself as the peer) a 1-GPU box has
+    (round-3 advice: the grouped call had only ever run through the in-process fallback, which does the two one after the other)."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sys
+sys.path.insert(0, %r)
+from fem_amd import capi
+ctx = capi.Context(0)
+comm = capi.Comm.rccl(ctx, 1, 0, capi.Comm.unique_id())
+n = 1000
+send, recv, red = capi.Vec(ctx, n), capi.Vec(ctx, n), capi.Vec(ctx, 4)
+x = np.arange(n, dtype=np.float64) * 0.25 - 3.0
+send.set_array(x); recv.set_array(np.zeros(n)); red.set_array(np.array([1.5, -2.0, 7.0, 9.0]))
+for rep in range(3):
+    comm.exchange_allreduce([0], [0, 600], send, recv, red, 2)
+got, r = recv.get_array(), red.get_array()
+assert np.array_equal(got[:600], x[:600]) and not got[600:].any(), got[:8]
+assert np.array_equal(r, [1.5, -2.0, 7.0, 9.0]), r            # one rank: the sum over all ranks is the value itself
+st = comm.stats()
+assert st["allreduce_calls"] == 3 and st["exchange_calls"] == 3 and st["exchange_max_doubles"] == 600
+comm.exchange_allreduce([], [0], send, recv, red, 4)            # a domain without neighbours still takes part in the reduction
+send.destroy(); recv.destroy(); red.destroy(); comm.destroy(); ctx.destroy()
+print("GROUPED_OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "GROUPED_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+
+
 def test_exchange_primitive_local_group():
     """The same primitive through the in-process communicator: three domains, everybody a neighbour of
     everybody; domain r must receive, in its segment for q, what q put into its segment for r."""

@@ -332,3 +332,34 @@ def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkey
     scale = np.abs(xs["walk"]).max()
     assert np.abs(xs["wave"] - xs["walk"]).max() <= 1e-6 * scale
     assert np.abs(xs["bcr"] - xs["walk"]).max() <= 1e-6 * scale
+
+
+def test_a_solve_that_fails_the_backward_error_test_goes_to_the_band_lu(gpu_ctx, monkeypatch, capfd):
+    """The safety net of block cyclic reduction: a solve whose componentwise backward error exceeds the bound is repeated by the band
+    LU (factorised then), and so is every later solve with that matrix.  The bound is set to 0 here (FEM_AMD_LU_BCR_TOL), so that
+    the first solve takes that way: same answer as with the band LU from the start, and a second right-hand side is solved too."""
+    m = structured_quad(300, 2, jitter=0.1)
+    monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    xs = {}
+    for name, env in (("fallback", {"FEM_AMD_LU_BCR": "1", "FEM_AMD_LU_BCR_TOL": "0"}), ("band", {"FEM_AMD_LU_BCR": "0", "FEM_AMD_LU_BCR_TOL": "1e-10"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        prob = driver.Problem(gpu_ctx, m, LU)
+        prob.assemble()
+        rp, ci, v = prob.K.get_csr()
+        r0 = m.ndof // 2
+        cols = ci[rp[r0]:rp[r0 + 1]]
+        prob.K.set_values([r0], [int(cols[cols != r0][0])], [1e-3 * np.abs(v[v < 1e29]).max()], "add")      # (unsymmetric: LU)
+        prob.ksp.set_operators(prob.K); prob.ksp.set_up()
+        prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+        prob.ksp.solve(prob.F, prob.U)
+        x1 = prob.U.get_array()
+        prob.F.set_array(np.cos(0.01 * np.arange(m.ndof)) * np.abs(prob.F.get_array()).max())
+        prob.ksp.solve(prob.F, prob.U)
+        xs[name] = (x1, prob.U.get_array())
+        log = capfd.readouterr().err
+        if name == "fallback":
+            assert "used" in log and log.count("backward error") == 1, log     # the second solve no longer tries the reduction
+        prob.destroy()
+    for a, b in zip(xs["fallback"], xs["band"]):
+        assert np.array_equal(a, b)

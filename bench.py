@@ -184,10 +184,12 @@ def main():
         raise SystemExit("--config 2 (the 1M-DOF plate) is a single-GPU configuration")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
-    if args.rehearse:
-        local_rank = local_rank % torch.cuda.device_count()      # (one GPU: everybody on device 0)
+    local_rank = local_rank % torch.cuda.device_count()          # (--rehearse on one GPU: everybody on device 0; a full node: the identity)
     torch.cuda.set_device(local_rank)
-    tdev = "cpu" if args.rehearse else "cuda"                     # where the tensors of torch's own collectives live (gloo: host)
+    # bench.py's own collectives (barriers, the MAX of the elapsed times, the per-rank table) are a handful of host scalars: they go
+    # over gloo at every N, so that the only RCCL communicator of the process is the library's (the data path: halo sums and the CG's
+    # scalars) and a failure of that one at its first contact with real peers can still be agreed upon and survived (comm_fallback below)
+    tdev = "cpu"
     use_comm = world > 1 or args.force_comm
     if args.force_comm:
         os.environ["FEM_AMD_FORCE_COLLECTIVES"] = "1"
@@ -197,10 +199,7 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
     if use_comm and "MASTER_ADDR" in os.environ:
-        if args.rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
 
     ctx = capi.Context(local_rank)
     grid = partition.brick_grid(world)
@@ -212,28 +211,74 @@ def main():
     else:
         mesh = structured_quad(args.n, jitter=args.jitter)
         label = f"{args.n}^2 quad4"
-    comm = halo = None
+    comm = halo = prob = None
+    comm_fallback = None
+    pc_opts = {"jacobi": "-pc_type jacobi", "mg": "-pc_type mg -pc_mg_type additive"}[args.pc]
+    popts = f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult}"
+    if use_comm:
+        halo = partition.brick_halo(rank, grid, npr)
+
+    def all_ranks_ok(ok: bool) -> bool:
+        if not dist.is_initialized():
+            return ok
+        tt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        return bool(tt.item() > 0.5)
+
     if use_comm and args.rehearse:
         comm = capi.Comm.gloo(ctx) if dist.is_initialized() else capi.Comm.self_(ctx)
-        halo = partition.brick_halo(rank, grid, npr)
         if dist.is_initialized():
             dist.barrier()
     elif use_comm:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+        # First contact of the library's RCCL communicator with real peers: creation, and one untimed step through every collective
+        # of the CG (grouped ncclSend / ncclRecv halo sums, the scalar all-reduces).  Whatever raises here is agreed upon over gloo and
+        # the job continues on the host-staged communicator (fem_comm_create_callbacks over gloo: the path --rehearse and the
+        # multi-process tests run), with the failure in the line (config.comm_fallback) -- a slower number instead of none.  A
+        # collective that never returns cannot be caught: the watchdog below ends the job (exit status 4).
+        first_contact = threading.Event()
+
+        def contact_watchdog():
+            if not first_contact.wait(float(os.environ.get("FEM_AMD_BENCH_CONTACT_TIMEOUT", "420"))):
+                print(f"bench.py rank {rank}: the first step over RCCL did not return; giving up", file=sys.stderr, flush=True)
+                os._exit(4)
+        threading.Thread(target=contact_watchdog, daemon=True).start()
+        err = None
+        try:
+            if os.environ.get("FEM_AMD_BENCH_INJECT_RCCL_FAILURE"):      # (every rank: a rank that fails alone leaves its peers inside ncclCommInitRank)
+                raise RuntimeError("injected failure of the RCCL communicator (test hook)")
+            uid = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0:
+                uid.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+            if dist.is_initialized():
+                dist.broadcast(uid, 0)
+            comm = capi.Comm.rccl(ctx, world, rank, bytes(uid.numpy().tobytes()))
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)[:300]
+        if all_ranks_ok(err is None):
+            try:
+                prob = driver.Problem(ctx, mesh, popts, comm=comm, halo=halo)
+                prob.assemble(); prob.ksp.set_up()
+                prob.dmesh.form_rhs(prob.F, 0.0, mesh.dt)
+                prob.ksp.solve(prob.F, prob.U)
+                ctx.synchronize()
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)[:300]
+        if not all_ranks_ok(err is None):
+            comm_fallback = {"to": "host-staged communicator over gloo (fem_comm_create_callbacks)",
+                             "why": err or "another rank's RCCL communicator failed"}
+            print(f"bench.py rank {rank}: RCCL path failed ({comm_fallback['why']}); continuing over the host-staged communicator",
+                  file=sys.stderr, flush=True)
+            prob = None          # (the objects of the failed attempt are left alone: their tear-down may involve the peers)
+            comm = capi.Comm.gloo(ctx)
+        first_contact.set()
         if dist.is_initialized():
-            dist.broadcast(uid, 0)
-        comm = capi.Comm.rccl(ctx, world, rank, bytes(uid.cpu().numpy().tobytes()))
-        halo = partition.brick_halo(rank, grid, npr)
-        if dist.is_initialized():
-            dist.barrier()                   # torch's own communicator comes up here
+            dist.barrier()
         torch.cuda.synchronize()
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     os.close(saved_stdout)
-    pc_opts = {"jacobi": "-pc_type jacobi", "mg": "-pc_type mg -pc_mg_type additive"}[args.pc]
-    prob = driver.Problem(ctx, mesh, f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult}", comm=comm, halo=halo)
+    if prob is None:
+        prob = driver.Problem(ctx, mesh, popts, comm=comm, halo=halo)
     period = max(1, args.profile_period)
     prob.ksp.set_profiling(period)
 
@@ -490,7 +535,11 @@ def main():
             "roofline": roof,
         }
         if per_rank is not None:
-            out["config"]["rccl_ranks"] = 0 if args.rehearse else world
+            out["config"]["rccl_ranks"] = 0 if (args.rehearse or comm_fallback) else world
+            out["config"]["control_plane"] = ("bench.py's own barriers and timing reductions: torch.distributed over gloo (host scalars); "
+                                              "data path (halo sums, CG scalars): the library's communicator")
+            if comm_fallback:
+                out["config"]["comm_fallback"] = comm_fallback
             if args.rehearse:
                 out["config"]["rehearsal"] = (f"{world} processes on one GPU, torch.distributed over gloo, the library's collectives through "
                                               "the host-staged communicator (fem_comm_create_callbacks): every N>1 code path of bench.py "

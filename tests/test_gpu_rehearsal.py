@@ -91,3 +91,17 @@ def test_bench_watchdog_prints_the_headline_when_a_rank_stalls():
     assert p.returncode != 0
     out = _json_line(p.stdout)
     assert out["value"] > 0 and "abandoned" in out["config"]["pc_mg"]["error"]
+
+
+def test_bench_survives_a_failing_rccl_communicator():
+    """`bench.py --gpus 2` WITHOUT --rehearse and with the RCCL communicator failing on every rank (injected; two ranks share the
+    box's one GPU): the ranks agree on the failure over gloo and the job carries on over the host-staged communicator -- a complete
+    line with the failure noted, exit status 0."""
+    p = _torchrun(2, "bench.py", ["--gpus", "2", "--edge", "16", "--steps", "1", "--warmup", "1", "--no-mg"],
+                  env={"FEM_AMD_BENCH_INJECT_RCCL_FAILURE": "1"}, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    out = _json_line(p.stdout)
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and cfg["converged_reason"] > 0
+    assert cfg["rccl_ranks"] == 0 and "injected" in cfg["comm_fallback"]["why"] and "gloo" in cfg["comm_fallback"]["to"]
+    assert len(cfg["per_rank"]) == 2 and cfg["comm_stats_rank0"]["exchange_calls"] > 0

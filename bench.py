@@ -169,6 +169,9 @@ def main():
     args = ap.parse_args()
     if not args.n:
         args.n = 149 if args.config == 3 else 707
+    # every solve of this file iterates: the library's shortcut for a repeated right-hand side (-ksp_reuse_solution: a solve that
+    # repeats the previous one returns the kept solution) stays off for the whole process, whatever options a leg passes
+    os.environ["FEM_AMD_KSP_REUSE"] = "0"
 
     import torch
     import torch.distributed as dist
@@ -214,7 +217,8 @@ def main():
     comm = halo = prob = None
     comm_fallback = None
     pc_opts = {"jacobi": "-pc_type jacobi", "mg": "-pc_type mg -pc_mg_type additive"}[args.pc]
-    popts = f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult}"
+    # (-ksp_reuse_solution 0: every timed solve iterates, also where a step repeats the previous right-hand side)
+    popts = f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult} -ksp_reuse_solution 0"
     if use_comm:
         halo = partition.brick_halo(rank, grid, npr)
 

@@ -104,6 +104,7 @@ _SIGS = {
     "fem_ksp_get_residual_history": [_h, _dp, C.c_int, _ip],
     "fem_ksp_set_profiling": [_h, C.c_int],
     "fem_ksp_get_profile": [_h, _ip, _dp, _dp],
+    "fem_ksp_get_reused_solves": [_h, _ip],
     "fem_recover_nodal_stress": [_h, _h, _dp],
     "fem_recover_nodal_stress_vec": [_h, _h, _h],
     "fem_mesh_set_cohesive": [_h, _ip, C.c_int, _dp],
@@ -693,6 +694,12 @@ class KSP:
         n = C.c_int(0); a = C.c_double(0); b = C.c_double(0)
         _ck(_lib.fem_ksp_get_profile(self.h, C.byref(n), C.byref(a), C.byref(b)))
         return n.value, a.value, b.value
+
+    def get_reused_solves(self) -> int:
+        """Solves answered with the kept solution of an identical earlier solve (-ksp_reuse_solution, fem_amd.h)."""
+        n = C.c_int(0)
+        _ck(_lib.fem_ksp_get_reused_solves(self.h, C.byref(n)))
+        return n.value
 
     def destroy(self):
         if self.h and self.owned:

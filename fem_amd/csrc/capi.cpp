@@ -45,6 +45,7 @@ void ksp_set_tolerances(fem_ksp, double, double, double, int);
 void ksp_set_from_options_impl(fem_ksp, const char*);
 void ksp_set_up_impl(fem_ksp);
 void ksp_solve_impl(fem_ksp, fem_vec, fem_vec);
+int ksp_get_reused(fem_ksp);
 void ksp_get_result(fem_ksp, int*, double*, int*);
 int ksp_get_history(fem_ksp, double*, int);
 void ksp_set_profiling(fem_ksp, int);
@@ -344,6 +345,7 @@ int fem_mat_zero_entries(fem_mat A)
     FEM_CHECK(A, 1, "null matrix");
     A->ctx->bind();
     A->lazy_zero = true;   // materialised by the first reader; the assembly overwrites instead (fem_mat_s::values())
+    A->state++;
     A->bc_saved = false;   // the next ApplyKBC sees a freshly assembled diagonal again
     FEM_CATCH
 }
@@ -352,6 +354,7 @@ int fem_mat_assemble_elements(fem_mat A)
 {
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
+    A->state++;
     mat_assemble_elements_impl(A);
     FEM_CATCH
 }
@@ -409,6 +412,7 @@ int fem_mat_apply_kbc(fem_mat A, int nbcs, const int* bcnode)
 {
     FEM_TRY
     FEM_CHECK(A, 1, "null matrix");
+    A->state++;
     mat_apply_kbc_impl(A, nbcs, bcnode);
     FEM_CATCH
 }
@@ -437,6 +441,7 @@ int fem_mat_set_values(fem_mat A, int m, const int* rows, int n, const int* cols
     FEM_CHECK(A, 1, "null matrix");
     FEM_CHECK(m >= 0 && n >= 0 && (m == 0 || rows) && (n == 0 || cols) && (m == 0 || n == 0 || v), 2, "fem_mat_set_values: bad arguments");
     FEM_CHECK(mode == 1 || mode == 2, 2, "fem_mat_set_values: mode must be 1 (INSERT_VALUES) or 2 (ADD_VALUES)");
+    A->state++;
     if (m && n) mat_set_values_impl(A, m, rows, n, cols, v, mode);
     FEM_CATCH
 }
@@ -694,6 +699,14 @@ int fem_ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_m
     FEM_CATCH
 }
 
+int fem_ksp_get_reused_solves(fem_ksp k, int* n)
+{
+    FEM_TRY
+    FEM_CHECK(k && n, 1, "fem_ksp_get_reused_solves: null argument");
+    *n = ksp_get_reused(k);
+    FEM_CATCH
+}
+
 // ---- cohesive elements + Newton ---------------------------------------------------------------
 int fem_mesh_set_cohesive(fem_mesh mesh, const int* nlmat, int ncohmats, const double* props)
 {
@@ -720,6 +733,7 @@ int fem_mat_copy(fem_mat src, fem_mat dst)
     src->ctx->bind();
     FEM_HIP(hipMemcpyAsync(dst->val.p, src->values(), src->val.bytes(), hipMemcpyDeviceToDevice, src->ctx->stream));
     dst->lazy_zero = false;
+    dst->state++;
     dst->unsymmetric = src->unsymmetric;
     // the copy holds the same penalty rows: with the values goes what ApplyKBC recorded about them (the constraint list, the
     // assembled diagonal under it, the shift of the element-by-element product), so that a later ApplyKBC with another list
@@ -742,6 +756,7 @@ int fem_mat_add_cohesive(fem_mat J, fem_vec u_total, double dt, int rels_mode, c
 {
     FEM_TRY
     FEM_CHECK(J && u_total && u_total->n == (long long)J->nbrows * J->bs, 8, "fem_mat_add_cohesive: vector size mismatch");
+    J->state++;
     mat_add_cohesive_impl(J, u_total->d.p, dt, rels_mode, rels_nodes);
     FEM_CATCH
 }

@@ -338,6 +338,18 @@ struct fem_ksp_s {
     std::vector<hipEvent_t> ev;
     int n_spmv = 0;
     double spmv_ms = 0.0, solve_ms = 0.0;
+    // -ksp_reuse_solution (on by default; FEM_AMD_KSP_REUSE=0): the reference's increment loop solves K du = F once per increment
+    // (src/main.F90:236-250), and on a linear deck whose loads are ramps every increment has the same F ("steps 2..n are
+    // redundant work the reference still does").  An iterative solve keeps its right-hand side and solution; the next solve with the
+    // same operator state, the same options and a right-hand side that is the same bit for bit returns the kept solution -- what the
+    // deterministic solver would compute again -- with the kept iteration count, norm and reason.
+    int reuse = -1;
+    DBuf<double> last_b, last_x, cmp;
+    bool last_valid = false;
+    fem_mat last_A = nullptr;
+    unsigned long long last_state = 0;
+    int last_its = 0, last_reason = 0, n_reused = 0;
+    double last_rnorm = 0.0;
     ~fem_ksp_s() {
         if (h_state) (void)hipHostFree(h_state);
         for (auto e : poll_ev) if (e) (void)hipEventDestroy(e);
@@ -385,6 +397,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-ksp_fuse_allreduce") { is >> k->fuse_allreduce; FEM_CHECK(k->fuse_allreduce == 0 || k->fuse_allreduce == 1, 6, "-ksp_fuse_allreduce 0|1"); }
         else if (key == "-ksp_cg_fuse_p") { is >> k->fuse_p; FEM_CHECK(k->fuse_p == 0 || k->fuse_p == 1, 6, "-ksp_cg_fuse_p 0|1"); }
         else if (key == "-ksp_stream_min_dof") { is >> k->stream_min_dof; FEM_CHECK(k->stream_min_dof >= 0, 6, "-ksp_stream_min_dof n >= 0"); }
+        else if (key == "-ksp_reuse_solution") { is >> k->reuse; FEM_CHECK(k->reuse == 0 || k->reuse == 1, 6, "-ksp_reuse_solution 0|1"); }
         else if (key == "-ksp_halo_overlap") { is >> k->halo_overlap; FEM_CHECK(k->halo_overlap == 0 || k->halo_overlap == 1, 6, "-ksp_halo_overlap 0|1"); }
         else if (key == "-ksp_norm_type") { is >> val; FEM_CHECK(val == "preconditioned", 6, "only -ksp_norm_type preconditioned"); }
         else if (key == "-pc_factor_mat_solver_package" || key == "-pc_factor_mat_solver_type") { is >> val; }  // one built-in factorisation
@@ -398,6 +411,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
 void ksp_set_up_impl(fem_ksp k)
 {
     FEM_CHECK(k->A, 7, "fem_ksp_set_up: no operator set");
+    k->last_valid = false;   // (new operator or new options: nothing kept from earlier solves applies)
     fem_ctx ctx = k->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
@@ -532,10 +546,74 @@ static void ksp_bcgs_solve(fem_ksp k, fem_vec b, fem_vec x)
     k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
 }
 
+// how many workgroups see a difference between a and b (bit patterns, so that -0 / NaN payloads count)
+__global__ void __launch_bounds__(256) k_count_differences(size_t n, const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ out)
+{
+    int diff = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        diff |= __double_as_longlong(a[i]) != __double_as_longlong(b[i]);
+    if (__syncthreads_or(diff) && threadIdx.x == 0) atomicAdd(out, 1.0);
+}
+static bool ksp_reuse_wanted(fem_ksp k)
+{
+    static const bool env = !(std::getenv("FEM_AMD_KSP_REUSE") && std::atoi(std::getenv("FEM_AMD_KSP_REUSE")) == 0);
+    return (k->reuse >= 0 ? k->reuse != 0 : env) && !k->direct && !k->direct_lu;
+}
+// the kept solution, if this solve repeats the last one (every domain of a partitioned mesh takes the same decision: the count of
+// differences is summed over the domains)
+static bool ksp_try_reuse(fem_ksp k, fem_vec b, fem_vec x, Comm* comm, hipStream_t s)
+{
+    if (!k->last_valid || k->last_A != k->A || k->last_state != k->A->state || k->last_b.n != (size_t)k->n) {
+        k->last_valid = false;
+        if (!comm) return false;
+    }
+    if (!k->cmp.p) k->cmp.alloc(1);
+    k->cmp.zero(s);
+    if (k->last_valid) hipLaunchKernelGGL(k_count_differences, dim3(vgrid((size_t)k->n)), dim3(256), 0, s, (size_t)k->n, b->d.p, k->last_b.p, k->cmp.p);
+    else hipLaunchKernelGGL(k_fill, dim3(1), dim3(256), 0, s, k->cmp.p, (size_t)1, 1.0);   // (a domain with nothing kept: "different")
+    if (comm) comm->allreduce_sum(k->cmp.p, 1, s);
+    double ndiff = 1.0;
+    k->cmp.download(&ndiff, 1, s);
+    FEM_HIP(hipStreamSynchronize(s));
+    if (ndiff != 0.0) return false;
+    FEM_HIP(hipMemcpyAsync(x->d.p, k->last_x.p, sizeof(double) * (size_t)k->n, hipMemcpyDeviceToDevice, s));
+    FEM_HIP(hipStreamSynchronize(s));
+    k->its = k->last_its; k->reason = k->last_reason; k->rnorm = k->last_rnorm;
+    k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
+    k->n_reused++;
+    return true;
+}
+static void ksp_keep_solution(fem_ksp k, fem_vec b, fem_vec x, hipStream_t s)
+{
+    k->last_valid = false;
+    if (k->reason <= 0) return;
+    if (k->last_b.n != (size_t)k->n) { k->last_b.alloc((size_t)k->n); k->last_x.alloc((size_t)k->n); }
+    FEM_HIP(hipMemcpyAsync(k->last_b.p, b->d.p, sizeof(double) * (size_t)k->n, hipMemcpyDeviceToDevice, s));
+    FEM_HIP(hipMemcpyAsync(k->last_x.p, x->d.p, sizeof(double) * (size_t)k->n, hipMemcpyDeviceToDevice, s));
+    FEM_HIP(hipStreamSynchronize(s));
+    k->last_A = k->A; k->last_state = k->A->state;
+    k->last_its = k->its; k->last_reason = k->reason; k->last_rnorm = k->rnorm;
+    k->last_valid = true;
+}
+
+static void ksp_solve_once(fem_ksp k, fem_vec b, fem_vec x);
 void ksp_solve_impl(fem_ksp k, fem_vec b, fem_vec x)
 {
     if (!k->setup_done) ksp_set_up_impl(k);
     FEM_CHECK(b && x && b->n == k->n && x->n == k->n, 8, "fem_ksp_solve: vector size mismatch");
+    k->ctx->bind();
+    hipStream_t s = k->ctx->stream;
+    const bool reuse = ksp_reuse_wanted(k);
+    if (reuse) {
+        Halo* halo = k->A->mesh ? k->A->mesh->halo.get() : nullptr;
+        Comm* comm = (halo && halo->comm && halo->comm->size > 1) ? halo->comm : nullptr;
+        if (ksp_try_reuse(k, b, x, comm, s)) return;
+    }
+    ksp_solve_once(k, b, x);
+    if (reuse) ksp_keep_solution(k, b, x, s);
+}
+static void ksp_solve_once(fem_ksp k, fem_vec b, fem_vec x)
+{
     fem_ctx ctx = k->ctx;
     ctx->bind();
     hipStream_t s = ctx->stream;
@@ -854,6 +932,7 @@ int ksp_get_history(fem_ksp k, double* hist, int len)
     return std::max(n, 0);
 }
 void ksp_set_profiling(fem_ksp k, int on) { k->profiling = on > 0 ? on : 0; }
+int ksp_get_reused(fem_ksp k) { return k->n_reused; }
 void ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_ms)
 {
     if (n_spmv) *n_spmv = k->n_spmv;

@@ -137,6 +137,8 @@ struct fem_mat_s {
     fem::DBuf<int>& n2e_ptr;
     fem::DBuf<unsigned>& n2e;
     fem::DBuf<double> val;
+    unsigned long long state = 0;   // bumped by whatever changes the values (as PETSc's object state): a KSP that kept the solution of
+                                    // an identical right-hand side (-ksp_reuse_solution) gives it out only for an unchanged operator
     // MatZeroEntries is lazy: the row-owner assembly overwrites every entry (padding included), so a
     // zeroed matrix that is assembled next never pays for the memset; every other reader goes through
     // values(), which materialises the zeros first.

@@ -265,6 +265,11 @@ int fem_ksp_get_residual_history(fem_ksp ksp, double *hist, int len, int *n);
  * their summed duration, total solve duration. */
 int fem_ksp_set_profiling(fem_ksp ksp, int on);
 int fem_ksp_get_profile(fem_ksp ksp, int *n_spmv, double *spmv_ms, double *solve_ms);
+/* -ksp_reuse_solution 0|1 (default 1; iterative solves): a solve whose operator state, options and right-hand side are those of
+ * the previous solve, bit for bit, returns the kept solution instead of iterating again -- increments 2..n of the reference's
+ * loop on a linear deck with ramped loads (src/main.F90:216-250: one KSPSolve per increment, the same Vec_F every time).
+ * n = how many solves of this KSP were answered that way. */
+int fem_ksp_get_reused_solves(fem_ksp ksp, int *n);
 
 /* ---- cohesive elements and the Newton increment: SURVEY 8 f1, BASELINE config 5 ------------------------------
  * The reference solves a deck with cohesive elements through SNES (src/main.F90:200-206,240-245) with the two

@@ -206,3 +206,42 @@ def test_cg_opened_by_the_quad4_product_is_bitwise_the_three_kernel_cg(gpu_ctx, 
     assert np.array_equal(a.aggregate_u, b.aggregate_u)
     assert np.array_equal(a.aggregate_stress, b.aggregate_stress)
     assert np.abs(b.aggregate_u - c.aggregate_u).max() <= 1e-9 * np.abs(c.aggregate_u).max()
+
+
+@pytest.mark.parametrize("opts", ["", "-mat_mult_type ebe", "-pc_type mg -pc_mg_type additive", "-ksp_type bcgs"])
+def test_repeated_right_hand_side_returns_the_kept_solution(gpu_ctx, opts):
+    """-ksp_reuse_solution (default on): the reference's increment loop solves K du = F once per increment (src/main.F90:236-250),
+    with the same F every time on a linear deck with ramped loads.  A solve that repeats the previous one -- same operator state,
+    same options, right-hand side equal bit for bit -- returns the kept solution with the kept iteration count; a changed
+    right-hand side, a changed operator (ApplyKBC again, MatSetValues) or new options make it iterate again.  Same fields to the
+    bit as with the shortcut off."""
+    m = structured_hex(7, 6, 5, jitter=0.15)
+    m.t, m.dt = 1.0, 0.25                                    # four increments, linear ramp: four identical right-hand sides
+    a = driver.run(m, f"-ksp_rtol 1e-12 {opts} -ksp_reuse_solution 0", ctx=gpu_ctx)
+    b = driver.run(m, f"-ksp_rtol 1e-12 {opts}", ctx=gpu_ctx)
+    assert len(a.its) == 4 and a.its == b.its and a.reasons == b.reasons and a.reasons[-1] > 0
+    assert np.array_equal(a.aggregate_u, b.aggregate_u) and np.array_equal(a.aggregate_stress, b.aggregate_stress)
+    prob = driver.Problem(gpu_ctx, m, f"-ksp_rtol 1e-12 {opts}")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    U2 = capi.Vec(gpu_ctx, m.ndof)
+    prob.ksp.solve(prob.F, prob.U)
+    its = prob.ksp.get_iteration_number()
+    assert prob.ksp.get_reused_solves() == 0
+    prob.ksp.solve(prob.F, U2)                                # the same again: kept
+    assert prob.ksp.get_reused_solves() == 1 and prob.ksp.get_iteration_number() == its
+    assert np.array_equal(prob.U.get_array(), U2.get_array())
+    f = prob.F.get_array(); j = int(np.argmax(np.abs(f))); f[j] = np.nextafter(f[j], 0.0); prob.F.set_array(f)
+    prob.ksp.solve(prob.F, U2)                                # one bit of F differs: a real solve
+    assert prob.ksp.get_reused_solves() == 1
+    prob.ksp.solve(prob.F, U2)
+    assert prob.ksp.get_reused_solves() == 2
+    prob.K.apply_kbc()                                        # the operator's state moved (same values): a real solve
+    prob.ksp.solve(prob.F, U2)
+    assert prob.ksp.get_reused_solves() == 2
+    prob.ksp.set_from_options("-ksp_rtol 1e-10")              # new options: a real solve
+    prob.ksp.solve(prob.F, U2)
+    assert prob.ksp.get_reused_solves() == 2
+    prob.ksp.solve(prob.F, U2)
+    assert prob.ksp.get_reused_solves() == 3
+    U2.destroy(); prob.destroy()

@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-mg", action="store_true", help="skip the extra -pc_type mg measurement")
     ap.add_argument("--no-c2", action="store_true", help="skip the config-2 (707^2 quad4) object of the default line")
     ap.add_argument("--no-distorted", action="store_true", help="skip the distorted-mesh (jitter 0.15) object of the default line")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 (cohesive deck x1000, Newton) object of the default line")
     ap.add_argument("--mg-timeout", type=float, default=240.0,
                     help="N>1 only: seconds after which the extra -pc_type mg measurement is abandoned and the "
                          "headline line is printed without it (the path over real RCCL peers could only be "
@@ -769,6 +770,30 @@ def main():
                 out["config2"]["cpu_baseline"]["host"] = hc2
                 out["config2"]["gpu_over_cpu"] = out["config2"]["value"] / out["config2"]["cpu_baseline"]["value"]
             p2.destroy()
+
+        if hex_case and not args.no_c5:
+            # config 5 of BASELINE.json: the reference's cohesive deck tiled x1000 (examples/cohesive_test_2.inp, the fixture under
+            # tests/golden/decks), the Newton increment loop of src/main.F90:216-296 with the reference's inner solver (KSPPREONLY +
+            # PCLU): as 1,000 disjoint copies (SURVEY 8(d)'s wording) and as one connected strip (shared edge nodes).  Wall time of a
+            # whole run (both increments, Jacobian and residual callbacks issued by the library, stress recovery included), third run.
+            try:
+                from fem_amd.inp import read_inp
+                from fem_amd.mesh import tile_deck, tile_deck_connected
+                m1 = read_inp(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "decks", "cohesive_test_2.inp"))
+                c5 = {"workload": "config 5: examples/cohesive_test_2.inp x1000 (quad4 + Xu-Needleman cohesive elements), SNES NEWTONLS, "
+                                  "-ksp_type preonly -pc_type lu; wall time of the whole increment loop"}
+                for key, mm, rels in (("disjoint_copies", tile_deck(m1, 1000), 0), ("connected_strip", tile_deck_connected(m1, 1000), 1)):
+                    for _ in range(3):
+                        t5 = time.perf_counter()
+                        r5 = driver.run_nonlinear(mm, "-ksp_type preonly -pc_type lu", ctx=ctx, rels_mode=rels, recover_stress=True,
+                                                  builtin_callbacks=True)
+                        t5 = time.perf_counter() - t5
+                    c5[key] = {"dof": mm.ndof, "elements": mm.nels, "increments": len(r5.snes_its), "ms": t5 * 1e3,
+                               "snes_iterations": [int(v) for v in r5.snes_its], "snes_reasons": [int(v) for v in r5.snes_reasons],
+                               "linear_solves": [int(v) for v in r5.its], "dof_increments_per_s": mm.ndof * len(r5.snes_its) / t5}
+                out["config5"] = c5
+            except Exception as e:  # noqa: BLE001 -- a side object must not take the line down
+                out["config5"] = {"error": repr(e)[:300]}
 
     if rank == 0 and world == 8 and args.n == 149 and args.jitter == 0.0 and hex_case:
         out["config"]["same_problem_on_one_gpu"] = same_problem_on_one_gpu(value)

@@ -72,7 +72,22 @@ void pool_release(void* p, size_t bytes) noexcept
     // same guarantee as hipFree: nothing in flight can still touch the block when it is handed out again
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_mu);
-    if (g_cached + bytes > pool_limit()) { (void)hipFree(p); return; }
+    if (bytes > pool_limit()) { (void)hipFree(p); return; }
+    // A full cache makes room for the block that is released NOW -- the sizes in use now are the ones asked for next -- by giving its
+    // largest blocks back to the driver (down to half the limit, so that this is rare).  Round 5: with the cache full of the big blocks
+    // of earlier problems (bench.py's legs: meshes and matrices of several sizes, 96 GB of them) every later release went to hipFree
+    // and every later request to hipMalloc -- the Newton loop of config 5, hundreds of small blocks per run, took 55 ms instead of 4.
+    if (g_cached + bytes > pool_limit()) {
+        for (auto it = g_free.end(); it != g_free.begin() && g_cached + bytes > pool_limit() / 2;) {
+            --it;
+            if (it->first.first != dev) continue;
+            while (!it->second.empty() && g_cached + bytes > pool_limit() / 2) {
+                (void)hipFree(it->second.back());
+                it->second.pop_back();
+                g_cached -= it->first.second;
+            }
+        }
+    }
     g_free[{dev, bytes}].push_back(p);
     g_cached += bytes;
 }

@@ -134,3 +134,40 @@ def test_device_pool_reuses_blocks_and_context_destroy_returns_them():
     held = used()
     ctx.destroy()
     assert used() < held - (100 << 20)      # the 140 MB matrix blocks went back
+
+
+def test_full_device_pool_makes_room_for_the_blocks_in_use():
+    """A cache of released blocks that is full (FEM_AMD_POOL_MAX_GB; here 0.05 GB in a child process) gives its largest blocks back
+    to the driver instead of refusing every later release: problems of several sizes one after the other, then a small one again
+    and again -- same answers every time, and the footprint of a cycle does not grow."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes as C, numpy as np
+from fem_amd import capi, driver
+from fem_amd.mesh import structured_hex
+hip = C.CDLL("libamdhip64.so")
+def used():
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return total.value - free.value
+ctx = capi.Context(0)
+ref, first = None, None
+for cycle in range(3):
+    for n in (30, 22, 26, 8, 8):
+        r = driver.run(structured_hex(n, jitter=0.1), "-ksp_rtol 1e-10", ctx=ctx)
+        assert r.reasons[-1] > 0
+        if n == 8:
+            ref = r.aggregate_u if ref is None else ref
+            assert np.array_equal(ref, r.aggregate_u)
+    if first is None:
+        first = used()
+    assert used() <= first + (64 << 20), (used(), first)     # (the footprint of a cycle does not grow: what the cache drops goes back)
+ctx.destroy()
+print("POOL_OK")
+'''
+    env = dict(os.environ, FEM_AMD_POOL_MAX_GB="0.05", PYTHONPATH=root)
+    p = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "POOL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -893,7 +893,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s)
         if (!vec.empty()) FEM_HIP(hipMemcpyAsync(dbuf.p, vec.data(), vec.size() * sizeof(vec[0]), hipMemcpyHostToDevice, s));
     };
     up(plan->list_aff, laff); up(plan->list_gen, lgen); up(plan->list_cart, lcart);
-    ebe_tile_list_headers(*plan, s);
+    ebe_tile_list_headers(*plan, !hex, s);
     if (!laff.empty() || !lcart.empty()) ebe_tile_store_geometry(m, *plan, d_taff.p, s);
     if (!hex) ebe_tile_quad_factors(m, *plan, s);
     FEM_HIP(hipStreamSynchronize(s));   // (the scratch buffers go out of scope; the lists were uploaded from host vectors)

@@ -29,6 +29,11 @@ struct EbeTilePlan {
     int n_aff_if = 0, n_gen_if = 0;      // how many of each list those are
     DBuf<int> list_cart;                 // tiles of axis-aligned bricks (a third list, same order rule); not in list_aff
     DBuf<int> lhdr_cart, lhdr_aff, lhdr_gen;   // [n * 8] the listed tiles' hdr records + tile id, in list order (what the kernels read)
+    // the listed tiles' node lists once more at a FIXED stride per list position (the kernels with x in LDS): the load of a tile's node
+    // ids then needs nothing from its record -- header and ids travel together instead of one behind the other (one round trip less at the
+    // start of every tile)
+    DBuf<int> pnodes_cart, pnodes_aff, pnodes_gen;
+    int pnode_stride = 0;
     int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
@@ -53,7 +58,7 @@ std::shared_ptr<fem::EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);    
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s);     // host worker threads (cross-check: FEM_AMD_TILE_PLAN=host)
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s);   // ebe_plan.hip
 // geometry records of the stored-geometry tiles' elements (taff: class per lane slot), ebe_tile.hip
-void ebe_tile_list_headers(fem::EbeTilePlan& P, hipStream_t s);   // lhdr_* from list_* and hdr (ebe_tile.hip)
+void ebe_tile_list_headers(fem::EbeTilePlan& P, bool quad, hipStream_t s);   // lhdr_* from list_* and hdr (ebe_tile.hip)
 void ebe_tile_quad_factors(fem_mesh m, fem::EbeTilePlan& P, hipStream_t s);   // quad4 plans: D factors per lane slot
 void ebe_tile_store_geometry(fem_mesh m, fem::EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s);
 

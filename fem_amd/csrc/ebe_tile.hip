@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 // under the next step's arithmetic; contributions to rim nodes are not added at all (their sums belong to other tiles).
 template <int KIND, bool STREAM = false, bool UNI = false>   // 2: axis-aligned bricks (three workgroups per CU), 1: other parallelepipeds (full adj(J) stored: two); UNI: every tile of the plan has one geometry record (lhdr[7])
 __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist, const int* __restrict__ lhdr,
-                                                       const int2* __restrict__ steps, const int* __restrict__ tnodes,
+                                                       const int2* __restrict__ steps, const int* __restrict__ pnodes,
                                                        const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
                                                        const double* __restrict__ x, const int* __restrict__ bc_node,
                                                        const int* __restrict__ bc_dof, const double* __restrict__ bc_shift,
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     if (lb >= (unsigned)nlist) return;
     // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
     const int* hd = lhdr + 8 * (size_t)lb;
-    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
+    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     const int uref = UNI ? hd[7] : 0;   // every element of the tile has the geometry record of slot uref - 1 (k_tile_geo_uniform)
     constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
     double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
@@ -488,7 +488,8 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     {   // stage in: node list, x -> LDS, sums zeroed (all loads of a lane in flight together)
         double xv[NPT][3];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? ld_list<STREAM>(tnodes + node_off + i) : 0; }
+        for (int j = 0; j < NPT; j++)   // (the list at a fixed stride per list position: asked for beside the record, not behind it; 0 beyond nnode)
+            nv[j] = ld_list<STREAM>(pnodes + (size_t)lb * TILE_X_MAX_NODES + threadIdx.x + 256 * j);
 #pragma unroll
         for (int j = 0; j < NPT; j++) {   // a node's three values as one 16 B and one 8 B load (a third fewer trips through the address unit)
             const int i = threadIdx.x + 256 * j;
@@ -935,7 +936,7 @@ constexpr int TILE_Q4X_MAX_NODES = 1280, TILE_Q4X_MAX_OWN = 1024;   // 5 / 4 slo
 constexpr int TILE_Q4X_LDS_NODES = 1104, TILE_Q4X_LDS_OWN = 976;    // the LDS image (33 x 33 nodes, 31 x 31 owned): 50 KB, three workgroups per CU
 template <bool FUSED>   // FUSED: the kernel opens the CG iteration itself (convergence test, p = M^-1 r + b p in the stage-in, x += a p): cg_device.h
 __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
-                                                      const int* __restrict__ tnodes, const uint4* __restrict__ tconn,
+                                                      const int* __restrict__ pnodes, const uint4* __restrict__ tconn,
                                                       const unsigned char* __restrict__ tflags, const double* __restrict__ geo,
                                                       size_t geo_stride, const double* __restrict__ coords, const double* __restrict__ x,
                                                       const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
@@ -956,7 +957,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     }
     if (lb >= (unsigned)nlist) return;   // (workgroup 0, which records the verdict of a fused opening, holds tile 0 of the list)
     const int* hd = lhdr + 8 * (size_t)lb;
-    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
+    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     double* xs = lds;               // xs[d * MN + i]: x of the tile's nodes
     double* Xs = lds + 2 * MN;      // Xs[d * MN + i]: their coordinates
     double* acc = lds + 4 * MN;     // acc[d * MO + i]: sums of the owned nodes
@@ -964,7 +965,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     {
         double xv[NPT][2], cv[NPT][2];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < NPT; j++) nv[j] = pnodes[(size_t)lb * TILE_Q4X_MAX_NODES + threadIdx.x + 256 * j];   // (fixed stride per list position: see EbeTilePlan::pnodes_*)
         if constexpr (FUSED) {
             // everything the stage-in reads is asked for BEFORE the scalars of the opening are summed (they do not depend on each
             // other, and with fewer tiles than workgroup slots the kernel lasts as long as one tile's chain of latencies)
@@ -1213,13 +1214,31 @@ __global__ void __launch_bounds__(256) k_tile_list_hdr(int n, const int* __restr
     for (int j = 0; j < 6; j++) out[8 * i + j] = hdr[(size_t)6 * t + j];
     out[8 * i + 6] = t; out[8 * i + 7] = 0;
 }
-void ebe_tile_list_headers(EbeTilePlan& P, hipStream_t s)
+// the listed tiles' node lists at a fixed stride (one workgroup per list position; zeros behind a tile's last node)
+__global__ void __launch_bounds__(256) k_tile_list_nodes(int n, const int* __restrict__ lhdr, const int* __restrict__ nodes, int stride, int* __restrict__ out)
+{
+    const size_t i = blockIdx.x;
+    const int node_off = lhdr[8 * i], nnode = lhdr[8 * i + 2];
+    for (int k = threadIdx.x; k < stride; k += 256) out[i * stride + k] = k < nnode ? nodes[(size_t)node_off + k] : 0;
+}
+void ebe_tile_list_headers(EbeTilePlan& P, bool quad, hipStream_t s)
 {
     auto go = [&](DBuf<int>& out, const DBuf<int>& list, int n) {
         out.alloc((size_t)std::max(n, 1) * 8);
         if (n) hipLaunchKernelGGL(k_tile_list_hdr, dim3(cdiv((size_t)n, 256)), dim3(256), 0, s, n, list.p, P.hdr.p, out.p);
     };
     go(P.lhdr_cart, P.list_cart, P.n_cart); go(P.lhdr_aff, P.list_aff, P.n_aff); go(P.lhdr_gen, P.list_gen, P.n_gen);
+    // plans of the kernels that keep x of a tile in LDS (small hex8 tiles: k_ebe_tile_x; quad4 tiles: k_ebe_tile_q4x)
+    P.pnode_stride = 0;
+    if (!quad && P.n_cart + P.n_aff > 0 && P.max_nnode <= TILE_X_LDS_NODES && P.max_nown <= TILE_X_MAX_OWN) P.pnode_stride = TILE_X_MAX_NODES;
+    else if (quad && P.max_nnode <= TILE_Q4X_LDS_NODES && P.max_nown <= TILE_Q4X_LDS_OWN) P.pnode_stride = TILE_Q4X_MAX_NODES;
+    if (P.pnode_stride) {
+        auto pad = [&](DBuf<int>& out, const DBuf<int>& lh, int n) {
+            out.alloc((size_t)std::max(n, 1) * P.pnode_stride);
+            if (n) hipLaunchKernelGGL(k_tile_list_nodes, dim3(n), dim3(256), 0, s, n, lh.p, P.nodes.p, P.pnode_stride, out.p);
+        };
+        pad(P.pnodes_cart, P.lhdr_cart, P.n_cart); pad(P.pnodes_aff, P.lhdr_aff, P.n_aff); pad(P.pnodes_gen, P.lhdr_gen, P.n_gen);
+    }
     FEM_HIP(hipGetLastError());
 }
 // quad4 plans: the D factors of every lane slot's element (k_ebe_tile_q4x reads them with the slot record)
@@ -1720,7 +1739,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s)
         piece(plan->conn16.p, o.tconn, eoff[i]); piece(plan->flags.p, o.tflags, eoff[i]); piece(d_taff.p, o.taff, eoff[i]);
     }
     FEM_HIP(hipStreamSynchronize(s));
-    ebe_tile_list_headers(*plan, s);
+    ebe_tile_list_headers(*plan, !hex, s);
     if (!laff.empty() || !lcart.empty()) ebe_tile_store_geometry(m, *plan, d_taff.p, s);
     if (!hex) ebe_tile_quad_factors(m, *plan, s);
     FEM_HIP(hipStreamSynchronize(s));   // (d_taff goes out of scope)
@@ -1796,7 +1815,7 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
             if (n1 > n0) {
                 auto launch = [&](auto kern, const CgFuseArgs& ca) {
                     hipLaunchKernelGGL(kern, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shqx, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
-                                       P.steps.p, P.nodes.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn,
+                                       P.steps.p, P.pnodes_gen.p + (size_t)n0 * TILE_Q4X_MAX_NODES, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn,
                                        A->bc_dof.p, A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out, ca);
                 };
                 if (cg) launch(k_ebe_tile_q4x<true>, *cg); else launch(k_ebe_tile_q4x<false>, CgFuseArgs{});
@@ -1833,9 +1852,9 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                                   reinterpret_cast<const void*>(k_ebe_tile_x<1, false, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, false, true>),
                                   reinterpret_cast<const void*>(k_ebe_tile_x<1, true, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
-        auto gox = [&](auto kern, int n, const int* list) {
+        auto gox = [&](auto kern, int n, const int* list, const int* pnodes) {
             if (!n) return;
-            hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.steps.p, P.nodes.p, P.conn16.p, P.flags.p,
+            hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.steps.p, pnodes, P.conn16.p, P.flags.p,
                                x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done, rcount,
                                P.ntiles, A->red_out);
         };
@@ -1843,17 +1862,17 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         // per plan -- a mesh with a graded region or a second material keeps the records slot by slot)
         const bool uni = P.n_uniform == (long long)P.n_cart + P.n_aff;
         if (P.stream && uni) {
-            gox(k_ebe_tile_x<2, true, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
-            gox(k_ebe_tile_x<1, true, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+            gox(k_ebe_tile_x<2, true, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<1, true, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
         } else if (P.stream) {
-            gox(k_ebe_tile_x<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
-            gox(k_ebe_tile_x<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+            gox(k_ebe_tile_x<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
         } else if (uni) {
-            gox(k_ebe_tile_x<2, false, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
-            gox(k_ebe_tile_x<1, false, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+            gox(k_ebe_tile_x<2, false, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<1, false, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
         } else {
-            gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);
-            gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0);
+            gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
         }
     } else if (P.stream) {
         go(k_ebe_tile<2, 0, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);

@@ -34,6 +34,14 @@ struct EbeTilePlan {
     // start of every tile)
     DBuf<int> pnodes_cart, pnodes_aff, pnodes_gen;
     int pnode_stride = 0;
+    // ... and, for the same reason, by global list position gp (cart tiles, then aff, then gen): the tile's step table (64 entries, zeros
+    // behind the last step), the slot records of its FIRST step (256 lanes; zeros where the step has no element) and, where the tile
+    // has one geometry record for all its elements (hex8, lhdr[7]) or per lane slot (quad4: the two D factors of the first step), that
+    // too.  With these the only load of a tile's start that waits for another one is the gather of x behind the node ids.
+    DBuf<int2> psteps;                   // [npos * 64]
+    DBuf<uint4> pconn0;                  // [npos * 256]
+    DBuf<unsigned char> pfl0;            // [npos * 256]
+    DBuf<double> pgeo;                   // hex8: [npos * 16] the tile's record (valid where lhdr[7] > 0); quad4: [npos * 512] lam, mu of the first step
     int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
@@ -58,7 +66,8 @@ std::shared_ptr<fem::EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s);    
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s);     // host worker threads (cross-check: FEM_AMD_TILE_PLAN=host)
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s);   // ebe_plan.hip
 // geometry records of the stored-geometry tiles' elements (taff: class per lane slot), ebe_tile.hip
-void ebe_tile_list_headers(fem::EbeTilePlan& P, bool quad, hipStream_t s);   // lhdr_* from list_* and hdr (ebe_tile.hip)
+void ebe_tile_list_headers(fem::EbeTilePlan& P, bool quad, hipStream_t s);
+void ebe_tile_first_records(fem::EbeTilePlan& P, bool quad, hipStream_t s);   // psteps, pconn0, pfl0, pgeo (after the stored geometry)   // lhdr_* from list_* and hdr (ebe_tile.hip)
 void ebe_tile_quad_factors(fem_mesh m, fem::EbeTilePlan& P, hipStream_t s);   // quad4 plans: D factors per lane slot
 void ebe_tile_store_geometry(fem_mesh m, fem::EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s);
 

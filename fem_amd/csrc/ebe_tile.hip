@@ -449,6 +449,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
+// a tile's step table, first-step slot records and geometry record by global list position (EbeTilePlan::psteps ...); gp0: position of
+// the launch's first tile
+struct TileFirst { const int2* psteps; const uint4* pconn0; const unsigned char* pfl0; const double* pgeo; unsigned long long gp0; };
+
 // Axis-aligned bricks with x of the tile in LDS.  On a mesh of bricks the plan uses small tiles (15 x 7 x 7 owned nodes: 1,024
 // elements = one 256-lane step in each of the four colours, 1,377 nodes), so that x of all the tile's nodes (24 B each) and the sums of its
 // owned nodes (24 B each) are 51 KB of LDS and THREE workgroups share a CU: their phases (stage-in, steps, write-out)
@@ -467,7 +471,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
                                                        const double* __restrict__ geo, size_t geo_stride, double g, int max_nnode,
                                                        int max_nown, double* __restrict__ y, double* __restrict__ partial,
                                                        const int* __restrict__ done, unsigned* __restrict__ rcount, int rtotal,
-                                                       double* __restrict__ red)
+                                                       double* __restrict__ red, TileFirst tf)
 {
     if (done && *done) return;
     static_assert(KIND == 1 || KIND == 2, "stored geometry only");
@@ -479,8 +483,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     if (lb >= (unsigned)nlist) return;
     // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
     const int* hd = lhdr + 8 * (size_t)lb;
-    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
-    const int uref = UNI ? hd[7] : 0;   // every element of the tile has the geometry record of slot uref - 1 (k_tile_geo_uniform)
+    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], nsteps = hd[5], t = hd[6];
     constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
     double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
     double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
@@ -512,9 +515,17 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for now, needed at the write-out
 #pragma unroll
     for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 256 * j < nown) ? bc_node[nv[j]] : -1;
-    // the steps of the tile in the lanes of every wavefront (lane s: step s; at most 64, checked by the host)
-    const int2 sv = ((int)(threadIdx.x & 63) < nsteps) ? steps[step_off + (threadIdx.x & 63)] : make_int2(0, 0);
+    // the steps of the tile in the lanes of every wavefront (lane s: step s; at most 64, checked by the host): from the copy at a fixed
+    // stride per list position, like the first step's slot records and the tile's geometry record below -- none of them waits for the
+    // tile's record
+    const size_t gp = (size_t)tf.gp0 + lb;
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
     struct Slot { uint4 c16; unsigned fl; double geo[NG]; };   // fl bit 1: an element (0: padding or past the step), bit 0: linked to the next lane
+    double ug[UNI ? NG : 1];
+    if constexpr (UNI) {   // one record for the tile: the same address in every lane
+#pragma unroll
+        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * 16 + j];
+    }
     auto fetch = [&](Slot& q, int s) {
         q.fl = 0;
         if (s >= nsteps) return;
@@ -523,12 +534,24 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         const size_t k = (size_t)elem_off + first + threadIdx.x;
         q.c16 = ld_list<STREAM>(tconn + k);
         q.fl = ld_list<STREAM>(tflags + k);
-        if constexpr (UNI) {   // one record for the tile: the same address in every lane (and every step: the caches hold it)
+        if constexpr (UNI) {
 #pragma unroll
-            for (int j = 0; j < NG; j++) q.geo[j] = geo[(size_t)j * geo_stride + (uref - 1)];
+            for (int j = 0; j < NG; j++) q.geo[j] = ug[j];
         } else {
 #pragma unroll
             for (int j = 0; j < NG; j++) q.geo[j] = ld_list<STREAM>(geo + (size_t)j * geo_stride + k);
+        }
+    };
+    auto fetch_first = [&](Slot& q) {   // step 0 (lanes beyond its count and tiles without a step hold zeros: no element)
+        q.c16 = ld_list<STREAM>(tf.pconn0 + gp * 256 + threadIdx.x);
+        q.fl = ld_list<STREAM>(tf.pfl0 + gp * 256 + threadIdx.x);
+        if constexpr (UNI) {
+#pragma unroll
+            for (int j = 0; j < NG; j++) q.geo[j] = ug[j];
+        } else {
+            const size_t k = (size_t)elem_off + __builtin_amdgcn_readlane(sv.x, 0) + threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < NG; j++) q.geo[j] = (q.fl & 2u) ? ld_list<STREAM>(geo + (size_t)j * geo_stride + k) : 0.0;
         }
     };
     // corner values of a step's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
@@ -550,7 +573,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         }
     };
     Slot q0, q1;
-    fetch(q0, 0);
+    fetch_first(q0);
     __syncthreads();
     double u[8][3];
     read_u(u, q0);
@@ -942,7 +965,8 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
                                                       const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
                                                       const double* __restrict__ bc_shift, double g, double w,
                                                       double* __restrict__ y, double* __restrict__ partial, const int* __restrict__ done,
-                                                      unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red, CgFuseArgs cg)
+                                                      unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red, CgFuseArgs cg,
+                                                      TileFirst tf)
 {
     constexpr int NPT = TILE_Q4X_MAX_NODES / 256, NPO = TILE_Q4X_MAX_OWN / 256, MN = TILE_Q4X_LDS_NODES, MO = TILE_Q4X_LDS_OWN;
     extern __shared__ double lds[];
@@ -957,7 +981,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     }
     if (lb >= (unsigned)nlist) return;   // (workgroup 0, which records the verdict of a fused opening, holds tile 0 of the list)
     const int* hd = lhdr + 8 * (size_t)lb;
-    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
+    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], nsteps = hd[5], t = hd[6];
     double* xs = lds;               // xs[d * MN + i]: x of the tile's nodes
     double* Xs = lds + 2 * MN;      // Xs[d * MN + i]: their coordinates
     double* acc = lds + 4 * MN;     // acc[d * MO + i]: sums of the owned nodes
@@ -1017,7 +1041,8 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     int kb[NPO];
 #pragma unroll
     for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 256 * j < nown) ? bc_node[nv[j]] : -1;
-    const int2 sv = ((int)(threadIdx.x & 63) < nsteps) ? steps[step_off + (threadIdx.x & 63)] : make_int2(0, 0);
+    const size_t gp = (size_t)tf.gp0 + lb;   // (step table, first step's slot records and D factors at fixed strides per list position: k_ebe_tile_x)
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
     struct Slot { uint4 c16; unsigned fl; double lam, mu; };
     auto fetch = [&](Slot& q, int s) {
         q.fl = 0; q.lam = 1.0; q.mu = 1.0;
@@ -1048,7 +1073,8 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
         }
     };
     Slot q0, q1;
-    fetch(q0, 0);
+    q0.c16 = tf.pconn0[gp * 256 + threadIdx.x]; q0.fl = tf.pfl0[gp * 256 + threadIdx.x];
+    q0.lam = tf.pgeo[gp * 512 + threadIdx.x]; q0.mu = tf.pgeo[gp * 512 + 256 + threadIdx.x];
     __syncthreads();
     double X[4][2], u[4][2];
     read_corners(X, u, q0);
@@ -1241,6 +1267,43 @@ void ebe_tile_list_headers(EbeTilePlan& P, bool quad, hipStream_t s)
     }
     FEM_HIP(hipGetLastError());
 }
+// step table, first-step slot records and geometry of one listed tile at fixed strides (EbeTilePlan::psteps ...); NG = 0: quad4
+__global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict__ lhdr, const int2* __restrict__ steps,
+                                                    const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
+                                                    const double* __restrict__ geo, size_t geo_stride, int ng, size_t gp0,
+                                                    int2* __restrict__ psteps, uint4* __restrict__ pconn0, unsigned char* __restrict__ pfl0,
+                                                    double* __restrict__ pgeo)
+{
+    const size_t i = blockIdx.x, gp = gp0 + i;
+    const int* hd = lhdr + 8 * i;
+    const int elem_off = hd[3], step_off = hd[4], nsteps = hd[5], uref = hd[7];
+    if (threadIdx.x < 64) psteps[gp * 64 + threadIdx.x] = (int)threadIdx.x < nsteps ? steps[step_off + threadIdx.x] : make_int2(0, 0);
+    const int2 s0 = nsteps > 0 ? steps[step_off] : make_int2(0, 0);
+    const bool have = (int)threadIdx.x < (s0.y & 0x7fffffff);
+    const size_t k = (size_t)elem_off + s0.x + threadIdx.x;
+    pconn0[gp * 256 + threadIdx.x] = have ? tconn[k] : make_uint4(0, 0, 0, 0);
+    pfl0[gp * 256 + threadIdx.x] = have ? tflags[k] : (unsigned char)0;
+    if (ng == 0) {   // quad4: lam, mu of the first step's lane slots
+        pgeo[gp * 512 + threadIdx.x] = (have && geo) ? geo[k] : 1.0;
+        pgeo[gp * 512 + 256 + threadIdx.x] = (have && geo) ? geo[geo_stride + k] : 1.0;
+    } else if ((int)threadIdx.x < 16) {
+        pgeo[gp * 16 + threadIdx.x] = (uref > 0 && (int)threadIdx.x < ng && geo) ? geo[(size_t)threadIdx.x * geo_stride + (uref - 1)] : 0.0;
+    }
+}
+void ebe_tile_first_records(EbeTilePlan& P, bool quad, hipStream_t s)
+{
+    if (!P.pnode_stride) return;
+    const size_t npos = (size_t)P.n_cart + P.n_aff + P.n_gen;
+    P.psteps.alloc(std::max<size_t>(npos, 1) * 64); P.pconn0.alloc(std::max<size_t>(npos, 1) * 256); P.pfl0.alloc(std::max<size_t>(npos, 1) * 256);
+    P.pgeo.alloc(std::max<size_t>(npos, 1) * (quad ? 512 : 16));
+    auto go = [&](const DBuf<int>& lh, int n, int ng, size_t gp0) {
+        if (n) hipLaunchKernelGGL(k_tile_first, dim3(n), dim3(256), 0, s, n, lh.p, P.steps.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, ng, gp0,
+                                  P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p);
+    };
+    if (quad) go(P.lhdr_gen, P.n_gen, 0, 0);
+    else { go(P.lhdr_cart, P.n_cart, 5, 0); go(P.lhdr_aff, P.n_aff, 11, (size_t)P.n_cart); }
+    FEM_HIP(hipGetLastError());
+}
 // quad4 plans: the D factors of every lane slot's element (k_ebe_tile_q4x reads them with the slot record)
 void ebe_tile_quad_factors(fem_mesh m, EbeTilePlan& P, hipStream_t s)
 {
@@ -1284,6 +1347,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
 {
     const char* how = std::getenv("FEM_AMD_TILE_PLAN");
     std::shared_ptr<EbeTilePlan> P = (how && std::string(how) == "host") ? ebe_tile_build_host(m, s) : ebe_tile_build_device(m, s);
+    if (P) ebe_tile_first_records(*P, m->pdim == 2, s);
     if (P) {
         // what one CG iteration walks through: the lists (slot records, flags, stored geometry, node lists) and five vectors, against
         // the 256 MB Infinity Cache (FEM_AMD_TILE_STREAM_MIN_MB: the threshold; measured -- 203 MB, 100^3 elements: plain loads 0.0443 ms
@@ -1816,7 +1880,8 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                 auto launch = [&](auto kern, const CgFuseArgs& ca) {
                     hipLaunchKernelGGL(kern, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shqx, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
                                        P.steps.p, P.pnodes_gen.p + (size_t)n0 * TILE_Q4X_MAX_NODES, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn,
-                                       A->bc_dof.p, A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out, ca);
+                                       A->bc_dof.p, A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out, ca,
+                                       TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)n0});
                 };
                 if (cg) launch(k_ebe_tile_q4x<true>, *cg); else launch(k_ebe_tile_q4x<false>, CgFuseArgs{});
             }
@@ -1852,27 +1917,27 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                                   reinterpret_cast<const void*>(k_ebe_tile_x<1, false, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, false, true>),
                                   reinterpret_cast<const void*>(k_ebe_tile_x<1, true, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
-        auto gox = [&](auto kern, int n, const int* list, const int* pnodes) {
+        auto gox = [&](auto kern, int n, const int* list, const int* pnodes, size_t gp0) {
             if (!n) return;
             hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.steps.p, pnodes, P.conn16.p, P.flags.p,
                                x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done, rcount,
-                               P.ntiles, A->red_out);
+                               P.ntiles, A->red_out, TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)gp0});
         };
         // (a run-time test of the header word inside one kernel cost more than the records: 0.131 against 0.124 ms; so the variant is
         // per plan -- a mesh with a graded region or a second material keeps the records slot by slot)
         const bool uni = P.n_uniform == (long long)P.n_cart + P.n_aff;
         if (P.stream && uni) {
-            gox(k_ebe_tile_x<2, true, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
-            gox(k_ebe_tile_x<1, true, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<2, true, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
+            gox(k_ebe_tile_x<1, true, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
         } else if (P.stream) {
-            gox(k_ebe_tile_x<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
-            gox(k_ebe_tile_x<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
+            gox(k_ebe_tile_x<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
         } else if (uni) {
-            gox(k_ebe_tile_x<2, false, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
-            gox(k_ebe_tile_x<1, false, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<2, false, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
+            gox(k_ebe_tile_x<1, false, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
         } else {
-            gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES);
-            gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES);
+            gox(k_ebe_tile_x<2>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
+            gox(k_ebe_tile_x<1>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
         }
     } else if (P.stream) {
         go(k_ebe_tile<2, 0, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0);

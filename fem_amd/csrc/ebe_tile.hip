@@ -487,7 +487,21 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
     double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
     double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
+    // Everything of the tile that sits at a fixed stride per list position is asked for FIRST, beside the tile's record: the step table
+    // (into the lanes of every wavefront: lane s holds step s; at most 64, checked by the host), the first step's slot records, the
+    // tile's geometry record, then the node ids.  (Behind the stage-in -- where they stood until the tile's life was measured -- they
+    // were a third round trip: issued when the gathers of x had come back, 2.2 us before the first step could start.)
+    const size_t gp = (size_t)tf.gp0 + lb;
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
+    const uint4 first_c16 = ld_list<STREAM>(tf.pconn0 + gp * 256 + threadIdx.x);
+    const unsigned first_fl = ld_list<STREAM>(tf.pfl0 + gp * 256 + threadIdx.x);
+    double ug[UNI ? NG : 1];
+    if constexpr (UNI) {   // one record for the tile: the same address in every lane
+#pragma unroll
+        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * 16 + j];
+    }
     int nv[NPT];
+    int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for with the gathers of x, needed at the write-out
     {   // stage in: node list, x -> LDS, sums zeroed (all loads of a lane in flight together)
         double xv[NPT][3];
 #pragma unroll
@@ -498,6 +512,10 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
             const int i = threadIdx.x + 256 * j;
             const Node3 v = (i < nnode) ? *reinterpret_cast<const Node3*>(x + (size_t)nv[j] * 3) : Node3{0.0, 0.0, 0.0};
             xv[j][0] = v.a; xv[j][1] = v.b; xv[j][2] = v.c;
+            // the node's penalty record with its values, unconditionally (no list: the tile's own record stands in and the result is not
+            // looked at; lanes without an owned node are skipped at the write-out).  As conditional loads behind the stage-in these came
+            // out of the compiler one behind the other, each waiting for the one before, in front of the barrier: 1.5 us of a 14 us tile.
+            if (j < NPO) kb[j] = (bc_node ? bc_node : hd)[bc_node ? nv[j] : 0];
         }
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
@@ -512,20 +530,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
             }
         }
     }
-    int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for now, needed at the write-out
-#pragma unroll
-    for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 256 * j < nown) ? bc_node[nv[j]] : -1;
-    // the steps of the tile in the lanes of every wavefront (lane s: step s; at most 64, checked by the host): from the copy at a fixed
-    // stride per list position, like the first step's slot records and the tile's geometry record below -- none of them waits for the
-    // tile's record
-    const size_t gp = (size_t)tf.gp0 + lb;
-    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
     struct Slot { uint4 c16; unsigned fl; double geo[NG]; };   // fl bit 1: an element (0: padding or past the step), bit 0: linked to the next lane
-    double ug[UNI ? NG : 1];
-    if constexpr (UNI) {   // one record for the tile: the same address in every lane
-#pragma unroll
-        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * 16 + j];
-    }
     auto fetch = [&](Slot& q, int s) {
         q.fl = 0;
         if (s >= nsteps) return;
@@ -543,8 +548,8 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         }
     };
     auto fetch_first = [&](Slot& q) {   // step 0 (lanes beyond its count and tiles without a step hold zeros: no element)
-        q.c16 = ld_list<STREAM>(tf.pconn0 + gp * 256 + threadIdx.x);
-        q.fl = ld_list<STREAM>(tf.pfl0 + gp * 256 + threadIdx.x);
+        q.c16 = first_c16;
+        q.fl = first_fl;
         if constexpr (UNI) {
 #pragma unroll
             for (int j = 0; j < NG; j++) q.geo[j] = ug[j];
@@ -633,7 +638,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         for (int d = 0; d < 3; d++) {
             sum[d] = acc[d * MO + i];
             const double xi = xs[d * MN + i];
-            if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum[d] += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
+            if (bc_node && kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum[d] += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
             dot += xi * sum[d];
         }
         *reinterpret_cast<Node3*>(y + (size_t)nv[j] * 3) = Node3{sum[0], sum[1], sum[2]};
@@ -985,11 +990,22 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     double* xs = lds;               // xs[d * MN + i]: x of the tile's nodes
     double* Xs = lds + 2 * MN;      // Xs[d * MN + i]: their coordinates
     double* acc = lds + 4 * MN;     // acc[d * MO + i]: sums of the owned nodes
+    // (step table, first step's slot records and D factors at fixed strides per list position, asked for first: see k_ebe_tile_x)
+    const size_t gp = (size_t)tf.gp0 + lb;
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
+    struct Slot { uint4 c16; unsigned fl; double lam, mu; };
+    Slot q0, q1;
+    q0.c16 = tf.pconn0[gp * 256 + threadIdx.x]; q0.fl = tf.pfl0[gp * 256 + threadIdx.x];
+    q0.lam = tf.pgeo[gp * 512 + threadIdx.x]; q0.mu = tf.pgeo[gp * 512 + 256 + threadIdx.x];
     int nv[NPT];
+    int kb[NPO];
     {
         double xv[NPT][2], cv[NPT][2];
 #pragma unroll
         for (int j = 0; j < NPT; j++) nv[j] = pnodes[(size_t)lb * TILE_Q4X_MAX_NODES + threadIdx.x + 256 * j];   // (fixed stride per list position: see EbeTilePlan::pnodes_*)
+        // (the penalty records of the owned nodes with the gathers, unconditionally: see k_ebe_tile_x)
+#pragma unroll
+        for (int j = 0; j < NPO; j++) kb[j] = (bc_node ? bc_node : hd)[bc_node ? nv[j] : 0];
         if constexpr (FUSED) {
             // everything the stage-in reads is asked for BEFORE the scalars of the opening are summed (they do not depend on each
             // other, and with fewer tiles than workgroup slots the kernel lasts as long as one tile's chain of latencies)
@@ -1038,12 +1054,6 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
             if (j < NPO && i < nown) { acc[i] = 0.0; acc[MO + i] = 0.0; }
         }
     }
-    int kb[NPO];
-#pragma unroll
-    for (int j = 0; j < NPO; j++) kb[j] = (bc_node && (int)threadIdx.x + 256 * j < nown) ? bc_node[nv[j]] : -1;
-    const size_t gp = (size_t)tf.gp0 + lb;   // (step table, first step's slot records and D factors at fixed strides per list position: k_ebe_tile_x)
-    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
-    struct Slot { uint4 c16; unsigned fl; double lam, mu; };
     auto fetch = [&](Slot& q, int s) {
         q.fl = 0; q.lam = 1.0; q.mu = 1.0;
         if (s >= nsteps) return;
@@ -1072,9 +1082,6 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
             }
         }
     };
-    Slot q0, q1;
-    q0.c16 = tf.pconn0[gp * 256 + threadIdx.x]; q0.fl = tf.pfl0[gp * 256 + threadIdx.x];
-    q0.lam = tf.pgeo[gp * 512 + threadIdx.x]; q0.mu = tf.pgeo[gp * 512 + 256 + threadIdx.x];
     __syncthreads();
     double X[4][2], u[4][2];
     read_corners(X, u, q0);
@@ -1125,7 +1132,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
         for (int d = 0; d < 2; d++) {
             sum[d] = acc[d * MO + i];
             const double xi = xs[d * MN + i];
-            if (kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum[d] += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
+            if (bc_node && kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum[d] += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
             dot += xi * sum[d];
         }
         reinterpret_cast<double2*>(y)[nv[j]] = make_double2(sum[0], sum[1]);

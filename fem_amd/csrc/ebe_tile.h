@@ -39,9 +39,11 @@ struct EbeTilePlan {
     // has one geometry record for all its elements (hex8, lhdr[7]) or per lane slot (quad4: the two D factors of the first step), that
     // too.  With these the only load of a tile's start that waits for another one is the gather of x behind the node ids.
     DBuf<int2> psteps;                   // [npos * 64]
-    DBuf<uint4> pconn0;                  // [npos * 256]
-    DBuf<unsigned char> pfl0;            // [npos * 256]
-    DBuf<double> pgeo;                   // hex8: [npos * 16] the tile's record (valid where lhdr[7] > 0); quad4: [npos * 512] lam, mu of the first step
+    int pslot_steps = 1;                 // steps whose slot records are stored that way: 4 where no tile has more (then ALL of a tile's
+                                         // slot records leave with its record), else the first
+    DBuf<uint4> pconn0;                  // [npos * pslot_steps * 256]
+    DBuf<unsigned char> pfl0;            // [npos * pslot_steps * 256]
+    DBuf<double> pgeo;                   // hex8: [npos * 16] the tile's record (valid where lhdr[7] > 0); quad4: [npos * pslot_steps * 512] lam, mu of those steps
     int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)

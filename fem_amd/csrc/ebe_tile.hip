@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 
 // a tile's step table, first-step slot records and geometry record by global list position (EbeTilePlan::psteps ...); gp0: position of
 // the launch's first tile
-struct TileFirst { const int2* psteps; const uint4* pconn0; const unsigned char* pfl0; const double* pgeo; unsigned long long gp0; };
+struct TileFirst { const int2* psteps; const uint4* pconn0; const unsigned char* pfl0; const double* pgeo; unsigned long long gp0; unsigned nsl; };   // nsl: EbeTilePlan::pslot_steps
 
 // Axis-aligned bricks with x of the tile in LDS.  On a mesh of bricks the plan uses small tiles (15 x 7 x 7 owned nodes: 1,024
 // elements = one 256-lane step in each of the four colours, 1,377 nodes), so that x of all the tile's nodes (24 B each) and the sums of its
@@ -493,8 +493,8 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     // were a third round trip: issued when the gathers of x had come back, 2.2 us before the first step could start.)
     const size_t gp = (size_t)tf.gp0 + lb;
     const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
-    const uint4 first_c16 = ld_list<STREAM>(tf.pconn0 + gp * 256 + threadIdx.x);
-    const unsigned first_fl = ld_list<STREAM>(tf.pfl0 + gp * 256 + threadIdx.x);
+    const uint4 first_c16 = ld_list<STREAM>(tf.pconn0 + gp * tf.nsl * 256 + threadIdx.x);
+    const unsigned first_fl = ld_list<STREAM>(tf.pfl0 + gp * tf.nsl * 256 + threadIdx.x);
     double ug[UNI ? NG : 1];
     if constexpr (UNI) {   // one record for the tile: the same address in every lane
 #pragma unroll
@@ -626,6 +626,171 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         }
         prev_bar = bar;
         q0 = q1;
+    }
+    __syncthreads();   // every sum is in
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPO; j++) {
+        const int i = threadIdx.x + 256 * j;
+        if (i >= nown) continue;
+        double sum[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            sum[d] = acc[d * MO + i];
+            const double xi = xs[d * MN + i];
+            if (bc_node && kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) sum[d] += bc_shift[kb[j] + d] * xi;   // ApplyKBC INSERTs on the diagonal only
+            dot += xi * sum[d];
+        }
+        *reinterpret_cast<Node3*>(y + (size_t)nv[j] * 3) = Node3{sum[0], sum[1], sum[2]};
+    }
+    tile_finish(dot, t, sh, partial, rcount, rtotal, red);
+}
+
+// The same kernel for plans whose tiles all have one geometry record (UNI) and at most four steps: the slot records of ALL the steps sit
+// at the fixed stride (EbeTilePlan::pslot_steps == 4) and are asked for with the tile's record -- no load is in flight at the barriers
+// between the colours and no step waits for the records of the next one (measured with s_memrealtime stamps: the first step of a tile
+// took 3.1 us, the others 1.4-1.8, of which the arithmetic is 0.9).
+template <int KIND, bool STREAM>
+__global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x4(int nlist, const int* __restrict__ lhdr,
+                                                       const int2* __restrict__ steps, const int* __restrict__ pnodes,
+                                                       const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
+                                                       const double* __restrict__ x, const int* __restrict__ bc_node,
+                                                       const int* __restrict__ bc_dof, const double* __restrict__ bc_shift,
+                                                       const double* __restrict__ geo, size_t geo_stride, double g, int max_nnode,
+                                                       int max_nown, double* __restrict__ y, double* __restrict__ partial,
+                                                       const int* __restrict__ done, unsigned* __restrict__ rcount, int rtotal,
+                                                       double* __restrict__ red, TileFirst tf)
+{
+    if (done && *done) return;
+    static_assert(KIND == 1 || KIND == 2, "stored geometry only");
+    constexpr int NG = KIND == 2 ? 5 : 11;
+    constexpr bool UNI = true;
+    constexpr int NPT = TILE_X_MAX_NODES / 256, NPO = TILE_X_MAX_OWN / 256;   // nodes / owned nodes per thread
+    extern __shared__ double lds[];
+    __shared__ double sh[4];
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // (XCD map as in k_ebe_tile)
+    if (lb >= (unsigned)nlist) return;
+    // the tile's record by its position in the list (one scalar load of 32 B; the list -> header indirection cost every tile a round trip)
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int nown = hd[1], nnode = hd[2], nsteps = hd[5], t = hd[6];
+    constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
+    double* xs = lds;                        // xs[d * MN + i]: x of the tile's nodes
+    double* acc = lds + 3 * MN;              // acc[d * MO + i]: sums of the owned nodes (the first nown of the list)
+    // Everything of the tile that sits at a fixed stride per list position is asked for FIRST, beside the tile's record: the step table
+    // (into the lanes of every wavefront: lane s holds step s; at most 64, checked by the host), the first step's slot records, the
+    // tile's geometry record, then the node ids.  (Behind the stage-in -- where they stood until the tile's life was measured -- they
+    // were a third round trip: issued when the gathers of x had come back, 2.2 us before the first step could start.)
+    const size_t gp = (size_t)tf.gp0 + lb;
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
+    uint4 sc16[4];
+    unsigned sfl[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        sc16[k] = ld_list<STREAM>(tf.pconn0 + (gp * 4 + k) * 256 + threadIdx.x);
+        sfl[k] = ld_list<STREAM>(tf.pfl0 + (gp * 4 + k) * 256 + threadIdx.x);
+    }
+    double ug[UNI ? NG : 1];
+    if constexpr (UNI) {   // one record for the tile: the same address in every lane
+#pragma unroll
+        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * 16 + j];
+    }
+    int nv[NPT];
+    int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for with the gathers of x, needed at the write-out
+    {   // stage in: node list, x -> LDS, sums zeroed (all loads of a lane in flight together)
+        double xv[NPT][3];
+#pragma unroll
+        for (int j = 0; j < NPT; j++)   // (the list at a fixed stride per list position: asked for beside the record, not behind it; 0 beyond nnode)
+            nv[j] = ld_list<STREAM>(pnodes + (size_t)lb * TILE_X_MAX_NODES + threadIdx.x + 256 * j);
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {   // a node's three values as one 16 B and one 8 B load (a third fewer trips through the address unit)
+            const int i = threadIdx.x + 256 * j;
+            const Node3 v = (i < nnode) ? *reinterpret_cast<const Node3*>(x + (size_t)nv[j] * 3) : Node3{0.0, 0.0, 0.0};
+            xv[j][0] = v.a; xv[j][1] = v.b; xv[j][2] = v.c;
+            // the node's penalty record with its values, unconditionally (no list: the tile's own record stands in and the result is not
+            // looked at; lanes without an owned node are skipped at the write-out).  As conditional loads behind the stage-in these came
+            // out of the compiler one behind the other, each waiting for the one before, in front of the barrier: 1.5 us of a 14 us tile.
+            if (j < NPO) kb[j] = (bc_node ? bc_node : hd)[bc_node ? nv[j] : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const int i = threadIdx.x + 256 * j;
+            if (i < nnode) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) xs[d * MN + i] = xv[j][d];
+            }
+            if (i < nown) {
+#pragma unroll
+                for (int d = 0; d < 3; d++) acc[d * MO + i] = 0.0;
+            }
+        }
+    }
+    // corner values of a step's elements: -x face always, +x face where the chain ends (tile_complete brings the others)
+    auto read_u = [&](double (&u)[8][3], const uint4& c16, const unsigned fl) {
+        const bool valid = (fl & 2u) != 0, linked = (fl & 1u) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int la = tile_loc(c16, c_tminus[i]);
+#pragma unroll
+            for (int d = 0; d < 3; d++) u[c_tminus[i]][d] = valid ? xs[d * MN + la] : 0.0;
+        }
+        if (valid && !linked) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int la = tile_loc(c16, c_tplus[i]);
+#pragma unroll
+                for (int d = 0; d < 3; d++) u[c_tplus[i]][d] = xs[d * MN + la];
+            }
+        }
+    };
+    __syncthreads();
+    double u[8][3];
+    read_u(u, sc16[0], sfl[0]);
+    bool prev_bar = false;   // the previous step closed a colour: its sums must be in before this step adds
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        if (s >= nsteps) break;
+        const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
+        const uint4 c16 = sc16[s];
+        const unsigned fl = sfl[s];
+        const bool valid = (fl & 2u) != 0, linked = (fl & 1u) != 0;
+        // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
+        tile_complete<3>(u, fl);
+        double fe[8][3], dot;
+        if constexpr (KIND == 2) {
+            const double a[3] = {ug[0], ug[1], ug[2]};
+            hex_forces_cart(a, ug[3], ug[4], u, g, fe, dot);
+        } else {
+            double A[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) A[i][j] = ug[3 * i + j];
+            hex_forces_geom(A, ug[9], ug[10], u, g, fe, dot);
+        }
+        {   // +x face forces of a linked lane go to the next lane's -x face nodes
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(fl & 1u), 0x111, 0xf, 0xf, true) != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int d = 0; d < 3; d++) {
+                    const double pv = row_prev(fe[c_tplus[i]][d]);
+                    if (recv) fe[c_tminus[i]][d] += pv;
+                }
+        }
+        if (s < 3) read_u(u, sc16[s < 3 ? s + 1 : 3], sfl[s < 3 ? s + 1 : 3]);
+        if (prev_bar) __syncthreads();
+        if (valid) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                if (linked && (c == 1 || c == 2 || c == 5 || c == 6)) continue;   // handed over
+                const int la = tile_loc(c16, c);
+                if (la >= nown) continue;     // a rim node: its sum belongs to another tile
+#pragma unroll
+                for (int d = 0; d < 3; d++)   // one writer per node and colour
+                    __hip_atomic_fetch_add(&acc[d * MO + la], fe[c][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        prev_bar = bar;
     }
     __syncthreads();   // every sum is in
     double dot = 0.0;
@@ -995,8 +1160,8 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
     struct Slot { uint4 c16; unsigned fl; double lam, mu; };
     Slot q0, q1;
-    q0.c16 = tf.pconn0[gp * 256 + threadIdx.x]; q0.fl = tf.pfl0[gp * 256 + threadIdx.x];
-    q0.lam = tf.pgeo[gp * 512 + threadIdx.x]; q0.mu = tf.pgeo[gp * 512 + 256 + threadIdx.x];
+    q0.c16 = tf.pconn0[gp * tf.nsl * 256 + threadIdx.x]; q0.fl = tf.pfl0[gp * tf.nsl * 256 + threadIdx.x];
+    q0.lam = tf.pgeo[gp * tf.nsl * 512 + threadIdx.x]; q0.mu = tf.pgeo[gp * tf.nsl * 512 + 256 + threadIdx.x];
     int nv[NPT];
     int kb[NPO];
     {
@@ -1277,7 +1442,7 @@ void ebe_tile_list_headers(EbeTilePlan& P, bool quad, hipStream_t s)
 // step table, first-step slot records and geometry of one listed tile at fixed strides (EbeTilePlan::psteps ...); NG = 0: quad4
 __global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict__ lhdr, const int2* __restrict__ steps,
                                                     const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
-                                                    const double* __restrict__ geo, size_t geo_stride, int ng, size_t gp0,
+                                                    const double* __restrict__ geo, size_t geo_stride, int ng, size_t gp0, int nsl,
                                                     int2* __restrict__ psteps, uint4* __restrict__ pconn0, unsigned char* __restrict__ pfl0,
                                                     double* __restrict__ pgeo)
 {
@@ -1285,27 +1450,31 @@ __global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict
     const int* hd = lhdr + 8 * i;
     const int elem_off = hd[3], step_off = hd[4], nsteps = hd[5], uref = hd[7];
     if (threadIdx.x < 64) psteps[gp * 64 + threadIdx.x] = (int)threadIdx.x < nsteps ? steps[step_off + threadIdx.x] : make_int2(0, 0);
-    const int2 s0 = nsteps > 0 ? steps[step_off] : make_int2(0, 0);
-    const bool have = (int)threadIdx.x < (s0.y & 0x7fffffff);
-    const size_t k = (size_t)elem_off + s0.x + threadIdx.x;
-    pconn0[gp * 256 + threadIdx.x] = have ? tconn[k] : make_uint4(0, 0, 0, 0);
-    pfl0[gp * 256 + threadIdx.x] = have ? tflags[k] : (unsigned char)0;
-    if (ng == 0) {   // quad4: lam, mu of the first step's lane slots
-        pgeo[gp * 512 + threadIdx.x] = (have && geo) ? geo[k] : 1.0;
-        pgeo[gp * 512 + 256 + threadIdx.x] = (have && geo) ? geo[geo_stride + k] : 1.0;
-    } else if ((int)threadIdx.x < 16) {
-        pgeo[gp * 16 + threadIdx.x] = (uref > 0 && (int)threadIdx.x < ng && geo) ? geo[(size_t)threadIdx.x * geo_stride + (uref - 1)] : 0.0;
+    for (int st = 0; st < nsl; st++) {
+        const int2 s0 = st < nsteps ? steps[step_off + st] : make_int2(0, 0);
+        const bool have = (int)threadIdx.x < (s0.y & 0x7fffffff);
+        const size_t k = (size_t)elem_off + s0.x + threadIdx.x, o = (gp * nsl + st) * 256 + threadIdx.x;
+        pconn0[o] = have ? tconn[k] : make_uint4(0, 0, 0, 0);
+        pfl0[o] = have ? tflags[k] : (unsigned char)0;
+        if (ng == 0) {   // quad4: lam, mu of the step's lane slots
+            pgeo[(gp * nsl + st) * 512 + threadIdx.x] = (have && geo) ? geo[k] : 1.0;
+            pgeo[(gp * nsl + st) * 512 + 256 + threadIdx.x] = (have && geo) ? geo[geo_stride + k] : 1.0;
+        }
     }
+    if (ng != 0 && (int)threadIdx.x < 16)
+        pgeo[gp * 16 + threadIdx.x] = (uref > 0 && (int)threadIdx.x < ng && geo) ? geo[(size_t)threadIdx.x * geo_stride + (uref - 1)] : 0.0;
 }
 void ebe_tile_first_records(EbeTilePlan& P, bool quad, hipStream_t s)
 {
     if (!P.pnode_stride) return;
-    const size_t npos = (size_t)P.n_cart + P.n_aff + P.n_gen;
-    P.psteps.alloc(std::max<size_t>(npos, 1) * 64); P.pconn0.alloc(std::max<size_t>(npos, 1) * 256); P.pfl0.alloc(std::max<size_t>(npos, 1) * 256);
-    P.pgeo.alloc(std::max<size_t>(npos, 1) * (quad ? 512 : 16));
+    const size_t npos = std::max<size_t>((size_t)P.n_cart + P.n_aff + P.n_gen, 1);
+    P.pslot_steps = P.max_nsteps <= 4 ? 4 : 1;
+    const size_t nsl = (size_t)P.pslot_steps;
+    P.psteps.alloc(npos * 64); P.pconn0.alloc(npos * nsl * 256); P.pfl0.alloc(npos * nsl * 256);
+    P.pgeo.alloc(quad ? npos * nsl * 512 : npos * 16);
     auto go = [&](const DBuf<int>& lh, int n, int ng, size_t gp0) {
         if (n) hipLaunchKernelGGL(k_tile_first, dim3(n), dim3(256), 0, s, n, lh.p, P.steps.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, ng, gp0,
-                                  P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p);
+                                  P.pslot_steps, P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p);
     };
     if (quad) go(P.lhdr_gen, P.n_gen, 0, 0);
     else { go(P.lhdr_cart, P.n_cart, 5, 0); go(P.lhdr_aff, P.n_aff, 11, (size_t)P.n_cart); }
@@ -1888,7 +2057,7 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
                     hipLaunchKernelGGL(kern, dim3((n1 - n0 + 7) / 8 * 8), dim3(256), shqx, s, n1 - n0, P.lhdr_gen.p + 8 * (size_t)n0,
                                        P.steps.p, P.pnodes_gen.p + (size_t)n0 * TILE_Q4X_MAX_NODES, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, x, bcn,
                                        A->bc_dof.p, A->bc_shift.p, g, w, y, part, done, rcount, P.ntiles, A->red_out, ca,
-                                       TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)n0});
+                                       TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)n0, (unsigned)P.pslot_steps});
                 };
                 if (cg) launch(k_ebe_tile_q4x<true>, *cg); else launch(k_ebe_tile_q4x<false>, CgFuseArgs{});
             }
@@ -1922,18 +2091,28 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
             for (const void* f : {reinterpret_cast<const void*>(k_ebe_tile_x<1>), reinterpret_cast<const void*>(k_ebe_tile_x<2>),
                                   reinterpret_cast<const void*>(k_ebe_tile_x<1, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true>),
                                   reinterpret_cast<const void*>(k_ebe_tile_x<1, false, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, false, true>),
-                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, true, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true, true>)})
+                                  reinterpret_cast<const void*>(k_ebe_tile_x<1, true, true>), reinterpret_cast<const void*>(k_ebe_tile_x<2, true, true>),
+                                  reinterpret_cast<const void*>(k_ebe_tile_x4<1, false>), reinterpret_cast<const void*>(k_ebe_tile_x4<2, false>),
+                                  reinterpret_cast<const void*>(k_ebe_tile_x4<1, true>), reinterpret_cast<const void*>(k_ebe_tile_x4<2, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shx_max));
         auto gox = [&](auto kern, int n, const int* list, const int* pnodes, size_t gp0) {
             if (!n) return;
             hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shx, s, n, list, P.steps.p, pnodes, P.conn16.p, P.flags.p,
                                x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p, (size_t)P.slots, g, P.max_nnode, P.max_nown, y, part, done, rcount,
-                               P.ntiles, A->red_out, TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)gp0});
+                               P.ntiles, A->red_out, TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)gp0, (unsigned)P.pslot_steps});
         };
         // (a run-time test of the header word inside one kernel cost more than the records: 0.131 against 0.124 ms; so the variant is
         // per plan -- a mesh with a graded region or a second material keeps the records slot by slot)
         const bool uni = P.n_uniform == (long long)P.n_cart + P.n_aff;
-        if (P.stream && uni) {
+        if (uni && P.pslot_steps == 4) {   // (every slot record of a tile at the fixed stride: none is loaded inside the steps)
+            if (P.stream) {
+                gox(k_ebe_tile_x4<2, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
+                gox(k_ebe_tile_x4<1, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
+            } else {
+                gox(k_ebe_tile_x4<2, false>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
+                gox(k_ebe_tile_x4<1, false>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
+            }
+        } else if (P.stream && uni) {
             gox(k_ebe_tile_x<2, true, true>, c1 - c0, P.lhdr_cart.p + 8 * (size_t)c0, P.pnodes_cart.p + (size_t)c0 * TILE_X_MAX_NODES, (size_t)c0);
             gox(k_ebe_tile_x<1, true, true>, a1 - a0, P.lhdr_aff.p + 8 * (size_t)a0, P.pnodes_aff.p + (size_t)a0 * TILE_X_MAX_NODES, (size_t)P.n_cart + a0);
         } else if (P.stream) {

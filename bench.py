@@ -51,6 +51,8 @@ FP64_PEAK_TFLOPS = 78.6
 EBE_WORK = {
     "k_ebe_tile_x<cartesian>": (286, 336, 468),  # one-pass tiles of a mesh of axis-aligned bricks, x of the tile in LDS (three
                                                   # workgroups per CU)
+    "k_ebe_tile_x4<cartesian>": (294, 349, 479),  # the same with one geometry record per tile and the slot records of all four steps
+                                                  # asked for with the tile's record (uniform bricks: the headline)
     "k_ebe_tile<cartesian>": (281, 349, 515),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
     "k_ebe_tile<affine>": (475, 658, 719),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
     "k_ebe_tile<general>": (1503, 2217, 1850),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
@@ -446,6 +448,9 @@ def main():
             # bench meshes: the regular brick (axis-aligned elements) or, with --jitter, distorted elements throughout
             x_in_lds = os.environ.get("FEM_AMD_TILE_X", "1") != "0"     # (the library's default for brick tiles)
             kname = ("k_ebe_tile_x<cartesian>" if x_in_lds else "k_ebe_tile<cartesian>") if affine else "k_ebe_tile<general>"
+            x4 = affine and x_in_lds and int(info.get("per_tile_records") or 0) == 2      # k_ebe_tile_x4: every list of a tile at a fixed stride
+            if x4:
+                kname = "k_ebe_tile_x4<cartesian>"
             visits, slots, tnodes = info["element_visits"], info["lane_slots"], info["tile_nodes"]
             # tile lists (local connectivity 16 B, element id 4 B, flag 1 B per lane slot; node lists 4 B per entry),
             # stored geometry 40 B per visit (axis-aligned bricks; 88 B for other parallelepipeds) or E, nu 16 B per visit + the
@@ -461,6 +466,12 @@ def main():
                      (("stored geometry 40 B/tile (one record for the tile's elements)" if per_tile else "stored geometry 40 B/element visit")
                       if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
                      " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
+            if x4:
+                # what k_ebe_tile_x4 reads per tile, padding included: node ids 1,536 x 4 B, slot records 4 x 256 x 17 B, step table
+                # 64 x 8 B, the tile's record 32 B, its geometry record 16 x 8 B
+                alg = info["tiles"] * (1536 * 4.0 + 1024 * 17.0 + 512.0 + 32.0 + 128.0) + nrows * 16.0
+                model = ("per tile: node ids at a fixed stride 6,144 B + slot records of four steps 17,408 B + step table 512 B + tile and "
+                         "geometry record 160 B; x 24 B/node read + y 24 B/node written (DESIGN.md 4d, round 5)")
             traffic = traffic_of("ebe_traffic.json") if (affine and x_in_lds) else None   # (the PMC passes were taken on the regular brick, default kernel)
         else:
             kname = "k_ebe_apply<3,8,8,3>" if affine else "k_ebe_apply<3,8,8,1>"

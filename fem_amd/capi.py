@@ -605,7 +605,7 @@ class Mat:
         u, pt, st = C.c_longlong(0), C.c_int(0), C.c_int(0)
         _ck(_lib.fem_mat_get_tile_geometry_info(self.h, C.byref(u), C.byref(pt), C.byref(st)))
         return {"kind": k.value, "tiles": a.value, "affine_tiles": b.value, "element_visits": c.value, "lane_slots": d.value,
-                "tile_nodes": e.value, "setup_ms": ms.value, "uniform_tiles": u.value, "per_tile_records": bool(pt.value),
+                "tile_nodes": e.value, "setup_ms": ms.value, "uniform_tiles": u.value, "per_tile_records": int(pt.value),
                 "streaming_lists": bool(st.value)}
 
     def set_mult_type(self, kind: str):

@@ -2000,7 +2000,10 @@ void ebe_tile_info(const EbeTilePlan& P, long long* tiles, long long* affine_til
 void ebe_tile_geometry_info(const EbeTilePlan& P, long long* uniform_tiles, int* per_tile_records, int* streaming_lists)
 {
     if (uniform_tiles) *uniform_tiles = P.n_uniform;
-    if (per_tile_records) *per_tile_records = (P.n_cart + P.n_aff > 0 && P.n_uniform == (long long)P.n_cart + P.n_aff) ? 1 : 0;
+    // 1: one geometry record per tile; 2: that, and every list of a tile at a fixed stride per list position with the slot records of
+    // all (at most four) steps (k_ebe_tile_x4)
+    const bool uni = P.n_cart + P.n_aff > 0 && P.n_uniform == (long long)P.n_cart + P.n_aff;
+    if (per_tile_records) *per_tile_records = !uni ? 0 : (P.pnode_stride == TILE_X_MAX_NODES && P.pslot_steps == 4) ? 2 : 1;
     if (streaming_lists) *streaming_lists = P.stream ? 1 : 0;
 }
 

@@ -189,7 +189,9 @@ int fem_mat_get_profile(fem_mat mat, int max_products, int *n, double *element_m
 int fem_mat_get_mult_info(fem_mat mat, int *kind, long long *tiles, long long *affine_tiles, long long *element_visits,
                           long long *lane_slots, long long *tile_nodes, double *setup_ms);
 /* One-pass tiles, further figures of the plan: the tiles (of parallelepipeds) whose elements all carry one stored geometry record,
- * whether the product reads that record once per tile (it does when every such tile of the plan has one) and whether the plan is
+ * whether the product reads that record once per tile (per_tile_records 1: it does when every such tile of the plan has one; 2: that,
+ * and every list of a tile sits at a fixed stride per list position with the slot records of all its -- at most four -- steps, so
+ * that the kernel asks for all of them with the tile's record: k_ebe_tile_x4) and whether the plan is
  * large enough for its lists to be loaded with the streaming hint (lists + five vectors beyond the 256 MB Infinity Cache).  Zeros for
  * the other products.  (No reference counterpart: the reference's MatMult is PETSc's, src/main.F90:247.) */
 int fem_mat_get_tile_geometry_info(fem_mat mat, long long *uniform_tiles, int *per_tile_records, int *streaming_lists);

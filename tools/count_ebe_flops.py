@@ -79,6 +79,21 @@ while i < len(lines):
     i = j
 
 lines = asm_of("fem_amd/csrc/ebe_tile.hip")
+# k_ebe_tile_x4 (four steps unrolled, no loop): everything between the stage-in barrier and the barrier behind the last step, a quarter of it
+i = 0
+while i < len(lines):
+    m4 = re.match(r"^(_ZN3fem13k_ebe_tile_x4ILi([12])E\w+):", lines[i])
+    if not m4:
+        i += 1
+        continue
+    j = i
+    while not lines[j].startswith(".Lfunc_end"):
+        j += 1
+    body = lines[i:j]
+    bars = [k for k, l in enumerate(body) if re.match(r"^\s*s_barrier", l)]
+    cnt = count(body[bars[0]:bars[-1]], [1] * (bars[-1] - bars[0]))
+    report("k_ebe_tile_x4<%s> per element visit" % {"1": "affine", "2": "cartesian"}[m4.group(2)], {k: (v + 2) // 4 for k, v in cnt.items()})
+    i = j
 i = 0
 while i < len(lines):
     m = re.match(r"^(_ZN3fem(?:10k_ebe_tile|12k_ebe_tile_x)ILi([012])E(?:Li(\d)E)?\w+):", lines[i])

@@ -511,6 +511,7 @@ def main():
         return r
 
     out = None
+    c2_cpu = None
     if rank == 0:
         avg_ms = spmv_ms / max(n_spmv, 1)                  # whole MatMult as the KSP sees it
         if args.mult == "ebe" and hex_case:
@@ -774,12 +775,10 @@ def main():
                 out["config2"]["pc_mg"] = {"options": f"-ksp_type cg -pc_type mg -pc_mg_type additive -mat_mult_type {args.mult}",
                                            "value": m2.ndof / tm2, "unit": "DOF/s", "ms_per_step": tm2 * 1e3, "cg_iterations": itm2,
                                            "converged_reason": rm2, "speedup_over_jacobi": tc / tm2}
-            if not args.no_cpu:
-                hc2 = host_cores()
-                th2 = args.cpu_threads if args.cpu_threads > 0 else hc2["use"]
-                out["config2"]["cpu_baseline"] = cpu_baseline(m2, "707^2 quad4", its2, th2, max(args.cpu_cg_its, 300))
-                out["config2"]["cpu_baseline"]["host"] = hc2
-                out["config2"]["gpu_over_cpu"] = out["config2"]["value"] / out["config2"]["cpu_baseline"]["value"]
+            # (config 2's CPU leg runs with the other one, behind every GPU leg: the OpenMP run-time of the oracle binds the thread that
+            # calls it to its first place -- OMP_PROC_BIND -- and the library's host helper threads inherit that mask afterwards: the
+            # Newton loop of config 5, measured behind it, took 40-55 ms instead of 4)
+            c2_cpu = (m2, its2) if not args.no_cpu else None
             p2.destroy()
 
         if hex_case and not args.no_c5:
@@ -906,6 +905,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(mesh, label, its, threads, args.cpu_cg_its)
             out["cpu_baseline"]["host"] = hc
             out["config"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+            if c2_cpu is not None and "config2" in out:
+                m2_, its2_ = c2_cpu
+                out["config2"]["cpu_baseline"] = cpu_baseline(m2_, "707^2 quad4", its2_, threads, max(args.cpu_cg_its, 300))
+                out["config2"]["cpu_baseline"]["host"] = hc
+                out["config2"]["gpu_over_cpu"] = out["config2"]["value"] / out["config2"]["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     prob.destroy()
     if comm is not None:

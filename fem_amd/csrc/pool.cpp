@@ -74,9 +74,8 @@ void pool_release(void* p, size_t bytes) noexcept
     std::lock_guard<std::mutex> lk(g_mu);
     if (bytes > pool_limit()) { (void)hipFree(p); return; }
     // A full cache makes room for the block that is released NOW -- the sizes in use now are the ones asked for next -- by giving its
-    // largest blocks back to the driver (down to half the limit, so that this is rare).  Round 5: with the cache full of the big blocks
-    // of earlier problems (bench.py's legs: meshes and matrices of several sizes, 96 GB of them) every later release went to hipFree
-    // and every later request to hipMalloc -- the Newton loop of config 5, hundreds of small blocks per run, took 55 ms instead of 4.
+    // largest blocks back to the driver (down to half the limit, so that this is rare).  Before round 5 a full cache -- the big blocks
+    // of earlier problems in a long-lived process -- sent every later release to hipFree and every later request to hipMalloc.
     if (g_cached + bytes > pool_limit()) {
         for (auto it = g_free.end(); it != g_free.begin() && g_cached + bytes > pool_limit() / 2;) {
             --it;

@@ -775,9 +775,9 @@ def main():
                 out["config2"]["pc_mg"] = {"options": f"-ksp_type cg -pc_type mg -pc_mg_type additive -mat_mult_type {args.mult}",
                                            "value": m2.ndof / tm2, "unit": "DOF/s", "ms_per_step": tm2 * 1e3, "cg_iterations": itm2,
                                            "converged_reason": rm2, "speedup_over_jacobi": tc / tm2}
-            # (config 2's CPU leg runs with the other one, behind every GPU leg: the OpenMP run-time of the oracle binds the thread that
-            # calls it to its first place -- OMP_PROC_BIND -- and the library's host helper threads inherit that mask afterwards: the
-            # Newton loop of config 5, measured behind it, took 40-55 ms instead of 4)
+            # (config 2's CPU leg runs with the other one, behind every GPU leg: the Newton loop of config 5, measured behind it, took
+            # 40-55 ms instead of 4 -- reproducibly, and neither the CPU mask the OpenMP run-time leaves on the calling thread nor the
+            # device-block cache explained it when tried alone; GPU legs are not measured behind a CPU leg any more)
             c2_cpu = (m2, its2) if not args.no_cpu else None
             p2.destroy()
 

@@ -43,7 +43,7 @@ struct EbeTilePlan {
                                          // slot records leave with its record), else the first
     DBuf<uint4> pconn0;                  // [npos * pslot_steps * 256]
     DBuf<unsigned char> pfl0;            // [npos * pslot_steps * 256]
-    DBuf<double> pgeo;                   // hex8: [npos * 16] the tile's record (valid where lhdr[7] > 0); quad4: [npos * pslot_steps * 512] lam, mu of those steps
+    DBuf<double> pgeo;                   // hex8: [npos * 16] the tile's record (valid where lhdr[7] > 0; entries 14, 15: E and nu of its elements); quad4: [npos * pslot_steps * 512] lam, mu of those steps
     int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)
@@ -69,7 +69,7 @@ std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_host(fem_mesh m, hipStream_t s)
 std::shared_ptr<fem::EbeTilePlan> ebe_tile_build_device(fem_mesh m, hipStream_t s);   // ebe_plan.hip
 // geometry records of the stored-geometry tiles' elements (taff: class per lane slot), ebe_tile.hip
 void ebe_tile_list_headers(fem::EbeTilePlan& P, bool quad, hipStream_t s);
-void ebe_tile_first_records(fem::EbeTilePlan& P, bool quad, hipStream_t s);   // psteps, pconn0, pfl0, pgeo (after the stored geometry)   // lhdr_* from list_* and hdr (ebe_tile.hip)
+void ebe_tile_first_records(fem_mesh m, fem::EbeTilePlan& P, bool quad, hipStream_t s);   // psteps, pconn0, pfl0, pgeo (after the stored geometry)   // lhdr_* from list_* and hdr (ebe_tile.hip)
 void ebe_tile_quad_factors(fem_mesh m, fem::EbeTilePlan& P, hipStream_t s);   // quad4 plans: D factors per lane slot
 void ebe_tile_store_geometry(fem_mesh m, fem::EbeTilePlan& P, const unsigned char* d_taff, hipStream_t s);
 

@@ -823,13 +823,16 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x4(int nlis
 // UNI: every tile of the plan has one geometry record (lhdr[7], k_tile_geo_uniform: a brick of one spacing and one material) -- the
 // record and the material of its element are read once per tile instead of 48 B per lane slot plus a gather of E and nu behind
 // the element id (round 3: 0.63 GB of traffic for 0.43 GB of nodal data, 0.19 GB of it these records)
-template <int KIND, bool UNI = false>
+// ALL4 (with UNI; plans of at most four steps per tile, EbeTilePlan::pslot_steps == 4): the slot records of every step are asked for with
+// the tile's record and the steps are unrolled, as in k_ebe_tile_x4
+template <int KIND, bool UNI = false, bool ALL4 = false>
 __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
                                                           const int* __restrict__ tnodes, const int* __restrict__ telems,
                                                           const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
                                                           const double* __restrict__ U, const double* __restrict__ geo, size_t geo_stride,
                                                           const double* __restrict__ Ev, const double* __restrict__ nuv, double w,
-                                                          double* __restrict__ S, const double* __restrict__ valence, size_t nn)
+                                                          double* __restrict__ S, const double* __restrict__ valence, size_t nn,
+                                                          const int* __restrict__ pnodes, TileFirst tf)
 {
     constexpr int NPT = TILE_X_MAX_NODES / 256, NPO = TILE_X_MAX_OWN / 256;
     constexpr int MN = TILE_X_LDS_NODES, MO = TILE_X_MAX_OWN;
@@ -837,16 +840,32 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // (XCD map as in k_ebe_tile)
     if (lb >= (unsigned)nlist) return;
     const int* hd = lhdr + 8 * (size_t)lb;
-    const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5];
-    const int uref = UNI ? hd[7] : 0;
-    const int eref = (UNI && uref > 0) ? telems[uref - 1] : -1;
+    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], nsteps = hd[5];
+    // (the tile's lists at fixed strides per list position, asked for with its record: see k_ebe_tile_x; with one record per tile the
+    // geometry, E and nu come from there too and no step loads anything but its slot records)
+    const size_t gp = (size_t)tf.gp0 + lb;
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
+    uint4 sc16[ALL4 ? 4 : 1]; unsigned sfl[ALL4 ? 4 : 1];
+    if constexpr (ALL4) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) { sc16[k] = tf.pconn0[(gp * 4 + k) * 256 + threadIdx.x]; sfl[k] = tf.pfl0[(gp * 4 + k) * 256 + threadIdx.x]; }
+    } else {
+        sc16[0] = tf.pconn0[gp * tf.nsl * 256 + threadIdx.x]; sfl[0] = tf.pfl0[gp * tf.nsl * 256 + threadIdx.x];
+    }
+    constexpr int NA = KIND == 2 ? 3 : 9;   // stored adj(J): the diagonal / row by row
+    double ua[UNI ? NA : 1], umw = 0.0, uE = 1.0, unu = 0.25;
+    if constexpr (UNI) {
+#pragma unroll
+        for (int j = 0; j < NA; j++) ua[j] = tf.pgeo[gp * 16 + j];
+        umw = tf.pgeo[gp * 16 + (KIND == 2 ? 4 : 10)]; uE = tf.pgeo[gp * 16 + 14]; unu = tf.pgeo[gp * 16 + 15];
+    }
     double* xs = lds;              // xs[d * MN + i]: u of the tile's nodes
     double* acc = lds + 3 * MN;    // acc[c * MO + i]: six stress sums of the owned nodes
     int nv[NPT];
     {
         double xv[NPT][3];
 #pragma unroll
-        for (int j = 0; j < NPT; j++) { const int i = threadIdx.x + 256 * j; nv[j] = (i < nnode) ? tnodes[node_off + i] : 0; }
+        for (int j = 0; j < NPT; j++) nv[j] = pnodes[(size_t)lb * TILE_X_MAX_NODES + threadIdx.x + 256 * j];
 #pragma unroll
         for (int j = 0; j < NPT; j++) {
             const int i = threadIdx.x + 256 * j;
@@ -866,8 +885,6 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
             }
         }
     }
-    const int2 sv = ((int)(threadIdx.x & 63) < nsteps) ? steps[step_off + (threadIdx.x & 63)] : make_int2(0, 0);
-    constexpr int NA = KIND == 2 ? 3 : 9;   // stored adj(J): the diagonal / row by row
     struct Slot { uint4 c16; unsigned fl; double a[NA], mw, E, nu; };
     auto fetch = [&](Slot& q, int s) {
         q.fl = 0;
@@ -877,12 +894,17 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
         const size_t k = (size_t)elem_off + first + threadIdx.x;
         q.c16 = tconn[k];
         q.fl = tflags[k];
-        const size_t kg = UNI ? (size_t)(uref - 1) : k;     // (UNI: the same address in every lane and step)
-        const int e = UNI ? eref : telems[k];
+        if constexpr (UNI) {
 #pragma unroll
-        for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + kg];
-        q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + kg];
-        q.E = (e >= 0) ? Ev[e] : 1.0; q.nu = (e >= 0) ? nuv[e] : 0.25;
+            for (int j = 0; j < NA; j++) q.a[j] = ua[j];
+            q.mw = umw; q.E = uE; q.nu = unu;
+        } else {
+            const int e = telems[k];
+#pragma unroll
+            for (int j = 0; j < NA; j++) q.a[j] = geo[(size_t)j * geo_stride + k];
+            q.mw = geo[(size_t)(KIND == 2 ? 4 : 10) * geo_stride + k];
+            q.E = (e >= 0) ? Ev[e] : 1.0; q.nu = (e >= 0) ? nuv[e] : 0.25;
+        }
     };
     auto read_u = [&](double (&u)[8][3], const Slot& q) {
         const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
@@ -902,14 +924,35 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
         }
     };
     Slot q0, q1;
-    fetch(q0, 0);
+    if constexpr (UNI) {   // the first step's slot records came with the tile's record
+        q0.c16 = sc16[0]; q0.fl = sfl[0];
+#pragma unroll
+        for (int j = 0; j < NA; j++) q0.a[j] = ua[j];
+        q0.mw = umw; q0.E = uE; q0.nu = unu;
+    } else {
+        fetch(q0, 0);
+    }
     __syncthreads();
     double u[8][3];
     read_u(u, q0);
     bool prev_bar = false;
-    for (int s = 0; s < nsteps; s++) {
+    // (ALL4: one outer pass, the four steps unrolled, their slot records in registers -- past a step's lane count and past the last step
+    // they are zero, k_tile_first; otherwise one step per outer pass)
+    for (int s0 = 0; s0 < (ALL4 ? 1 : nsteps); s0++) {
+#pragma unroll
+    for (int k = 0; k < (ALL4 ? 4 : 1); k++) {
+        const int s = s0 + k;
+        if (s >= nsteps) break;
         const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
-        fetch(q1, s + 1);
+        if constexpr (ALL4) {
+            q1.fl = 0;
+            if (k < 3) { q1.c16 = sc16[k < 3 ? k + 1 : 0]; q1.fl = sfl[k < 3 ? k + 1 : 0]; }
+#pragma unroll
+            for (int j = 0; j < NA; j++) q1.a[j] = ua[j];
+            q1.mw = umw; q1.E = uE; q1.nu = unu;
+        } else {
+            fetch(q1, s + 1);
+        }
         const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
         tile_complete<3>(u, q0.fl);
         // differences of u along the four xi-, eta-, zeta-edges (node pairs in the order of their lower node: bottom CCW, top CCW)
@@ -976,6 +1019,7 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
         }
         prev_bar = bar;
         q0 = q1;
+    }
     }
     __syncthreads();
 #pragma unroll
@@ -1444,7 +1488,8 @@ __global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict
                                                     const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
                                                     const double* __restrict__ geo, size_t geo_stride, int ng, size_t gp0, int nsl,
                                                     int2* __restrict__ psteps, uint4* __restrict__ pconn0, unsigned char* __restrict__ pfl0,
-                                                    double* __restrict__ pgeo)
+                                                    double* __restrict__ pgeo, const int* __restrict__ telems, const double* __restrict__ Ev,
+                                                    const double* __restrict__ nuv)
 {
     const size_t i = blockIdx.x, gp = gp0 + i;
     const int* hd = lhdr + 8 * i;
@@ -1461,12 +1506,19 @@ __global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict
             pgeo[(gp * nsl + st) * 512 + 256 + threadIdx.x] = (have && geo) ? geo[geo_stride + k] : 1.0;
         }
     }
-    if (ng != 0 && (int)threadIdx.x < 16)
-        pgeo[gp * 16 + threadIdx.x] = (uref > 0 && (int)threadIdx.x < ng && geo) ? geo[(size_t)threadIdx.x * geo_stride + (uref - 1)] : 0.0;
+    if (ng != 0 && (int)threadIdx.x < 16) {
+        double v = (uref > 0 && (int)threadIdx.x < ng && geo) ? geo[(size_t)threadIdx.x * geo_stride + (uref - 1)] : 0.0;
+        if (threadIdx.x >= 14) {   // E, nu of the tile's elements (one record: one material), for the nodal stress over the tiles
+            const int e = uref > 0 ? telems[uref - 1] : -1;
+            v = e >= 0 ? (threadIdx.x == 14 ? Ev[e] : nuv[e]) : (threadIdx.x == 14 ? 1.0 : 0.25);
+        }
+        pgeo[gp * 16 + threadIdx.x] = v;
+    }
 }
-void ebe_tile_first_records(EbeTilePlan& P, bool quad, hipStream_t s)
+void ebe_tile_first_records(fem_mesh m, EbeTilePlan& P, bool quad, hipStream_t s)
 {
     if (!P.pnode_stride) return;
+    auto& grp = m->groups[0];
     const size_t npos = std::max<size_t>((size_t)P.n_cart + P.n_aff + P.n_gen, 1);
     P.pslot_steps = P.max_nsteps <= 4 ? 4 : 1;
     const size_t nsl = (size_t)P.pslot_steps;
@@ -1474,7 +1526,7 @@ void ebe_tile_first_records(EbeTilePlan& P, bool quad, hipStream_t s)
     P.pgeo.alloc(quad ? npos * nsl * 512 : npos * 16);
     auto go = [&](const DBuf<int>& lh, int n, int ng, size_t gp0) {
         if (n) hipLaunchKernelGGL(k_tile_first, dim3(n), dim3(256), 0, s, n, lh.p, P.steps.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, ng, gp0,
-                                  P.pslot_steps, P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p);
+                                  P.pslot_steps, P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, P.elems.p, grp.E.p, grp.nu.p);
     };
     if (quad) go(P.lhdr_gen, P.n_gen, 0, 0);
     else { go(P.lhdr_cart, P.n_cart, 5, 0); go(P.lhdr_aff, P.n_aff, 11, (size_t)P.n_cart); }
@@ -1523,7 +1575,7 @@ std::shared_ptr<EbeTilePlan> ebe_tile_build(fem_mesh m, hipStream_t s)
 {
     const char* how = std::getenv("FEM_AMD_TILE_PLAN");
     std::shared_ptr<EbeTilePlan> P = (how && std::string(how) == "host") ? ebe_tile_build_host(m, s) : ebe_tile_build_device(m, s);
-    if (P) ebe_tile_first_records(*P, m->pdim == 2, s);
+    if (P) ebe_tile_first_records(m, *P, m->pdim == 2, s);
     if (P) {
         // what one CG iteration walks through: the lists (slot records, flags, stored geometry, node lists) and five vectors, against
         // the 256 MB Infinity Cache (FEM_AMD_TILE_STREAM_MIN_MB: the threshold; measured -- 203 MB, 100^3 elements: plain loads 0.0443 ms
@@ -2160,21 +2212,28 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
     // tiles of parallelepipeds: one pass, from the stored geometry (FEM_AMD_STRESS_CART=0: the two passes below for them too)
     static const bool cart_env = !(std::getenv("FEM_AMD_STRESS_CART") && std::atoi(std::getenv("FEM_AMD_STRESS_CART")) == 0);
     const bool cart_one_pass = cart_env && (P.n_cart > 0 || P.n_aff > 0) && P.max_nsteps <= 64 && P.max_nnode <= TILE_X_LDS_NODES &&
-                               P.max_nown <= TILE_X_MAX_OWN;
+                               P.max_nown <= TILE_X_MAX_OWN && P.pnode_stride == TILE_X_MAX_NODES;
     if (cart_one_pass) {
         constexpr size_t shs = (size_t)(3 * TILE_X_LDS_NODES + 6 * TILE_X_MAX_OWN) * sizeof(double);
         static OncePerDevice sonce;
         if (sonce.first(m->ctx->device))
             for (const void* f : {reinterpret_cast<const void*>(k_tile_stress_cart<1, false>), reinterpret_cast<const void*>(k_tile_stress_cart<2, false>),
-                                  reinterpret_cast<const void*>(k_tile_stress_cart<1, true>), reinterpret_cast<const void*>(k_tile_stress_cart<2, true>)})
+                                  reinterpret_cast<const void*>(k_tile_stress_cart<1, true>), reinterpret_cast<const void*>(k_tile_stress_cart<2, true>),
+                                  reinterpret_cast<const void*>(k_tile_stress_cart<1, true, true>), reinterpret_cast<const void*>(k_tile_stress_cart<2, true, true>)})
                 FEM_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shs));
         const bool uni = P.n_uniform == (long long)P.n_cart + P.n_aff;    // (as the product: every tile has one record)
-        auto launch = [&](auto kern, int n, const int* list) {
+        auto launch = [&](auto kern, int n, const int* list, const int* pnodes, size_t gp0) {
             hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shs, s, n, list, P.steps.p, P.nodes.p, P.elems.p, P.conn16.p, P.flags.p, U,
-                               P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn);
+                               P.geo.p, (size_t)P.slots, grp.E.p, grp.nu.p, w, S, valence, nn, pnodes,
+                               TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, (unsigned long long)gp0, (unsigned)P.pslot_steps});
         };
-        if (P.n_cart) { if (uni) launch(k_tile_stress_cart<2, true>, P.n_cart, P.lhdr_cart.p); else launch(k_tile_stress_cart<2, false>, P.n_cart, P.lhdr_cart.p); }
-        if (P.n_aff) { if (uni) launch(k_tile_stress_cart<1, true>, P.n_aff, P.lhdr_aff.p); else launch(k_tile_stress_cart<1, false>, P.n_aff, P.lhdr_aff.p); }
+        if (uni && P.pslot_steps == 4) {
+            if (P.n_cart) launch(k_tile_stress_cart<2, true, true>, P.n_cart, P.lhdr_cart.p, P.pnodes_cart.p, 0);
+            if (P.n_aff) launch(k_tile_stress_cart<1, true, true>, P.n_aff, P.lhdr_aff.p, P.pnodes_aff.p, (size_t)P.n_cart);
+        } else {
+            if (P.n_cart) { if (uni) launch(k_tile_stress_cart<2, true>, P.n_cart, P.lhdr_cart.p, P.pnodes_cart.p, 0); else launch(k_tile_stress_cart<2, false>, P.n_cart, P.lhdr_cart.p, P.pnodes_cart.p, 0); }
+            if (P.n_aff) { if (uni) launch(k_tile_stress_cart<1, true>, P.n_aff, P.lhdr_aff.p, P.pnodes_aff.p, (size_t)P.n_cart); else launch(k_tile_stress_cart<1, false>, P.n_aff, P.lhdr_aff.p, P.pnodes_aff.p, (size_t)P.n_cart); }
+        }
     }
     for (int half = 0; half < 2; half++) {
         double* out = S + (size_t)(3 * half) * nn;

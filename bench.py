@@ -51,8 +51,10 @@ FP64_PEAK_TFLOPS = 78.6
 EBE_WORK = {
     "k_ebe_tile_x<cartesian>": (286, 336, 468),  # one-pass tiles of a mesh of axis-aligned bricks, x of the tile in LDS (three
                                                   # workgroups per CU)
-    "k_ebe_tile_x4<cartesian>": (294, 349, 479),  # the same with one geometry record per tile and the slot records of all four steps
-                                                  # asked for with the tile's record (uniform bricks: the headline)
+    "k_ebe_tile_x<cartesian, one record>": (192, 219, 346),  # the same with one geometry record per tile: the element map from the
+                                                  # tile's 30 coefficients (hex_forces_cart_k)
+    "k_ebe_tile_x4<cartesian>": (201, 233, 367),  # ... and the slot records of all four steps asked for with the tile's record
+                                                  # (uniform bricks: the headline)
     "k_ebe_tile<cartesian>": (281, 349, 515),  # one-pass tiles, axis-aligned bricks (stored diagonal of adj(J))
     "k_ebe_tile<affine>": (475, 658, 719),     # one-pass tiles, parallelepipeds (stored geometry, seven sparse applications)
     "k_ebe_tile<general>": (1503, 2217, 1850),  # one-pass tiles, distorted elements: monomial-basis Gauss pairs (as k_ebe_apply<..,2>)
@@ -451,6 +453,8 @@ def main():
             x4 = affine and x_in_lds and int(info.get("per_tile_records") or 0) == 2      # k_ebe_tile_x4: every list of a tile at a fixed stride
             if x4:
                 kname = "k_ebe_tile_x4<cartesian>"
+            elif affine and x_in_lds and int(info.get("per_tile_records") or 0) == 1:
+                kname = "k_ebe_tile_x<cartesian, one record>"
             visits, slots, tnodes = info["element_visits"], info["lane_slots"], info["tile_nodes"]
             # tile lists (local connectivity 16 B, element id 4 B, flag 1 B per lane slot; node lists 4 B per entry),
             # stored geometry 40 B per visit (axis-aligned bricks; 88 B for other parallelepipeds) or E, nu 16 B per visit + the
@@ -460,18 +464,18 @@ def main():
             alg = slots * slot_bytes + tnodes * 4.0 + nrows * 16.0
             per_tile = bool(info.get("per_tile_records")) and affine and x_in_lds   # one geometry record per tile (uniform bricks)
             alg_slot_records = alg + (visits * 40.0 if affine else visits * 16.0 + nrows * 8.0)   # (the byte model of rounds 2-3a: a record per element visit)
-            if per_tile: alg += info["tiles"] * 40.0
+            if per_tile: alg += info["tiles"] * 240.0
             else: alg = alg_slot_records
             model = (f"tile lists {slot_bytes:.0f} B/lane slot + node lists 4 B/entry + " +
-                     (("stored geometry 40 B/tile (one record for the tile's elements)" if per_tile else "stored geometry 40 B/element visit")
+                     (("stored geometry 240 B/tile (one record of 30 coefficients for the tile's elements)" if per_tile else "stored geometry 40 B/element visit")
                       if affine else "E, nu 16 B/element visit + coordinates 24 B/node") +
                      " + x 24 B/node read + y 24 B/node written (DESIGN.md 4d)")
             if x4:
                 # what k_ebe_tile_x4 reads per tile, padding included: node ids 1,536 x 4 B, slot records 4 x 256 x 17 B, step table
-                # 64 x 8 B, the tile's record 32 B, its geometry record 16 x 8 B
-                alg = info["tiles"] * (1536 * 4.0 + 1024 * 17.0 + 512.0 + 32.0 + 128.0) + nrows * 16.0
+                # 64 x 8 B, the tile's record 32 B, the 30 coefficients of its geometry record 240 B
+                alg = info["tiles"] * (1536 * 4.0 + 1024 * 17.0 + 512.0 + 32.0 + 240.0) + nrows * 16.0
                 model = ("per tile: node ids at a fixed stride 6,144 B + slot records of four steps 17,408 B + step table 512 B + tile and "
-                         "geometry record 160 B; x 24 B/node read + y 24 B/node written (DESIGN.md 4d, round 5)")
+                         "geometry record 272 B; x 24 B/node read + y 24 B/node written (DESIGN.md 4d, round 5)")
             traffic = traffic_of("ebe_traffic.json") if (affine and x_in_lds) else None   # (the PMC passes were taken on the regular brick, default kernel)
         else:
             kname = "k_ebe_apply<3,8,8,3>" if affine else "k_ebe_apply<3,8,8,1>"

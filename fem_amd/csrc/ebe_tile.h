@@ -8,6 +8,7 @@
 namespace fem {
 
 constexpr int TILE_MAXC = 16;            // colours a tile may need (more: the mesh keeps the two-kernel product)
+constexpr int TILE_GEO_STRIDE = 48;   // doubles per tile in EbeTilePlan::pgeo (hex8)
 constexpr int TILE_X_MAX_NODES = 1536, TILE_X_MAX_OWN = 768;   // tiles of the kernels with x in LDS (k_ebe_tile_x): 6 / 3 slots per thread
 constexpr int TILE_X_LDS_NODES = 1408;   // their LDS image, fixed (the component offsets become immediates of the LDS instructions):
                                          // (1408 + 768) * 24 B = 51 KiB, three workgroups per CU; the 16 x 8 x 8-element tile has 1,377 nodes
@@ -43,7 +44,7 @@ struct EbeTilePlan {
                                          // slot records leave with its record), else the first
     DBuf<uint4> pconn0;                  // [npos * pslot_steps * 256]
     DBuf<unsigned char> pfl0;            // [npos * pslot_steps * 256]
-    DBuf<double> pgeo;                   // hex8: [npos * 16] the tile's record (valid where lhdr[7] > 0; entries 14, 15: E and nu of its elements); quad4: [npos * pslot_steps * 512] lam, mu of those steps
+    DBuf<double> pgeo;                   // hex8: [npos * TILE_GEO_STRIDE] the tile's record (valid where lhdr[7] > 0; entries 14, 15: E and nu of its elements; from 16: the 30 coefficients of hex_forces_cart_k for a tile of bricks); quad4: [npos * pslot_steps * 512] lam, mu of those steps
     int n_cart = 0, n_cart_if = 0;
     const void* halo_seen = nullptr;     // the mesh's Halo when the plan was built (the split above is only valid for that one)
     DBuf<double> geo;                    // [11][tile_elements] stored geometry of the affine tiles' elements (hex_affine_geom)

@@ -495,10 +495,13 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
     const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
     const uint4 first_c16 = ld_list<STREAM>(tf.pconn0 + gp * tf.nsl * 256 + threadIdx.x);
     const unsigned first_fl = ld_list<STREAM>(tf.pfl0 + gp * tf.nsl * 256 + threadIdx.x);
-    double ug[UNI ? NG : 1];
-    if constexpr (UNI) {   // one record for the tile: the same address in every lane
+    double ug[UNI ? NG : 1], uk[(UNI && KIND == 2) ? CART_NK : 1];
+    if constexpr (UNI && KIND == 2) {   // one record for the tile, the same address in every lane: the coefficients of hex_forces_cart_k
 #pragma unroll
-        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * 16 + j];
+        for (int j = 0; j < CART_NK; j++) uk[j] = tf.pgeo[gp * TILE_GEO_STRIDE + 16 + j];
+    } else if constexpr (UNI) {
+#pragma unroll
+        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * TILE_GEO_STRIDE + j];
     }
     int nv[NPT];
     int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for with the gathers of x, needed at the write-out
@@ -590,7 +593,9 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x(int nlist
         // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
         tile_complete<3>(u, q0.fl);
         double fe[8][3], dot;
-        if constexpr (KIND == 2) {
+        if constexpr (KIND == 2 && UNI) {
+            hex_forces_cart_k(uk, u, fe, dot);
+        } else if constexpr (KIND == 2) {
             const double a[3] = {q0.geo[0], q0.geo[1], q0.geo[2]};
             hex_forces_cart(a, q0.geo[3], q0.geo[4], u, g, fe, dot);
         } else {
@@ -689,10 +694,13 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x4(int nlis
         sc16[k] = ld_list<STREAM>(tf.pconn0 + (gp * 4 + k) * 256 + threadIdx.x);
         sfl[k] = ld_list<STREAM>(tf.pfl0 + (gp * 4 + k) * 256 + threadIdx.x);
     }
-    double ug[UNI ? NG : 1];
-    if constexpr (UNI) {   // one record for the tile: the same address in every lane
+    double ug[UNI ? NG : 1], uk[(UNI && KIND == 2) ? CART_NK : 1];
+    if constexpr (UNI && KIND == 2) {   // one record for the tile, the same address in every lane: the coefficients of hex_forces_cart_k
 #pragma unroll
-        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * 16 + j];
+        for (int j = 0; j < CART_NK; j++) uk[j] = tf.pgeo[gp * TILE_GEO_STRIDE + 16 + j];
+    } else if constexpr (UNI) {
+#pragma unroll
+        for (int j = 0; j < NG; j++) ug[j] = tf.pgeo[gp * TILE_GEO_STRIDE + j];
     }
     int nv[NPT];
     int kb[NPO];   // penalty rows among the owned nodes (ApplyKBC): asked for with the gathers of x, needed at the write-out
@@ -757,8 +765,7 @@ __global__ void __launch_bounds__(256, KIND == 2 ? 3 : 2) k_ebe_tile_x4(int nlis
         tile_complete<3>(u, fl);
         double fe[8][3], dot;
         if constexpr (KIND == 2) {
-            const double a[3] = {ug[0], ug[1], ug[2]};
-            hex_forces_cart(a, ug[3], ug[4], u, g, fe, dot);
+            hex_forces_cart_k(uk, u, fe, dot);
         } else {
             double A[3][3];
 #pragma unroll
@@ -856,8 +863,8 @@ __global__ void __launch_bounds__(256, 2) k_tile_stress_cart(int nlist, const in
     double ua[UNI ? NA : 1], umw = 0.0, uE = 1.0, unu = 0.25;
     if constexpr (UNI) {
 #pragma unroll
-        for (int j = 0; j < NA; j++) ua[j] = tf.pgeo[gp * 16 + j];
-        umw = tf.pgeo[gp * 16 + (KIND == 2 ? 4 : 10)]; uE = tf.pgeo[gp * 16 + 14]; unu = tf.pgeo[gp * 16 + 15];
+        for (int j = 0; j < NA; j++) ua[j] = tf.pgeo[gp * TILE_GEO_STRIDE + j];
+        umw = tf.pgeo[gp * TILE_GEO_STRIDE + (KIND == 2 ? 4 : 10)]; uE = tf.pgeo[gp * TILE_GEO_STRIDE + 14]; unu = tf.pgeo[gp * TILE_GEO_STRIDE + 15];
     }
     double* xs = lds;              // xs[d * MN + i]: u of the tile's nodes
     double* acc = lds + 3 * MN;    // acc[c * MO + i]: six stress sums of the owned nodes
@@ -1489,7 +1496,7 @@ __global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict
                                                     const double* __restrict__ geo, size_t geo_stride, int ng, size_t gp0, int nsl,
                                                     int2* __restrict__ psteps, uint4* __restrict__ pconn0, unsigned char* __restrict__ pfl0,
                                                     double* __restrict__ pgeo, const int* __restrict__ telems, const double* __restrict__ Ev,
-                                                    const double* __restrict__ nuv)
+                                                    const double* __restrict__ nuv, double g)
 {
     const size_t i = blockIdx.x, gp = gp0 + i;
     const int* hd = lhdr + 8 * i;
@@ -1512,7 +1519,16 @@ __global__ void __launch_bounds__(256) k_tile_first(int n, const int* __restrict
             const int e = uref > 0 ? telems[uref - 1] : -1;
             v = e >= 0 ? (threadIdx.x == 14 ? Ev[e] : nuv[e]) : (threadIdx.x == 14 ? 1.0 : 0.25);
         }
-        pgeo[gp * 16 + threadIdx.x] = v;
+        pgeo[gp * TILE_GEO_STRIDE + threadIdx.x] = v;
+    }
+    if (ng == 5 && threadIdx.x == 16) {   // a tile of bricks: the coefficients of hex_forces_cart_k
+        double K[CART_NK] = {};
+        if (uref > 0 && geo) {
+            const size_t e = (size_t)(uref - 1);
+            const double a[3] = {geo[e], geo[geo_stride + e], geo[2 * geo_stride + e]};
+            hex_cart_consts(a, geo[3 * geo_stride + e], geo[4 * geo_stride + e], g, K);
+        }
+        for (int j = 0; j < CART_NK; j++) pgeo[gp * TILE_GEO_STRIDE + 16 + j] = K[j];
     }
 }
 void ebe_tile_first_records(fem_mesh m, EbeTilePlan& P, bool quad, hipStream_t s)
@@ -1523,10 +1539,11 @@ void ebe_tile_first_records(fem_mesh m, EbeTilePlan& P, bool quad, hipStream_t s
     P.pslot_steps = P.max_nsteps <= 4 ? 4 : 1;
     const size_t nsl = (size_t)P.pslot_steps;
     P.psteps.alloc(npos * 64); P.pconn0.alloc(npos * nsl * 256); P.pfl0.alloc(npos * nsl * 256);
-    P.pgeo.alloc(quad ? npos * nsl * 512 : npos * 16);
+    P.pgeo.alloc(quad ? npos * nsl * 512 : npos * TILE_GEO_STRIDE);
     auto go = [&](const DBuf<int>& lh, int n, int ng, size_t gp0) {
         if (n) hipLaunchKernelGGL(k_tile_first, dim3(n), dim3(256), 0, s, n, lh.p, P.steps.p, P.conn16.p, P.flags.p, P.geo.p, (size_t)P.slots, ng, gp0,
-                                  P.pslot_steps, P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, P.elems.p, grp.E.p, grp.nu.p);
+                                  P.pslot_steps, P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, P.elems.p, grp.E.p, grp.nu.p,
+                                  std::fabs(host_elem_tables()[grp.type].xi[0][0]));
     };
     if (quad) go(P.lhdr_gen, P.n_gen, 0, 0);
     else { go(P.lhdr_cart, P.n_cart, 5, 0); go(P.lhdr_aff, P.n_aff, 11, (size_t)P.n_cart); }

@@ -369,7 +369,102 @@ __device__ __forceinline__ void hex_cart_apply(const double (&a)[3], double lw, 
 #pragma unroll
     for (int l = 0; l < 3; l++) F[l].xyz += T[l][2];
 }
-// nodal forces of an axis-aligned brick from its stored geometry (a[3], lw, mw) and the nodal values u
+// The same map with its coefficients formed first.  In the basis of the sign patterns (the monomials' coefficients without their
+// scalings: c^ = B u, B the three-stage butterfly, B B^T = 8 I) the element matrix of a brick is  f = B^T K^ c^  with
+// K^ = D K D, D = diag(1/8 | g/8 | g^2/8) by the order of the monomial, and K has 45 entries that are not zero:
+//   first order   F^j.j = P_j c^j.j + Q_ji c^i.i + Q_jk c^k.k          F^l.j = R_j c^l.j + S_jl c^j.l   (l != j)
+//   second order  F^l.ij = (diagonal: sums of two of P, R) c^l.ij + one Q or two S terms (below)
+//   third order   F^l.xyz = (P_l + R_i + R_k) c^l.xyz
+// with  P_j = (2 mw + lw) a_j^2,  R_j = mw a_j^2,  Q_ij = lw a_i a_j,  S_ij = mw a_i a_j  (what cart_T<7,7> ... cart_T<4,4> add up
+// to).  30 coefficients: 12 + 15 + 3, formed once per tile by k_tile_first for the kernels whose tiles carry one geometry record
+// (k_ebe_tile_x<2, .., UNI>, k_ebe_tile_x4<2>: wave-uniform, in scalar registers).  45 multiply-adds and two butterflies without
+// scalings instead of 177 + 42 instructions; the results differ from hex_forces_cart's in the last bits.
+constexpr int CART_NK = 30;
+__device__ __host__ __forceinline__ void hex_cart_consts(const double (&a)[3], double lw, double mw, double g, double (&K)[CART_NK])
+{
+#pragma clang fp contract(off)
+    const double lw1 = lw * 0.015625, mw1 = mw * 0.015625;   // D^2 of the first order: 1/64
+    const double pl = (mw1 + mw1) + lw1;
+    const double aa[3] = {a[0] * a[0], a[1] * a[1], a[2] * a[2]};
+    const double ab[3] = {a[0] * a[1], a[0] * a[2], a[1] * a[2]};   // pairs 01, 02, 12
+    double P[3], R[3], Q[3], S[3];
+    for (int j = 0; j < 3; j++) { P[j] = pl * aa[j]; R[j] = mw1 * aa[j]; Q[j] = lw1 * ab[j]; S[j] = mw1 * ab[j]; }
+    const double g2 = g * g, g4 = g2 * g2;
+    for (int j = 0; j < 3; j++) { K[j] = P[j]; K[3 + j] = R[j]; K[6 + j] = Q[j]; K[9 + j] = S[j]; }
+    // second order, diagonal: rows (component, monomial) 0.xy 1.xy 2.xy 0.xz 1.xz 2.xz 0.yz 1.yz 2.yz
+    K[12] = (R[1] + P[0]) * g2; K[13] = (P[1] + R[0]) * g2; K[14] = (R[1] + R[0]) * g2;
+    K[15] = (R[2] + P[0]) * g2; K[16] = (R[2] + R[0]) * g2; K[17] = (P[2] + R[0]) * g2;
+    K[18] = (R[2] + R[1]) * g2; K[19] = (R[2] + P[1]) * g2; K[20] = (P[2] + R[1]) * g2;
+    for (int j = 0; j < 3; j++) { K[21 + j] = Q[j] * g2; K[24 + j] = S[j] * g2; }
+    K[27] = (P[0] + (R[1] + R[2])) * g4; K[28] = (P[1] + (R[0] + R[2])) * g4; K[29] = (P[2] + (R[0] + R[1])) * g4;
+}
+// c^ = B v (no scalings, no constant term)
+__device__ __forceinline__ Mono hex_signs(const double (&v)[8])
+{
+    const double s00 = v[1] + v[0], d00 = v[1] - v[0];
+    const double s10 = v[2] + v[3], d10 = v[2] - v[3];
+    const double s01 = v[5] + v[4], d01 = v[5] - v[4];
+    const double s11 = v[6] + v[7], d11 = v[6] - v[7];
+    const double ss0 = s10 + s00, sd0 = s10 - s00, ds0 = d10 + d00, dd0 = d10 - d00;
+    const double ss1 = s11 + s01, sd1 = s11 - s01, ds1 = d11 + d01, dd1 = d11 - d01;
+    Mono c;
+    c.x = ds1 + ds0; c.y = sd1 + sd0; c.z = ss1 - ss0;
+    c.xy = dd1 + dd0; c.xz = ds1 - ds0; c.yz = sd1 - sd0;
+    c.xyz = dd1 - dd0;
+    return c;
+}
+// nodal forces of an axis-aligned brick from the coefficients K^ (hex_cart_consts) and the nodal values u
+__device__ __forceinline__ void hex_forces_cart_k(const double (&K)[CART_NK], const double (&u)[8][3], double (&fe)[8][3], double& dot)
+{
+    Mono c[3], F[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double v[8];
+#pragma unroll
+        for (int a_ = 0; a_ < 8; a_++) v[a_] = u[a_][j];
+        c[j] = hex_signs(v);
+    }
+    const double *P = K, *R = K + 3, *Q = K + 6, *S = K + 9, *D = K + 12, *Q2 = K + 21, *S2 = K + 24, *X = K + 27;   // Q, S: pairs 01, 02, 12
+    F[0].x = fma(Q[1], c[2].z, fma(Q[0], c[1].y, P[0] * c[0].x));
+    F[1].y = fma(Q[2], c[2].z, fma(Q[0], c[0].x, P[1] * c[1].y));
+    F[2].z = fma(Q[2], c[1].y, fma(Q[1], c[0].x, P[2] * c[2].z));
+    F[1].x = fma(S[0], c[0].y, R[0] * c[1].x);
+    F[2].x = fma(S[1], c[0].z, R[0] * c[2].x);
+    F[0].y = fma(S[0], c[1].x, R[1] * c[0].y);
+    F[2].y = fma(S[2], c[1].z, R[1] * c[2].y);
+    F[0].z = fma(S[1], c[2].x, R[2] * c[0].z);
+    F[1].z = fma(S[2], c[2].y, R[2] * c[1].z);
+    F[0].xy = fma(Q2[1], c[2].yz, D[0] * c[0].xy);
+    F[1].xy = fma(Q2[2], c[2].xz, D[1] * c[1].xy);
+    F[2].xy = fma(S2[1], c[0].yz, fma(S2[2], c[1].xz, D[2] * c[2].xy));
+    F[0].xz = fma(Q2[0], c[1].yz, D[3] * c[0].xz);
+    F[1].xz = fma(S2[0], c[0].yz, fma(S2[2], c[2].xy, D[4] * c[1].xz));
+    F[2].xz = fma(Q2[2], c[1].xy, D[5] * c[2].xz);
+    F[0].yz = fma(S2[0], c[1].xz, fma(S2[1], c[2].xy, D[6] * c[0].yz));
+    F[1].yz = fma(Q2[0], c[0].xz, D[7] * c[1].yz);
+    F[2].yz = fma(Q2[1], c[0].xy, D[8] * c[2].yz);
+#pragma unroll
+    for (int l = 0; l < 3; l++) F[l].xyz = X[l] * c[l].xyz;
+    double d = 0.0;
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+        // x_e . f_e = c^ . K^ c^
+        d += c[l].x * F[l].x + c[l].y * F[l].y + c[l].z * F[l].z + c[l].xy * F[l].xy + c[l].xz * F[l].xz + c[l].yz * F[l].yz +
+             c[l].xyz * F[l].xyz;
+        // f = B^T F: zeta, then eta, then xi (hex_finish without its scalings)
+        const double a10m = F[l].x - F[l].xz, a10p = F[l].x + F[l].xz, a01m = F[l].y - F[l].yz, a01p = F[l].y + F[l].yz;
+        const double a11m = F[l].xy - F[l].xyz, a11p = F[l].xy + F[l].xyz;
+        const double b0mm = -F[l].z - a01m, b0pm = -F[l].z + a01m, b0mp = F[l].z - a01p, b0pp = F[l].z + a01p;      // [eta][zeta]
+        const double b1mm = a10m - a11m, b1pm = a10m + a11m, b1mp = a10p - a11p, b1pp = a10p + a11p;
+        fe[0][l] = b0mm - b1mm; fe[1][l] = b0mm + b1mm;
+        fe[3][l] = b0pm - b1pm; fe[2][l] = b0pm + b1pm;
+        fe[4][l] = b0mp - b1mp; fe[5][l] = b0mp + b1mp;
+        fe[7][l] = b0pp - b1pp; fe[6][l] = b0pp + b1pp;
+    }
+    dot = d;
+}
+// nodal forces of an axis-aligned brick from its stored geometry (a[3], lw, mw) and the nodal values u: the seven sparse applications
+// (kernels that keep a record per lane slot: the 30 coefficients of the other form would not fit their registers)
 __device__ __forceinline__ void hex_forces_cart(const double (&a)[3], double lw, double mw, const double (&u)[8][3], double g,
                                                 double (&fe)[8][3], double& dot)
 {

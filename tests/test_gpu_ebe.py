@@ -434,8 +434,8 @@ def test_streaming_tile_kernels_give_the_same_product(gpu_ctx, name, monkeypatch
                                          ("hex_two_materials", False), ("hex_graded", False)])
 def test_one_geometry_record_per_tile(gpu_ctx, name, expect, monkeypatch):
     """Tiles whose elements share one stored geometry record (same spacing, same material) are marked by k_tile_geo_uniform; when
-    every tile of the plan is, the product reads the record once per tile (k_ebe_tile_x<.., UNI>, k_ebe_tile_x4): bitwise the product of the
-    slot-by-slot records (FEM_AMD_TILE_UNIFORM=0).  A second material, a graded spacing or a shear (records equal only up to rounding)
+    every tile of the plan is, the product reads the record once per tile (k_ebe_tile_x<.., UNI>, k_ebe_tile_x4): the product of the
+    slot-by-slot records (FEM_AMD_TILE_UNIFORM=0) to rounding.  A second material, a graded spacing or a shear (records equal only up to rounding)
     keep the per-slot records."""
     m = _meshes()[name]
     ys, infos = [], []
@@ -453,8 +453,15 @@ def test_one_geometry_record_per_tile(gpu_ctx, name, expect, monkeypatch):
     if expect:
         assert infos[1]["uniform_tiles"] == infos[1]["affine_tiles"] > 0
         # (no tile of these meshes has more than four steps: every list of a tile at a fixed stride, all slot records asked for with the
-        # tile's record -- k_ebe_tile_x4 -- and still the bits of the slot-by-slot kernel)
+        # tile's record -- k_ebe_tile_x4)
         assert infos[1]["per_tile_records"] == 2
     else:
         assert infos[1]["uniform_tiles"] < infos[1]["affine_tiles"]
-    assert np.array_equal(ys[0], ys[1])
+    if expect:
+        # tiles of bricks with one record: the element map from the tile's 30 coefficients (hex_forces_cart_k) -- the same product in
+        # another order of operations, equal to rounding; the penalty rows do not pass through it
+        free = np.abs(ys[0]) < 1e20
+        assert np.array_equal(ys[0][~free], ys[1][~free])
+        assert np.abs(ys[0][free] - ys[1][free]).max() <= 2e-14 * np.abs(ys[0][free]).max()
+    else:
+        assert np.array_equal(ys[0], ys[1])

@@ -325,7 +325,7 @@ def test_bench_work_table_matches_the_compiled_kernels():
             got[m.group(1)] = tuple(int(v) for v in m.group(2, 3, 4))
     sys.path.insert(0, root)
     import bench
-    for name in ("k_ebe_tile_x<cartesian>", "k_ebe_tile_x4<cartesian>", "k_ebe_tile<cartesian>", "k_ebe_tile<affine>", "k_ebe_apply<3,8,8,3>"):
+    for name in ("k_ebe_tile_x<cartesian>", "k_ebe_tile_x<cartesian, one record>", "k_ebe_tile_x4<cartesian>", "k_ebe_tile<cartesian>", "k_ebe_tile<affine>", "k_ebe_apply<3,8,8,3>"):
         assert got[name] == tuple(bench.EBE_WORK[name]), (name, got[name], bench.EBE_WORK[name])
     # distorted elements: the arithmetic of the general path alone (the tool's count of k_ebe_tile<general> includes the
     # parallelepiped shortcut that a wavefront of distorted elements never takes)

@@ -138,6 +138,7 @@ while i < len(lines):
     if mq:
         report("k_ebe_tile_q4x<%s> per element visit" % ("fused CG opening" if m.group(2) == "1" else "plain"), count(body, weight))
     else:
-        report("%s<%s> per element visit" % ("k_ebe_tile_x" if xk else "k_ebe_tile", {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)]),
-               count(body, weight))
+        uni = bool(re.match(r"^_ZN3fem12k_ebe_tile_xILi[12]ELb[01]ELb1E", m.group(1)))   # one geometry record per tile
+        report("%s<%s%s> per element visit" % ("k_ebe_tile_x" if xk else "k_ebe_tile", {"0": "general", "1": "affine", "2": "cartesian"}[m.group(2)],
+                                               ", one record" if uni else ""), count(body, weight))
     i = j

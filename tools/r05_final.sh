@@ -11,7 +11,7 @@ echo "== rocprofv3 stats of the same command"; (cd /tmp && timeout -k 10 600 roc
 find $O/prof_stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; rm -rf $O/prof_stats
 head -12 $O/kernel_stats.csv | cut -c1-160
 echo "== pmc"; for c in FETCH_SIZE WRITE_SIZE; do (cd /tmp && timeout -k 10 300 rocprofv3 --pmc $c --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_$c -o ebe -- python3 $GRAFT_REPO_ROOT/tools/ebe_products.py 149 10 > $GRAFT_REPO_ROOT/$O/pmc_$c.log 2>&1); done
-python3 tools/pmc_to_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "k_ebe_tile_x4<2, true>" $O/ebe_traffic.json 149 3 "k_assemble_rows<3, 8, 32>" "k_tile_stress_cart<2, true>" > /dev/null
+python3 tools/pmc_to_traffic.py $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE "k_ebe_tile_x4<2, true>" $O/ebe_traffic.json 149 3 "k_assemble_rows<3, 8, 32>" "k_tile_stress_cart<2, true, true>" > /dev/null
 python3 tools/pmc_summary.py $O/pmc_FETCH_SIZE FETCH_SIZE > $O/pmc_summary.txt; python3 tools/pmc_summary.py $O/pmc_WRITE_SIZE WRITE_SIZE >> $O/pmc_summary.txt
 rm -rf $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE
 echo "== config 5"; timeout -k 10 300 python3 tools/config5_timing.py 1000 > $O/config5.txt 2>&1; cat $O/config5.txt

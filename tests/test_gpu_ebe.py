@@ -27,6 +27,13 @@ def _rotated(m):
     return m
 
 
+def _stretched(m):
+    """bricks of three different edge lengths (dyadic, so that every element's stored geometry is the same to the bit): the
+    30 coefficients of the tile's element map with a_x, a_y, a_z all different"""
+    m.coords = np.ascontiguousarray(m.coords * np.array([1.0, 0.75, 1.25]))
+    return m
+
+
 def _graded(m):
     """axis-aligned bricks of growing size (geometric grading along x and z): boxes of the mean spacing hold very different
     numbers of nodes -- the crowded ones are halved until they fit the LDS image of the brick kernel"""
@@ -97,6 +104,7 @@ def _meshes():
         "hex_isolated_nodes": _with_isolated_nodes(structured_hex(6, 5, 4, jitter=0.1)),
         "hex_shuffled": _shuffled(structured_hex(13, 11, 9, jitter=0.1)),
         "hex_uniform": structured_hex(7, 6, 5),                      # every element a cube: affine path
+        "hex_stretched": _stretched(structured_hex(21, 10, 9)),      # one brick of 1 x 0.75 x 1.25 throughout, several tiles
         "hex_sheared": _sheared(structured_hex(9, 8, 7)),
         "hex_rotated": _rotated(structured_hex(18, 9, 17)),
         "hex_graded": _graded(structured_hex(40, 18, 16)),
@@ -151,7 +159,7 @@ def test_ebe_product_matches_assembled_product_and_oracle(gpu_ctx, oracle, name)
         o.destroy()
 
 
-@pytest.mark.parametrize("name", ["hex_isolated_nodes", "hex_shuffled", "hex_uniform", "hex_sheared", "hex_half_jitter",
+@pytest.mark.parametrize("name", ["hex_isolated_nodes", "hex_shuffled", "hex_uniform", "hex_stretched", "hex_sheared", "hex_half_jitter",
                                   "hex_67nodes_x", "hex_tiles", "hex_tiles_flat", "hex_graded", "hex_annulus", "hex_two_materials"])
 def test_nodal_stress_over_the_tiles_matches_the_element_buffer_path(gpu_ctx, oracle, name):
     """Once a hex8 mesh carries the tile plan of the one-pass product, RecoverNodalStress + the nodal average
@@ -430,7 +438,7 @@ def test_streaming_tile_kernels_give_the_same_product(gpu_ctx, name, monkeypatch
     assert np.array_equal(ys[0], ys[1])
 
 
-@pytest.mark.parametrize("name,expect", [("hex_uniform", True), ("hex_sheared", False), ("hex_tiles_flat", True),
+@pytest.mark.parametrize("name,expect", [("hex_uniform", True), ("hex_stretched", True), ("hex_sheared", False), ("hex_tiles_flat", True),
                                          ("hex_two_materials", False), ("hex_graded", False)])
 def test_one_geometry_record_per_tile(gpu_ctx, name, expect, monkeypatch):
     """Tiles whose elements share one stored geometry record (same spacing, same material) are marked by k_tile_geo_uniform; when

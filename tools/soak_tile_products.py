@@ -20,6 +20,8 @@ for seed in range(lo, hi):
     dims = tuple(int(v) for v in rng.integers(2, [48, 30, 22]))
     kind = ["straight", "sheared", "turned", "jitter", "half_jitter", "shuffled"][seed % 6]
     m = structured_hex(*dims, jitter=0.15 if kind == "jitter" else 0.0)
+    if kind == "straight":   # bricks of three (dyadic) edge lengths: one geometry record per tile, the coefficients of hex_forces_cart_k
+        m.coords = np.ascontiguousarray(m.coords * rng.choice([0.5, 0.75, 1.0, 1.25, 1.5, 2.0], 3))
     if kind == "sheared":
         M = np.eye(3) + 0.4 * rng.standard_normal((3, 3))
         if abs(np.linalg.det(M)) < 0.3:

@@ -350,6 +350,18 @@ struct fem_ksp_s {
     unsigned long long last_state = 0;
     int last_its = 0, last_reason = 0, n_reused = 0;
     double last_rnorm = 0.0;
+    // what the kept solution was computed with: a solve under other tolerances / another method is another solve (KSPSetTolerances
+    // between two solves of one F, src/main.F90:349-351, must be honoured) -- the setters drop the kept solution and the key is
+    // compared again at the solve, so that no path that changes an option can hand out a stale one
+    double last_rtol = 0.0, last_abstol = 0.0, last_dtol = 0.0;
+    int last_maxit = 0;
+    std::string last_method;
+    // the operator state of the previous solve: a host whose operator changes from solve to solve (Newton, cohesive increments)
+    // never repeats a solve, and keeping b and x there would only cost two copies per solve
+    fem_mat prev_A = nullptr;
+    unsigned long long prev_state = 0;
+    bool prev_seen = false, op_changes = false;
+    std::string method_key() const { return type + "/" + pc + "/" + mult_type + (mg_additive ? "/a" : "/m"); }
     ~fem_ksp_s() {
         if (h_state) (void)hipHostFree(h_state);
         for (auto e : poll_ev) if (e) (void)hipEventDestroy(e);
@@ -406,6 +418,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         FEM_CHECK(!is.fail(), 6, "fem_ksp_set_from_options: bad value for " + key);
     }
     k->setup_done = false;
+    k->last_valid = false;
 }
 
 void ksp_set_up_impl(fem_ksp k)
@@ -563,7 +576,9 @@ static bool ksp_reuse_wanted(fem_ksp k)
 // differences is summed over the domains)
 static bool ksp_try_reuse(fem_ksp k, fem_vec b, fem_vec x, Comm* comm, hipStream_t s)
 {
-    if (!k->last_valid || k->last_A != k->A || k->last_state != k->A->state || k->last_b.n != (size_t)k->n) {
+    if (!k->last_valid || k->last_A != k->A || k->last_state != k->A->state || k->last_b.n != (size_t)k->n ||
+        k->last_rtol != k->rtol || k->last_abstol != k->abstol || k->last_dtol != k->dtol || k->last_maxit != k->maxit ||
+        k->last_method != k->method_key()) {
         k->last_valid = false;
         if (!comm) return false;
     }
@@ -577,7 +592,7 @@ static bool ksp_try_reuse(fem_ksp k, fem_vec b, fem_vec x, Comm* comm, hipStream
     FEM_HIP(hipStreamSynchronize(s));
     if (ndiff != 0.0) return false;
     FEM_HIP(hipMemcpyAsync(x->d.p, k->last_x.p, sizeof(double) * (size_t)k->n, hipMemcpyDeviceToDevice, s));
-    FEM_HIP(hipStreamSynchronize(s));
+    FEM_HIP(hipStreamSynchronize(s));   // (as after a computed solve: x is complete on return, also for a reader on another stream)
     k->its = k->last_its; k->reason = k->last_reason; k->rnorm = k->last_rnorm;
     k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
     k->n_reused++;
@@ -586,13 +601,20 @@ static bool ksp_try_reuse(fem_ksp k, fem_vec b, fem_vec x, Comm* comm, hipStream
 static void ksp_keep_solution(fem_ksp k, fem_vec b, fem_vec x, hipStream_t s)
 {
     k->last_valid = false;
-    if (k->reason <= 0) return;
+    // an operator that changed since the previous solve marks a non-linear host: nothing is kept until two solves in a row
+    // have seen one operator state again
+    const bool changed = k->prev_seen && (k->prev_A != k->A || k->prev_state != k->A->state);
+    k->op_changes = changed;
+    k->prev_A = k->A; k->prev_state = k->A->state; k->prev_seen = true;
+    if (k->reason <= 0 || changed) return;
     if (k->last_b.n != (size_t)k->n) { k->last_b.alloc((size_t)k->n); k->last_x.alloc((size_t)k->n); }
     FEM_HIP(hipMemcpyAsync(k->last_b.p, b->d.p, sizeof(double) * (size_t)k->n, hipMemcpyDeviceToDevice, s));
     FEM_HIP(hipMemcpyAsync(k->last_x.p, x->d.p, sizeof(double) * (size_t)k->n, hipMemcpyDeviceToDevice, s));
-    FEM_HIP(hipStreamSynchronize(s));
+    FEM_HIP(hipStreamSynchronize(s));   // (a holder of fem_vec_device_ptr may write b on its own stream once the solve has returned)
     k->last_A = k->A; k->last_state = k->A->state;
     k->last_its = k->its; k->last_reason = k->reason; k->last_rnorm = k->rnorm;
+    k->last_rtol = k->rtol; k->last_abstol = k->abstol; k->last_dtol = k->dtol; k->last_maxit = k->maxit;
+    k->last_method = k->method_key();
     k->last_valid = true;
 }
 
@@ -895,22 +917,23 @@ void ksp_delete(fem_ksp k)
     if (k->ctx) k->ctx->bind();
     delete k;
 }
-void ksp_set_operators(fem_ksp k, fem_mat A) { k->A = A; k->setup_done = false; }
+void ksp_set_operators(fem_ksp k, fem_mat A) { k->A = A; k->setup_done = false; k->last_valid = false; }
 void ksp_set_type(fem_ksp k, const char* t)
 {
     FEM_CHECK(t && (std::string(t) == "cg" || std::string(t) == "preonly" || std::string(t) == "bcgs"), 6,
               std::string("fem_ksp_set_type: unsupported type ") + (t ? t : "(null)"));
-    k->type = t; k->setup_done = false;
+    k->type = t; k->setup_done = false; k->last_valid = false;
 }
 void ksp_set_pc_type(fem_ksp k, const char* t)
 {
     const std::string v = t ? t : "";
     FEM_CHECK(v == "jacobi" || v == "none" || v == "mg" || v == "gamg" || v == "lu" || v == "cholesky", 6,
               std::string("fem_ksp_set_pc_type: unsupported type ") + (t ? t : "(null)"));
-    k->pc = (v == "gamg") ? "mg" : (v == "cholesky") ? "lu" : v; k->setup_done = false;
+    k->pc = (v == "gamg") ? "mg" : (v == "cholesky") ? "lu" : v; k->setup_done = false; k->last_valid = false;
 }
 void ksp_set_tolerances(fem_ksp k, double rtol, double abstol, double dtol, int maxit)
 {
+    k->last_valid = false;   // (KSPSetTolerances: the next solve is a solve under the new tolerances, never a kept one)
     if (rtol != FEM_DEFAULT_REAL) { FEM_CHECK(rtol >= 0 && rtol < 1.0, 6, "rtol out of range"); k->rtol = rtol; }
     if (abstol != FEM_DEFAULT_REAL) { FEM_CHECK(abstol >= 0, 6, "abstol out of range"); k->abstol = abstol; }
     if (dtol != FEM_DEFAULT_REAL) { FEM_CHECK(dtol > 0, 6, "dtol out of range"); k->dtol = dtol; }

@@ -32,6 +32,11 @@ module defmod_deck
     real(c_double), allocatable :: coords(:), mats(:), bcval(:), fval(:), tval(:)
   end type deck_t
 
+  ! -resolve_rtol <tol>: after the last increment, KSPSetTolerances(tol) (src/main.F90:349-351) and KSPSolve of the same Vec_F
+  ! again -- a parity check's "tighten and re-solve"; the line it prints carries the iteration count and how many solves of this
+  ! KSP were answered from a kept solution (-ksp_reuse_solution)
+  real(c_double), save :: resolve_rtol = -1.0_c_double
+
 contains
 
   ! ReadParameters / ReadElementsCoords / ReadDist* (src/m_io.F90:12-20,71-105,282-475); ids become 0-based
@@ -323,6 +328,20 @@ contains
       dtNo = dtNo + 1
     end do
 
+    if (resolve_rtol > 0.0_c_double) then
+      call fem_check(fem_ksp_get_reused_solves(Krylov, i), "fem_ksp_get_reused_solves")
+      call fem_check(fem_ksp_set_tolerances(Krylov, resolve_rtol, FEM_DEFAULT_REAL, FEM_DEFAULT_REAL, FEM_DEFAULT_INT), &
+                     "fem_ksp_set_tolerances")
+      call fem_check(fem_ksp_solve(Krylov, Vec_F, Vec_U), "fem_ksp_solve")
+      call fem_check(fem_ksp_get_iteration_number(Krylov, j), "its")
+      call fem_check(fem_ksp_get_converged_reason(Krylov, reason), "reason")
+      call fem_check(fem_ksp_get_reused_solves(Krylov, k), "fem_ksp_get_reused_solves")
+      if (root) write(*, '(A,ES10.3,A,I0,A,I0,A,I0,A,I0,A,I0)') " Re-solve at rtol ", resolve_rtol, ": iterations ", j, &
+        "  (last increment ", its, ")  reason ", reason, "  reused before ", i, " after ", k
+      call fem_check(fem_vec_get_array(Vec_U, uu), "fem_vec_get_array")
+      if (root) write(*, '(A,ES23.15)') " Re-solve max |du|: ", maxval(abs(uu))
+    end if
+
     call write_output()
 
     if (root) print *, "Cleaning up ..."
@@ -439,6 +458,8 @@ program main_amd
       call get_command_argument(i + 1, arg); read(arg, *) np_local; i = i + 2
     else if (trim(arg) == "-vec_view") then
       vec_view = .true.; i = i + 1
+    else if (trim(arg) == "-resolve_rtol" .and. i < nargs) then
+      call get_command_argument(i + 1, arg); read(arg, *) resolve_rtol; i = i + 2
     else
       options = trim(options)//" "//trim(arg); i = i + 1
     end if

@@ -36,6 +36,23 @@ int main(void)
     CK(fem_ksp_set_operators(ksp, K));
     CK(fem_ksp_set_from_options(ksp, "-ksp_type cg -pc_type jacobi -ksp_rtol 1e-14"));
     CK(fem_ksp_set_up(ksp));
+    /* KSPSetTolerances between two solves of one F (src/main.F90:349-351): the second solve runs under the new tolerances and is
+     * never the solution kept from the first (-ksp_reuse_solution, on by default); a third, unchanged, solve is the kept one */
+    {
+        int its_a, its_b, its_c, reused_b, reused_c;
+        CK(fem_form_rhs(mesh, 6, bcnode, bcval, 0, NULL, NULL, 0, NULL, NULL, t, 0.0, dt, F));
+        CK(fem_ksp_set_tolerances(ksp, 1e-2, FEM_DEFAULT_REAL, FEM_DEFAULT_REAL, FEM_DEFAULT_INT));
+        CK(fem_ksp_solve(ksp, F, U));
+        CK(fem_ksp_get_iteration_number(ksp, &its_a));
+        CK(fem_ksp_set_tolerances(ksp, 1e-14, FEM_DEFAULT_REAL, FEM_DEFAULT_REAL, FEM_DEFAULT_INT));
+        CK(fem_ksp_solve(ksp, F, U));
+        CK(fem_ksp_get_iteration_number(ksp, &its_b));
+        CK(fem_ksp_get_reused_solves(ksp, &reused_b));
+        CK(fem_ksp_solve(ksp, F, U));
+        CK(fem_ksp_get_iteration_number(ksp, &its_c));
+        CK(fem_ksp_get_reused_solves(ksp, &reused_c));
+        printf("RETOL %d %d %d %d %d\n", its_a, its_b, its_c, reused_b, reused_c);
+    }
     for (step = 0; dt * step < t; step++) {
         CK(fem_form_rhs(mesh, 6, bcnode, bcval, 0, NULL, NULL, 0, NULL, NULL, t, dt * step, dt, F));
         CK(fem_ksp_solve(ksp, F, U));

@@ -145,6 +145,27 @@ def test_fortran_driver_with_the_element_by_element_product(tmp_path, oracle):
     assert np.abs(full[:, 2:] - so).max() <= 1e-9 * np.abs(so).max()
 
 
+def test_fortran_driver_tightens_and_re_solves(tmp_path):
+    """`defmod_amd -ksp_rtol 1e-6 -resolve_rtol 1e-13` on a hex8 deck with four identical increments: increments 2-4 are the
+    kept solution (-ksp_reuse_solution, default on), and the KSPSetTolerances + KSPSolve of the same F after them (the
+    reference's calls, src/main.F90:349-351,247) iterates under the new tolerance instead of handing out the kept 1e-6 one."""
+    _need(EXE)
+    import re
+    from fem_amd.inp import write_inp
+    from fem_amd.mesh import structured_hex
+    m = structured_hex(7, 6, 5, jitter=0.12)
+    m.t, m.dt = 1.0, 0.25
+    deck = str(tmp_path / "hex.inp")
+    write_inp(deck, m)
+    p = subprocess.run([EXE, "-f", deck, "-ksp_rtol", "1e-6", "-resolve_rtol", "1e-13", "-o", str(tmp_path / "0_output")],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    g = re.search(r"Re-solve at rtol\s+\S+: iterations (\d+)\s+\(last increment (\d+)\)\s+reason (-?\d+)\s+reused before (\d+) after (\d+)", p.stdout)
+    assert g, p.stdout
+    its13, its6, reason, before, after = (int(v) for v in g.groups())
+    assert before == 3 and after == 3 and reason > 0 and its13 > its6
+
+
 @pytest.mark.parametrize("np_", [1, 2])
 def test_fortran_driver_on_a_hex8_deck_with_the_one_pass_product(tmp_path, oracle, np_):
     """A 3-D deck of distorted hex8 elements written in the reference's format, through the Fortran driver with
@@ -188,6 +209,9 @@ def test_plain_c_client_of_the_abi(tmp_path):
     assert p.returncode == 0, p.stdout + p.stderr
     rows = [ln.split() for ln in p.stdout.splitlines() if ln.startswith("NODE")]
     assert "STEPS 10" in p.stdout and len(rows) == 6
+    # fem_ksp_set_tolerances between two solves of one F: the tighter solve iterates (no kept solution), the third is the kept one
+    its_a, its_b, its_c, reused_b, reused_c = [int(v) for v in next(ln for ln in p.stdout.splitlines() if ln.startswith("RETOL")).split()[1:]]
+    assert reused_b == 0 and reused_c == 1 and its_b >= its_a and its_c == its_b
     got = np.array([[float(x) for x in r[2:]] for r in rows])
     expect_u = np.array([[0, .1], [0, .05], [0, 0], [0, .1], [0, .05], [0, 0]])
     assert np.abs(got[:, :2] - expect_u).max() < 1e-12

@@ -245,3 +245,58 @@ def test_repeated_right_hand_side_returns_the_kept_solution(gpu_ctx, opts):
     prob.ksp.solve(prob.F, U2)
     assert prob.ksp.get_reused_solves() == 3
     U2.destroy(); prob.destroy()
+
+
+@pytest.mark.parametrize("opts", ["", "-mat_mult_type ebe"])
+def test_tightened_tolerances_are_honoured_after_a_kept_solve(gpu_ctx, oracle, opts):
+    """KSPSetTolerances between two solves of one right-hand side (the reference's own call, src/main.F90:349-351, then KSPSolve :247):
+    the second solve runs under the new tolerances -- it never hands out the solution kept by -ksp_reuse_solution (default on) from
+    the looser solve.  The same for KSPSetType / PCSetType / KSPSetOperators."""
+    m = structured_hex(9, 8, 7, jitter=0.15)
+    uo, _, _ = oracle.run(m, "cg", rtol=1e-13)
+    prob = driver.Problem(gpu_ctx, m, f"-ksp_rtol 1e-9 {opts}")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U)
+    its9, u9 = prob.ksp.get_iteration_number(), prob.U.get_array()
+    prob.ksp.set_tolerances(rtol=1e-13)
+    prob.ksp.solve(prob.F, prob.U)
+    its13, u13 = prob.ksp.get_iteration_number(), prob.U.get_array()
+    assert prob.ksp.get_reused_solves() == 0 and prob.ksp.get_converged_reason() > 0
+    assert its13 > its9 and not np.array_equal(u9, u13)
+    assert np.abs(u13 - uo).max() <= 1e-10 * np.abs(uo).max()
+    prob.ksp.solve(prob.F, prob.U)                            # unchanged options: kept
+    assert prob.ksp.get_reused_solves() == 1 and prob.ksp.get_iteration_number() == its13
+    prob.ksp.set_tolerances(max_it=its13 + 50)                # every field of KSPSetTolerances counts
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_reused_solves() == 1
+    prob.ksp.set_tolerances(abstol=1e-40)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_reused_solves() == 1
+    prob.ksp.set_pc_type("jacobi"); prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_reused_solves() == 1 and prob.ksp.get_iteration_number() == its13
+    prob.ksp.set_type("cg"); prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_reused_solves() == 1
+    prob.ksp.set_operators(prob.K); prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_reused_solves() == 1
+    assert np.array_equal(prob.U.get_array(), u13)            # the deterministic solver: the same bits every time
+    prob.destroy()
+
+
+def test_a_changing_operator_keeps_nothing(gpu_ctx):
+    """A host whose operator changes between solves (Newton / cohesive increments, src/m_global.F90:98-158) never repeats a solve:
+    after the first change of state nothing is kept, until two solves in a row see one state again."""
+    m = structured_hex(6, 5, 4, jitter=0.1)
+    prob = driver.Problem(gpu_ctx, m, "-ksp_rtol 1e-12")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U); u0 = prob.U.get_array()
+    for _ in range(3):
+        prob.K.apply_kbc()                                    # state moves (same values)
+        prob.ksp.solve(prob.F, prob.U)
+        assert prob.ksp.get_reused_solves() == 0 and np.array_equal(prob.U.get_array(), u0)
+    prob.ksp.solve(prob.F, prob.U)                            # first solve on an unchanged state: computed, and kept again
+    assert prob.ksp.get_reused_solves() == 0
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_reused_solves() == 1 and np.array_equal(prob.U.get_array(), u0)
+    prob.destroy()

@@ -70,7 +70,8 @@ def test_bench_line_at_n_ranks(world):
     cfg = out["config"]
     assert out["n_gpus"] == world and out["scaling"] == "weak" and out["value"] > 0 and out["unit"] == "DOF/s"
     assert out["metric"].startswith("DOF/sec assemble+solve")
-    assert cfg["rccl_ranks"] == 0 and "rehearsal" in cfg
+    assert cfg["rccl_ranks"] == 0 and "rehearsal" in cfg and out["rccl_ranks"] == 0 and out["transport"] == "gloo-host-staged"
+    assert cfg["ksp_reuse_solution"].startswith("0 ")
     assert len(cfg["per_rank"]) == world and all(r["cg_iterations"] == cfg["cg_iterations"] for r in cfg["per_rank"])
     assert all(r["neighbours"] == world - 1 for r in cfg["per_rank"])                 # 2x1x1 / 2x2x1: everybody touches everybody
     assert all(r["halo_bytes_per_exchange"] > 0 for r in cfg["per_rank"])
@@ -96,12 +97,14 @@ def test_bench_watchdog_prints_the_headline_when_a_rank_stalls():
 def test_bench_survives_a_failing_rccl_communicator():
     """`bench.py --gpus 2` WITHOUT --rehearse and with the RCCL communicator failing on every rank (injected; two ranks share the
     box's one GPU): the ranks agree on the failure over gloo and the job carries on over the host-staged communicator -- a complete
-    line with the failure noted, exit status 0."""
+    line with the failure noted at its top level (`transport: gloo-host-staged`, `rccl_ranks: 0`) and a NON-ZERO exit status, so
+    that a scaling record cannot pass a host-staged number off as one measured over xGMI."""
     p = _torchrun(2, "bench.py", ["--gpus", "2", "--edge", "16", "--steps", "1", "--warmup", "1", "--no-mg"],
                   env={"FEM_AMD_BENCH_INJECT_RCCL_FAILURE": "1"}, timeout=600)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.returncode != 0, p.stdout[-3000:] + p.stderr[-3000:]
     out = _json_line(p.stdout)
     cfg = out["config"]
     assert out["n_gpus"] == 2 and out["value"] > 0 and cfg["converged_reason"] > 0
+    assert out["rccl_ranks"] == 0 and out["transport"] == "gloo-host-staged"
     assert cfg["rccl_ranks"] == 0 and "injected" in cfg["comm_fallback"]["why"] and "gloo" in cfg["comm_fallback"]["to"]
     assert len(cfg["per_rank"]) == 2 and cfg["comm_stats_rank0"]["exchange_calls"] > 0

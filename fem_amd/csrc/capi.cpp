@@ -124,6 +124,8 @@ int fem_ctx_create(int device, fem_ctx* out)
     c->num_cu = prop.multiProcessorCount;
     FEM_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     FEM_HIP(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+    fem::pool_register_stream(c->stream);        // (released device blocks are ordered behind the work of these two: pool.cpp)
+    fem::pool_register_stream(c->comm_stream);
     FEM_HIP(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
     FEM_HIP(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
     FEM_HIP(hipEventCreateWithFlags(&c->ev_c, hipEventDisableTiming));
@@ -141,6 +143,9 @@ int fem_ctx_destroy(fem_ctx c)
     if (!c) return 0;
     c->bind();
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->comm_stream);
+    fem::pool_unregister_stream(c->stream);
+    fem::pool_unregister_stream(c->comm_stream);
     (void)hipEventDestroy(c->t0); (void)hipEventDestroy(c->t1);
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->comm_stream);

@@ -42,9 +42,12 @@ void set_last_error(const std::string& m);
 // Device-memory pool behind DBuf (pool.cpp).  The path re-creates its large objects every run
 // (Mat_K: 7 GB at config 3, the symbolic-phase scratch, the multigrid hierarchy); going to the
 // driver for each of them costs from a few to >100 ms per step depending on the machine.  Released
-// blocks are kept by exact size (after a device synchronisation, which is what hipFree does
-// implicitly) and handed out again; the cache is bounded (FEM_AMD_POOL_MAX_GB, default 96) and is
-// emptied when an allocation fails and when a context is destroyed.
+// blocks are kept by exact size and handed out again once the work that was in flight at their release has
+// completed (one event per registered stream, taken at the release: no device-wide synchronisation); the
+// cache is bounded (FEM_AMD_POOL_MAX_GB, default 96) and is emptied when an allocation fails and when a
+// context is destroyed.
+void pool_register_stream(hipStream_t s);              // a context's streams: what a released block may still be in use by
+void pool_unregister_stream(hipStream_t s) noexcept;
 void* pool_alloc(size_t bytes);
 void pool_release(void* p, size_t bytes) noexcept;
 void pool_trim() noexcept;      // give every cached block of the current device back to the driver

@@ -125,7 +125,10 @@ __device__ __forceinline__ void tile_resolve(TileIdx& in, const TileRaw& rw, con
     if (!rw.valid) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) in.v[c_tminus[i]] = gl[tile_loc(in.c16, c_tminus[i])];
-    if (!(in.fl & 1u)) {
+#ifndef FEM_EXP_NOCHAIN
+    if (!(in.fl & 1u))
+#endif
+    {
 #pragma unroll
         for (int i = 0; i < 4; i++) in.v[c_tplus[i]] = gl[tile_loc(in.c16, c_tplus[i])];
     }
@@ -340,13 +343,18 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         if (in.valid) {
 #pragma unroll
             for (int a = 0; a < 8; a++) {
+#ifndef FEM_EXP_NOCHAIN
                 if ((in.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
+#endif
                 load_node3(Xn[a], coords, in.v[a]);
                 load_node3(un[a], x, in.v[a]);
             }
         }
     };
     if constexpr (!AFFINE) gather_general(i0);
+#ifdef FEM_EXP_TOUCH
+    unsigned touch_reg = 0;
+#endif
     auto do_step = [&](int s, TileData& dcur, TileData& dnext) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
@@ -374,15 +382,37 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             for (int a = 0; a < 8; a++)
 #pragma unroll
                 for (int d = 0; d < 3; d++) { X[a][d] = Xn[a][d]; u[a][d] = un[a][d]; }
+#ifndef FEM_EXP_NOCHAIN
             tile_complete<3>(X, i0.fl);
             tile_complete<3>(u, i0.fl);
+#endif
+#ifdef FEM_EXP_TOUCH
+        if constexpr (!AFFINE) {
+            // the lines the gathers at the end of this step will ask for, touched now: one dword each into one scratch register (loads return
+            // in order; nothing waits for these), so that the gathers find them in L2 instead of the Infinity Cache / HBM
+            asm volatile("" :: "v"(touch_reg), "v"(__double2hiint(u[7][2])));   // (behind the wait for the LAST gathered value of this step: no wait of the compiler's sees the touches; the scratch register of the previous step's touches stays reserved up to here: they have landed -- the gathers behind them were waited for)
+            if (i1.valid) {
+#pragma unroll
+                for (int a = 0; a < 8; a++) {
+                    if ((i1.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(touch_reg) : "v"(coords + (size_t)i1.v[a] * 3) : "memory");
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(touch_reg) : "v"(x + (size_t)i1.v[a] * 3) : "memory");
+                }
+            }
+        }
+#endif
             if constexpr (OP == 0) {
                 const DCoef D = dmat_coef(i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25);
+#ifdef FEM_EXP_NOAFF
+                hex_forces<false>(X, u, g, w, D.d12, D.d44, fe, dot);
+#else
                 hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
+#endif
             } else hex_nodal_stress<OP - 1>(X, u, g, i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25, fe);
             gather_general(i1);   // step s + 1 (an invalid record beyond the last step: nothing is loaded)
         }
         // +x face forces of a linked lane go to the next lane's -x face nodes
+#ifndef FEM_EXP_NOHAND
         {
             const bool recv = __builtin_amdgcn_update_dpp(0, (int)(i0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
 #pragma unroll
@@ -393,10 +423,16 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                     if (recv) fe[c_tminus[i]][d] += pv;
                 }
         }
+#endif
+#ifdef FEM_EXP_BAR
+        if (s > 0 && steps[step_off + s - 1].y < 0) __syncthreads();
+#endif
         if (i0.valid) {
 #pragma unroll
             for (int a = 0; a < 8; a++) {
+#ifndef FEM_EXP_NOHAND
                 if ((i0.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;   // handed over
+#endif
                 const int la = tile_loc(i0.c16, a);
                 if (la >= nown) continue;     // a rim node: its sum belongs to another tile
 #pragma unroll
@@ -404,7 +440,11 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                     __hip_atomic_fetch_add(&acc[3 * la + d], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+#ifndef FEM_EXP_BAR
         if (bar) __syncthreads();
+#else
+        (void)bar;
+#endif
         if constexpr (AFFINE) { i0 = i1; i1 = i2; r2 = r3; }
         else { i0 = i1; tile_resolve(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernels)
     };
@@ -412,6 +452,9 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         do_step(s, d0, d1);
         if constexpr (AFFINE) d0 = d1;
     }
+#ifdef FEM_EXP_BAR
+    __syncthreads();
+#endif
     double dot = 0.0;
     for (int i0n = 0; i0n < nown; i0n += 1024) {   // four owned nodes per lane and round: their loads in flight together
         int kb[4];

@@ -428,6 +428,10 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
                                            double (&K)[NPE][PD][PD], uint2& s01, uint2& s23)
 {
     const ElemTable& tab = c_tab[TYPE];
+    // hex8: the shape functions sum to one, so sum_b dN_b/dx = 0 and the last block of the row is minus the sum of the others,
+    // M_a7 = -sum_{b<7} M_ab: 63 running sums per lane instead of 72 (the 72 did not fit beside the element's coordinates in the
+    // 256 registers two waves per SIMD leave a lane: 17 of them lived in scratch) and an eighth of the inner products less
+    constexpr int NB = (NPE == 8) ? NPE - 1 : NPE;
     double X[NPE][PD];
 #pragma unroll
     for (int b = 0; b < NPE; b++) {
@@ -447,6 +451,20 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
         for (int i = 0; i < PD; i++)
 #pragma unroll
             for (int j = 0; j < PD; j++) K[b][i][j] = 0.0;
+    // hex8: the coordinates as the seven gradient coefficients of the trilinear map (hex8_ebe.h: the three-stage butterfly, once per
+    // lane); the Jacobian at a Gauss point (s1 g, s2 g, s3 g) is then eight multiply-adds per component instead of the 24 against
+    // dN/dxi -- 24 instead of 72 per point
+    [[maybe_unused]] Mono cX[3];
+    if constexpr (NPE == 8 && PD == 3) {
+        const double gq = fabs(tab.xi[0][0]), g8 = 0.125 * gq, gg8 = g8 * gq;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double v[8], c0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v[b] = X[b][j];
+            cX[j] = hex_mono(v, g8, gg8, c0);
+        }
+    }
     double Em = 0.0, num = 0.0;
 #pragma unroll 1
     for (int g = 0; g < NIP; g++) {
@@ -464,15 +482,28 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
             Em = gv.E[e]; num = gv.nu[e];
         }
         double J[PD][PD];
+        if constexpr (NPE == 8 && PD == 3) {
+            const double s1 = tab.xi[g][0] > 0.0 ? 1.0 : -1.0, s2 = tab.xi[g][1] > 0.0 ? 1.0 : -1.0, s3 = tab.xi[g][2] > 0.0 ? 1.0 : -1.0;
 #pragma unroll
-        for (int i = 0; i < PD; i++)
-#pragma unroll
-            for (int j = 0; j < PD; j++) {
-                double sj = 0.0;
-#pragma unroll
-                for (int b = 0; b < NPE; b++) sj += tab.dNxi[g][i][b] * X[b][j];
-                J[i][j] = sj;
+            for (int j = 0; j < 3; j++) {
+                const Mono& c = cX[j];
+                const double A1 = fma(s1, c.xy, c.y), A2 = fma(s1, c.xyz, c.yz), A3 = fma(s1, c.xz, c.z);
+                const double B1 = fma(s2, c.xy, c.x), B2 = fma(s2, c.xyz, c.xz);
+                J[0][j] = fma(s3, B2, B1);
+                J[1][j] = fma(s3, A2, A1);
+                J[2][j] = fma(s2, A2, A3);
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PD; i++)
+#pragma unroll
+                for (int j = 0; j < PD; j++) {
+                    double sj = 0.0;
+#pragma unroll
+                    for (int b = 0; b < NPE; b++) sj += tab.dNxi[g][i][b] * X[b][j];
+                    J[i][j] = sj;
+                }
+        }
         double inv[PD][PD], detj;        // inv[i][j] = d xi_j / d x_i, as in dndx_at_gp (FormdNdetJ)
         if constexpr (PD == 2) {
             detj = J[0][0] * J[1][1] - J[0][1] * J[1][0];
@@ -484,7 +515,9 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
             const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
             const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
             detj = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
-            const double rd = 1.0 / detj;
+            double rd = __builtin_amdgcn_rcp(detj);      // two Newton steps: full double precision (as hex_point_T)
+            rd = fma(fma(-detj, rd, 1.0), rd, rd);
+            rd = fma(fma(-detj, rd, 1.0), rd, rd);
             inv[0][0] = c00 * rd;
             inv[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * rd;
             inv[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * rd;
@@ -505,7 +538,7 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
             da[i] = wd * t;
         }
 #pragma unroll
-        for (int b = 0; b < NPE; b++) {
+        for (int b = 0; b < NB; b++) {
             double db[PD];
 #pragma unroll
             for (int i = 0; i < PD; i++) {
@@ -519,6 +552,17 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
 #pragma unroll
                 for (int j = 0; j < PD; j++) K[b][i][j] += da[i] * db[j];
         }
+    }
+    if constexpr (NB < NPE) {
+#pragma unroll
+        for (int i = 0; i < PD; i++)
+#pragma unroll
+            for (int j = 0; j < PD; j++) {
+                double t = 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) t += K[b][i][j];
+                K[NPE - 1][i][j] = -t;
+            }
     }
     const DCoef D = dmat_coef(Em, num);
 #pragma unroll
@@ -660,7 +704,11 @@ void mat_assemble_elements_impl(fem_mat A)
         gs.g[i] = AsmGroup{g.conn.p, g.E.p, g.nu.p, g.slot.p, g.type, g.npe};
     }
     const int add = A->lazy_zero ? 0 : 1;
+#ifdef FEM_EXP_ASM16
+    constexpr int LDS_BUDGET = 38 * 1024;
+#else
     constexpr int LDS_BUDGET = 76 * 1024;   // two workgroups per CU (160 KiB)
+#endif
     // FEM_AMD_ASM_WCAP (tests): a smaller accumulator window, so that small decks exercise the multi-window path
     // a slice wider than the LDS image takes
     static const int wcap_env = std::getenv("FEM_AMD_ASM_WCAP") ? std::atoi(std::getenv("FEM_AMD_ASM_WCAP")) : 0;
@@ -679,7 +727,11 @@ void mat_assemble_elements_impl(fem_mat A)
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(tpb), shmem, s, m->nnds, nparts, npass, A->boff.p,
                            A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p);
     };
+#ifdef FEM_EXP_ASM16
+    if (m->pdim == 3) launch(k_assemble_rows<3, 8, 16>, 9, 16, 128);
+#else
     if (m->pdim == 3) launch(k_assemble_rows<3, 8, 32>, 9, 32, 256);
+#endif
     else launch(k_assemble_rows<2, 4, 64>, 4, 64, 256);
     A->lazy_zero = false;
     FEM_HIP(hipGetLastError());

@@ -136,6 +136,40 @@ def test_device_pool_reuses_blocks_and_context_destroy_returns_them():
     assert used() < held - (100 << 20)      # the 140 MB matrix blocks went back
 
 
+def test_releasing_a_block_does_not_stall_the_device():
+    """pool.cpp: a released block takes an event per stream of the library and goes into the cache at once -- no device-wide
+    synchronisation at the release (a host that frees inside its increment loop, src/main.F90:300-312 at the end of every run of a
+    long-lived process).  With about 0.2 s of work queued on the context's stream a Vec is destroyed in far less than that; the
+    next request of that size gets the block once that work has finished, and uses it safely."""
+    import time
+    ctx = capi.Context(0)
+    n = 1 << 25
+    a, b, c = capi.Vec(ctx, n), capi.Vec(ctx, n), capi.Vec(ctx, n)
+    a.set(1.0); b.set(0.0); c.set(3.0)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    b.axpy(1.0, a)
+    ctx.synchronize()
+    one = time.perf_counter() - t0
+    reps = max(50, int(0.2 / max(one, 1e-5)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        c.axpy(1.0, a)                       # the block about to be released is in use by queued work
+    t_queue = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    c.destroy()
+    t_release = time.perf_counter() - t0
+    d = capi.Vec(ctx, n)                     # the same size: the cached block, once the queued work is through
+    d.set(7.0)
+    ctx.synchronize()
+    t_all = time.perf_counter() - t0
+    assert t_release < 0.25 * reps * one + 0.005, (t_release, reps * one, t_queue)
+    assert np.all(d.get_array() == 7.0)
+    b.axpy(1.0, a); ctx.synchronize()
+    assert np.all(b.get_array() == 2.0) and t_all > 0
+    a.destroy(); b.destroy(); d.destroy(); ctx.destroy()
+
+
 def test_full_device_pool_makes_room_for_the_blocks_in_use():
     """A cache of released blocks that is full (FEM_AMD_POOL_MAX_GB; here 0.05 GB in a child process) gives its largest blocks back
     to the driver instead of refusing every later release: problems of several sizes one after the other, then a small one again

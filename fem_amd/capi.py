@@ -105,6 +105,7 @@ _SIGS = {
     "fem_ksp_set_profiling": [_h, C.c_int],
     "fem_ksp_get_profile": [_h, _ip, _dp, _dp],
     "fem_ksp_get_reused_solves": [_h, _ip],
+    "fem_ksp_get_resident_solves": [_h, _ip],
     "fem_recover_nodal_stress": [_h, _h, _dp],
     "fem_recover_nodal_stress_vec": [_h, _h, _h],
     "fem_mesh_set_cohesive": [_h, _ip, C.c_int, _dp],
@@ -699,6 +700,12 @@ class KSP:
         """Solves answered with the kept solution of an identical earlier solve (-ksp_reuse_solution, fem_amd.h)."""
         n = C.c_int(0)
         _ck(_lib.fem_ksp_get_reused_solves(self.h, C.byref(n)))
+        return n.value
+
+    def get_resident_solves(self) -> int:
+        """Solves that ran as one resident launch (-ksp_cg_resident, fem_amd.h)."""
+        n = C.c_int(0)
+        _ck(_lib.fem_ksp_get_resident_solves(self.h, C.byref(n)))
         return n.value
 
     def destroy(self):

@@ -46,6 +46,7 @@ void ksp_set_from_options_impl(fem_ksp, const char*);
 void ksp_set_up_impl(fem_ksp);
 void ksp_solve_impl(fem_ksp, fem_vec, fem_vec);
 int ksp_get_reused(fem_ksp);
+int ksp_get_resident(fem_ksp);
 void ksp_get_result(fem_ksp, int*, double*, int*);
 int ksp_get_history(fem_ksp, double*, int);
 void ksp_set_profiling(fem_ksp, int);
@@ -709,6 +710,14 @@ int fem_ksp_get_reused_solves(fem_ksp k, int* n)
     FEM_TRY
     FEM_CHECK(k && n, 1, "fem_ksp_get_reused_solves: null argument");
     *n = ksp_get_reused(k);
+    FEM_CATCH
+}
+
+int fem_ksp_get_resident_solves(fem_ksp k, int* n)
+{
+    FEM_TRY
+    FEM_CHECK(k && n, 1, "fem_ksp_get_resident_solves: null argument");
+    *n = ksp_get_resident(k);
     FEM_CATCH
 }
 

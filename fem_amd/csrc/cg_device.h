@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/fem_amd.h"
+#include "grid_barrier.h"
 
 namespace fem {
 
@@ -105,6 +106,21 @@ struct CgFuseArgs {
     CgOpenArgs open;
     const double *dinv, *r, *p_old;
     double *p_new, *x;
+};
+
+// KSPCG / PCJACOBI as one resident launch (ebe_tile.hip: k_cg_resident_q4)
+struct CgResidentArgs {
+    KspState* st;
+    double rtol, abstol, dtol;
+    int maxit;
+    double* hist;
+    int hist_len;
+    const double* b;       // right-hand side
+    const double* dinv;    // M^-1 (1 for -pc_type none)
+    double* x;             // solution (written at the end)
+    double* r;             // residual: owned nodes written every iteration (the neighbours' rims read it), final residual
+    double *ppw, *pzz, *pzr;   // [ntiles] partials
+    GridBarrier bar;
 };
 
 }  // namespace fem

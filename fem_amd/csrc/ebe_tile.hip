@@ -26,12 +26,15 @@
 #include <sched.h>
 
 #include <array>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "comm.h"
 #include "cg_device.h"
 #include "ebe_tile.h"
+#include "grid_barrier.h"
 #include "hex8_ebe.h"
 #include "quad4_ebe.h"
 #include "objects.h"
@@ -119,16 +122,14 @@ __device__ __forceinline__ void tile_fetch_raw(TileRaw& rw, bool inside, size_t 
     if constexpr (!AFFINE) { rw.E = Ev[e]; rw.nu = nuv[e]; }
 }
 // stage 2 (two steps ahead): global node ids from the tile's list in LDS
+template <bool CHAINS = true>   // CHAINS false (the general kernel): every node id, the links are not used
 __device__ __forceinline__ void tile_resolve(TileIdx& in, const TileRaw& rw, const int* gl)
 {
     in.valid = rw.valid; in.fl = rw.valid ? rw.fl : 0u; in.c16 = rw.c16; in.E = rw.E; in.nu = rw.nu;
     if (!rw.valid) return;
 #pragma unroll
     for (int i = 0; i < 4; i++) in.v[c_tminus[i]] = gl[tile_loc(in.c16, c_tminus[i])];
-#ifndef FEM_EXP_NOCHAIN
-    if (!(in.fl & 1u))
-#endif
-    {
+    if (!CHAINS || !(in.fl & 1u)) {
 #pragma unroll
         for (int i = 0; i < 4; i++) in.v[c_tplus[i]] = gl[tile_loc(in.c16, c_tplus[i])];
     }
@@ -325,8 +326,8 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     TileRaw r2, r3;            // steps s + 2, s + 3
     TileIdx i0, i1, i2;        // steps s, s + 1, s + 2
     TileData d0, d1;           // steps s, s + 1 (affine kernel)
-    raw_of(r2, 0); tile_resolve(i0, r2, gl);
-    raw_of(r2, 1); tile_resolve(i1, r2, gl);
+    raw_of(r2, 0); tile_resolve<AFFINE>(i0, r2, gl);
+    raw_of(r2, 1); tile_resolve<AFFINE>(i1, r2, gl);
     raw_of(r2, 2);
     constexpr int NG = KIND == 2 ? 5 : 11;
     if constexpr (AFFINE) tile_fetch_data<NG, STREAM>(d0, i0, pos_of(0), geo, geo_stride, x);
@@ -334,6 +335,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     // arithmetic, in front of the hand-over, the LDS adds and the barrier -- so that their way through L2 / the Infinity Cache runs
     // under those instead of in front of the next step's arithmetic (round-4 counters: 30 % of the wave time parked at s_waitcnt with
     // the gathers at the top of the step).  No register is added at the peak: inside the Gauss pairs these 48 doubles are dead.
+    // The general kernel does not use the chains of the lane rows: all eight corners are gathered and all eight forces go to LDS
+    // (round 6: the 96 DPP moves and selects of the hand-overs cost this kernel, whose bound is the vector issue, more than the
+    // eight extra gathers and twelve extra LDS adds -- 0.377 against 0.389 ms per product at the distorted config 3; same values
+    // gathered, so the element forces are bit for bit the same; the order of the LDS adds inside a colour differs).
     double Xn[8][3], un[8][3];
     auto gather_general = [&](const TileIdx& in) {
 #pragma unroll
@@ -343,23 +348,17 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
         if (in.valid) {
 #pragma unroll
             for (int a = 0; a < 8; a++) {
-#ifndef FEM_EXP_NOCHAIN
-                if ((in.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
-#endif
                 load_node3(Xn[a], coords, in.v[a]);
                 load_node3(un[a], x, in.v[a]);
             }
         }
     };
     if constexpr (!AFFINE) gather_general(i0);
-#ifdef FEM_EXP_TOUCH
-    unsigned touch_reg = 0;
-#endif
     auto do_step = [&](int s, TileData& dcur, TileData& dnext) {
         const bool bar = steps[step_off + s].y < 0;
         if constexpr (AFFINE) {
             raw_of(r3, s + 3);
-            tile_resolve(i2, r2, gl);
+            tile_resolve<true>(i2, r2, gl);
             tile_fetch_data<NG, STREAM>(dnext, i1, pos_of(s + 1), geo, geo_stride, x);
         }
         // (lanes without an element run the arithmetic on whatever their registers hold: nothing of it is stored or handed on)
@@ -382,38 +381,14 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
             for (int a = 0; a < 8; a++)
 #pragma unroll
                 for (int d = 0; d < 3; d++) { X[a][d] = Xn[a][d]; u[a][d] = un[a][d]; }
-#ifndef FEM_EXP_NOCHAIN
-            tile_complete<3>(X, i0.fl);
-            tile_complete<3>(u, i0.fl);
-#endif
-#ifdef FEM_EXP_TOUCH
-        if constexpr (!AFFINE) {
-            // the lines the gathers at the end of this step will ask for, touched now: one dword each into one scratch register (loads return
-            // in order; nothing waits for these), so that the gathers find them in L2 instead of the Infinity Cache / HBM
-            asm volatile("" :: "v"(touch_reg), "v"(__double2hiint(u[7][2])));   // (behind the wait for the LAST gathered value of this step: no wait of the compiler's sees the touches; the scratch register of the previous step's touches stays reserved up to here: they have landed -- the gathers behind them were waited for)
-            if (i1.valid) {
-#pragma unroll
-                for (int a = 0; a < 8; a++) {
-                    if ((i1.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(touch_reg) : "v"(coords + (size_t)i1.v[a] * 3) : "memory");
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(touch_reg) : "v"(x + (size_t)i1.v[a] * 3) : "memory");
-                }
-            }
-        }
-#endif
             if constexpr (OP == 0) {
                 const DCoef D = dmat_coef(i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25);
-#ifdef FEM_EXP_NOAFF
-                hex_forces<false>(X, u, g, w, D.d12, D.d44, fe, dot);
-#else
                 hex_forces<true>(X, u, g, w, D.d12, D.d44, fe, dot);
-#endif
             } else hex_nodal_stress<OP - 1>(X, u, g, i0.valid ? i0.E : 1.0, i0.valid ? i0.nu : 0.25, fe);
             gather_general(i1);   // step s + 1 (an invalid record beyond the last step: nothing is loaded)
         }
-        // +x face forces of a linked lane go to the next lane's -x face nodes
-#ifndef FEM_EXP_NOHAND
-        {
+        // +x face forces of a linked lane go to the next lane's -x face nodes (kernels of stored geometry)
+        if constexpr (AFFINE) {
             const bool recv = __builtin_amdgcn_update_dpp(0, (int)(i0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -423,16 +398,10 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                     if (recv) fe[c_tminus[i]][d] += pv;
                 }
         }
-#endif
-#ifdef FEM_EXP_BAR
-        if (s > 0 && steps[step_off + s - 1].y < 0) __syncthreads();
-#endif
         if (i0.valid) {
 #pragma unroll
             for (int a = 0; a < 8; a++) {
-#ifndef FEM_EXP_NOHAND
-                if ((i0.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;   // handed over
-#endif
+                if (AFFINE && (i0.fl & 1u) && (a == 1 || a == 2 || a == 5 || a == 6)) continue;   // handed over
                 const int la = tile_loc(i0.c16, a);
                 if (la >= nown) continue;     // a rim node: its sum belongs to another tile
 #pragma unroll
@@ -440,21 +409,14 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                     __hip_atomic_fetch_add(&acc[3 * la + d], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
-#ifndef FEM_EXP_BAR
         if (bar) __syncthreads();
-#else
-        (void)bar;
-#endif
         if constexpr (AFFINE) { i0 = i1; i1 = i2; r2 = r3; }
-        else { i0 = i1; tile_resolve(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernels)
+        else { i0 = i1; tile_resolve<false>(i1, r2, gl); raw_of(r2, s + 3); }   // (registers: one stage less than the affine kernels)
     };
     for (int s = 0; s < nsteps; s++) {   // (letting the two data buffers change roles instead of copying one costs registers: spills)
         do_step(s, d0, d1);
         if constexpr (AFFINE) d0 = d1;
     }
-#ifdef FEM_EXP_BAR
-    __syncthreads();
-#endif
     double dot = 0.0;
     for (int i0n = 0; i0n < nown; i0n += 1024) {   // four owned nodes per lane and round: their loads in flight together
         int kb[4];
@@ -1213,14 +1175,109 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4(int nlist, const int* __
     tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
 
+// ---- the steps of a quad4 tile whose x and coordinates sit in LDS (k_ebe_tile_q4x and the resident CG below) ----------------------
+constexpr int TILE_Q4X_MAX_NODES = 1280, TILE_Q4X_MAX_OWN = 1024;   // 5 / 4 slots per thread
+constexpr int TILE_Q4X_LDS_NODES = 1104, TILE_Q4X_LDS_OWN = 976;    // the LDS image (33 x 33 nodes, 31 x 31 owned): 50 KB, three workgroups per CU
+struct Q4Slot { uint4 c16; unsigned fl; double lam, mu; };   // fl bit 1: an element (0: padding or past the step), bit 0: linked to the next lane
+// the slot record of step s (s >= nsteps, or a lane past the step's count: an empty record)
+__device__ __forceinline__ void q4x_fetch(Q4Slot& q, int s, int nsteps, const int2& sv, int elem_off, const uint4* __restrict__ tconn,
+                                          const unsigned char* __restrict__ tflags, const double* __restrict__ geo, size_t geo_stride)
+{
+    q.fl = 0; q.lam = 1.0; q.mu = 1.0;
+    if (s >= nsteps) return;
+    const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
+    if ((int)threadIdx.x >= cnt) return;
+    const size_t k = (size_t)elem_off + first + threadIdx.x;
+    q.c16 = tconn[k];
+    q.fl = tflags[k];
+    q.lam = geo[k]; q.mu = geo[geo_stride + k];
+}
+__device__ __forceinline__ void q4x_read_corners(double (&X)[4][2], double (&u)[4][2], const Q4Slot& q, const double* xs, const double* Xs)
+{
+    constexpr int MN = TILE_Q4X_LDS_NODES;
+    const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        if (a == 1 || a == 2) continue;
+        const int la = tile_loc(q.c16, a);
+#pragma unroll
+        for (int d = 0; d < 2; d++) { X[a][d] = valid ? Xs[d * MN + la] : 0.0; u[a][d] = valid ? xs[d * MN + la] : 0.0; }
+    }
+    if (valid && !linked) {
+#pragma unroll
+        for (int a = 1; a < 3; a++) {
+            const int la = tile_loc(q.c16, a);
+#pragma unroll
+            for (int d = 0; d < 2; d++) { X[a][d] = Xs[d * MN + la]; u[a][d] = xs[d * MN + la]; }
+        }
+    }
+}
+// Every step of the tile: element forces from the corner values in LDS, the hand-over along the lane rows, the adds into the sums of
+// the owned nodes (acc, zeroed by the caller; a barrier between the colours and one at the end).  q0: the slot record of step 0.
+// KEEP (the resident CG): the records of the first KEEP steps come from `kept` (registers of the caller) instead of the lists.
+template <int KEEP = 0>
+__device__ __forceinline__ void q4x_steps(Q4Slot q0, int nsteps, const int2& sv, int elem_off, int nown, const uint4* __restrict__ tconn,
+                                          const unsigned char* __restrict__ tflags, const double* __restrict__ geo, size_t geo_stride,
+                                          const double* xs, const double* Xs, double* acc, double g, double w, const Q4Slot* kept = nullptr)
+{
+    constexpr int MO = TILE_Q4X_LDS_OWN;
+    Q4Slot q1;
+    double X[4][2], u[4][2];
+    q4x_read_corners(X, u, q0, xs, Xs);
+    bool prev_bar = false;
+    auto one_step = [&](int s, const Q4Slot* next) {   // next: the record of step s + 1 where the caller keeps it
+        const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
+        if (next) { q1 = *next; if (s + 1 >= nsteps) q1.fl = 0; }
+        else q4x_fetch(q1, s + 1, nsteps, sv, elem_off, tconn, tflags, geo, geo_stride);
+        const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {   // the +x edge (nodes 1, 2) of a linked lane: the next lane's -x edge (nodes 0, 3)
+            const double x1 = row_next(X[0][d]), x2 = row_next(X[3][d]), u1 = row_next(u[0][d]), u2 = row_next(u[3][d]);
+            if (linked) { X[1][d] = x1; X[2][d] = x2; u[1][d] = u1; u[2][d] = u2; }
+        }
+        double fe[4][2], dote;
+        quad4_forces(X, u, g, w, q0.lam, q0.mu, fe, dote);
+        {
+            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const double p1 = row_prev(fe[1][d]), p2 = row_prev(fe[2][d]);
+                if (recv) { fe[0][d] += p1; fe[3][d] += p2; }
+            }
+        }
+        q4x_read_corners(X, u, q1, xs, Xs);
+        if (prev_bar) __syncthreads();
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                if (linked && (a == 1 || a == 2)) continue;   // handed over
+                const int la = tile_loc(q0.c16, a);
+                if (la >= nown) continue;     // a rim node: its sum belongs to another tile
+#pragma unroll
+                for (int d = 0; d < 2; d++)   // one writer per node and colour
+                    __hip_atomic_fetch_add(&acc[d * MO + la], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        prev_bar = bar;
+        q0 = q1;
+    };
+    if constexpr (KEEP > 0) {
+#pragma unroll
+        for (int s = 0; s < KEEP; s++)
+            if (s < nsteps) one_step(s, s + 1 < KEEP ? kept + s + 1 : nullptr);
+        for (int s = KEEP; s < nsteps; s++) one_step(s, nullptr);
+    } else {
+        for (int s = 0; s < nsteps; s++) one_step(s, nullptr);
+    }
+    __syncthreads();
+}
+
 // The same product with x AND the coordinates of the tile's nodes staged in LDS (the quad4 counterpart of k_ebe_tile_x): at a
 // million dofs every tile of the mesh is resident at once and the kernel lasts as long as one tile's chain of latencies, which
 // the gathering kernel above runs through once per step (slot -> node ids in LDS -> coordinates and x from global memory).  Here
 // the chain is: tile record -> node ids -> x, X (one wave of loads) and from then on LDS only; the slot records (local numbers,
 // flags, the element's two D factors: stored at set-up, no E / nu gather behind the element id) stream in one step ahead.
 // LDS: x and X of the tile's nodes (32 B each) + the sums of its owned nodes (16 B each): 50 KB for the 33 x 33-node tile.
-constexpr int TILE_Q4X_MAX_NODES = 1280, TILE_Q4X_MAX_OWN = 1024;   // 5 / 4 slots per thread
-constexpr int TILE_Q4X_LDS_NODES = 1104, TILE_Q4X_LDS_OWN = 976;    // the LDS image (33 x 33 nodes, 31 x 31 owned): 50 KB, three workgroups per CU
 template <bool FUSED>   // FUSED: the kernel opens the CG iteration itself (convergence test, p = M^-1 r + b p in the stage-in, x += a p): cg_device.h
 __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* __restrict__ lhdr, const int2* __restrict__ steps,
                                                       const int* __restrict__ pnodes, const uint4* __restrict__ tconn,
@@ -1252,8 +1309,7 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     // (step table, first step's slot records and D factors at fixed strides per list position, asked for first: see k_ebe_tile_x)
     const size_t gp = (size_t)tf.gp0 + lb;
     const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
-    struct Slot { uint4 c16; unsigned fl; double lam, mu; };
-    Slot q0, q1;
+    Q4Slot q0;
     q0.c16 = tf.pconn0[gp * tf.nsl * 256 + threadIdx.x]; q0.fl = tf.pfl0[gp * tf.nsl * 256 + threadIdx.x];
     q0.lam = tf.pgeo[gp * tf.nsl * 512 + threadIdx.x]; q0.mu = tf.pgeo[gp * tf.nsl * 512 + 256 + threadIdx.x];
     int nv[NPT];
@@ -1313,74 +1369,8 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
             if (j < NPO && i < nown) { acc[i] = 0.0; acc[MO + i] = 0.0; }
         }
     }
-    auto fetch = [&](Slot& q, int s) {
-        q.fl = 0; q.lam = 1.0; q.mu = 1.0;
-        if (s >= nsteps) return;
-        const int first = __builtin_amdgcn_readlane(sv.x, s), cnt = __builtin_amdgcn_readlane(sv.y, s) & 0x7fffffff;
-        if ((int)threadIdx.x >= cnt) return;
-        const size_t k = (size_t)elem_off + first + threadIdx.x;
-        q.c16 = tconn[k];
-        q.fl = tflags[k];
-        q.lam = geo[k]; q.mu = geo[geo_stride + k];
-    };
-    auto read_corners = [&](double (&X)[4][2], double (&u)[4][2], const Slot& q) {
-        const bool valid = (q.fl & 2u) != 0, linked = (q.fl & 1u) != 0;
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            if (a == 1 || a == 2) continue;
-            const int la = tile_loc(q.c16, a);
-#pragma unroll
-            for (int d = 0; d < 2; d++) { X[a][d] = valid ? Xs[d * MN + la] : 0.0; u[a][d] = valid ? xs[d * MN + la] : 0.0; }
-        }
-        if (valid && !linked) {
-#pragma unroll
-            for (int a = 1; a < 3; a++) {
-                const int la = tile_loc(q.c16, a);
-#pragma unroll
-                for (int d = 0; d < 2; d++) { X[a][d] = Xs[d * MN + la]; u[a][d] = xs[d * MN + la]; }
-            }
-        }
-    };
     __syncthreads();
-    double X[4][2], u[4][2];
-    read_corners(X, u, q0);
-    bool prev_bar = false;
-    for (int s = 0; s < nsteps; s++) {
-        const bool bar = __builtin_amdgcn_readlane(sv.y, s) < 0;
-        fetch(q1, s + 1);
-        const bool valid = (q0.fl & 2u) != 0, linked = (q0.fl & 1u) != 0;
-#pragma unroll
-        for (int d = 0; d < 2; d++) {   // the +x edge (nodes 1, 2) of a linked lane: the next lane's -x edge (nodes 0, 3)
-            const double x1 = row_next(X[0][d]), x2 = row_next(X[3][d]), u1 = row_next(u[0][d]), u2 = row_next(u[3][d]);
-            if (linked) { X[1][d] = x1; X[2][d] = x2; u[1][d] = u1; u[2][d] = u2; }
-        }
-        double fe[4][2], dote;
-        quad4_forces(X, u, g, w, q0.lam, q0.mu, fe, dote);
-        {
-            const bool recv = __builtin_amdgcn_update_dpp(0, (int)(q0.fl & 1u), 0x111, 0xf, 0xf, true) != 0;
-#pragma unroll
-            for (int d = 0; d < 2; d++) {
-                const double p1 = row_prev(fe[1][d]), p2 = row_prev(fe[2][d]);
-                if (recv) { fe[0][d] += p1; fe[3][d] += p2; }
-            }
-        }
-        read_corners(X, u, q1);
-        if (prev_bar) __syncthreads();
-        if (valid) {
-#pragma unroll
-            for (int a = 0; a < 4; a++) {
-                if (linked && (a == 1 || a == 2)) continue;   // handed over
-                const int la = tile_loc(q0.c16, a);
-                if (la >= nown) continue;     // a rim node: its sum belongs to another tile
-#pragma unroll
-                for (int d = 0; d < 2; d++)   // one writer per node and colour
-                    __hip_atomic_fetch_add(&acc[d * MO + la], fe[a][d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-        }
-        prev_bar = bar;
-        q0 = q1;
-    }
-    __syncthreads();
+    q4x_steps(q0, nsteps, sv, elem_off, nown, tconn, tflags, geo, geo_stride, xs, Xs, acc, g, w);
     double dot = 0.0;
 #pragma unroll
     for (int j = 0; j < NPO; j++) {
@@ -1398,6 +1388,256 @@ __global__ void __launch_bounds__(256, 3) k_ebe_tile_q4x(int nlist, const int* _
     }
     tile_finish(dot, t, sh, partial, rcount, rtotal, red);
 }
+// ---- KSPCG / PCJACOBI as ONE resident launch (quad4 plans whose tiles are all resident at once: config 2) -----------------------
+// At a million dofs the CG of the launch-per-kernel path is a chain of latencies: 529 tiles, all resident, two kernels per iteration,
+// and the product kernel spends most of its 24 us on its own start (tile record -> node ids -> stage-in loads -> the opening's
+// partial sums).  Here one workgroup per tile stays for the whole solve: node ids, penalty records, coordinates (LDS), M^-1, the slot
+// records of the first four steps, and r / x of its owned nodes live in registers or LDS across the iterations; p of all the tile's
+// nodes (owned + rim) stays in LDS and is advanced by the tile itself -- the rim recomputed as in k_ebe_tile_q4x<true> -- from the rim
+// nodes' r, the only vector data that crosses tiles (16 B per rim node and iteration, through global memory).  Two grid barriers
+// (grid_barrier.h, 6-7 us each) per iteration:
+//   [sum z.z, z.r partials -> KSPConvergedDefault, beta, b]  [x += a p, p = M^-1 r + b p in LDS]  [w = K p, tile steps]  p.w partial
+//   -- barrier --  [sum p.w partials -> a]  [r -= a w, z = M^-1 r]  z.z, z.r partials, r of the owned nodes to global  -- barrier --
+// Same operations per entry as the kernels of ksp.hip (cg_z, cg_p, cg_open_logic); the p.w partials are the launch path's (one
+// per tile, summed in the same order), z.z and z.r are summed tile by tile instead of in index order -- the iteration path agrees
+// with the launch path to round-off, not to the bit.
+// two sums at once: the shuffle trees and the fixed tree over the four waves of block_sum (cg_device.h), one pair of barriers for both
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* sh)
+{
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { sh[w] = a; sh[4 + w] = b; }
+    __syncthreads();
+    a = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    b = (sh[4] + sh[5]) + (sh[6] + sh[7]);
+}
+__device__ __forceinline__ double2 ld2(const double* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+__device__ __forceinline__ void st2(double* base, unsigned byte_off, double2 v)
+{
+    *reinterpret_cast<double2*>(reinterpret_cast<char*>(base) + byte_off) = v;
+}
+__global__ void __launch_bounds__(256, 3) k_cg_resident_q4(int nlist, const int* __restrict__ lhdr, const int* __restrict__ pnodes,
+                                                           const uint4* __restrict__ tconn, const unsigned char* __restrict__ tflags,
+                                                           const double* __restrict__ geo, size_t geo_stride,
+                                                           const double* __restrict__ coords, const int* __restrict__ bc_node,
+                                                           const int* __restrict__ bc_dof, const double* __restrict__ bc_shift,
+                                                           double g, double w, CgResidentArgs cg, TileFirst tf)
+{
+    constexpr int NPT = TILE_Q4X_MAX_NODES / 256, NPO = TILE_Q4X_MAX_OWN / 256, MN = TILE_Q4X_LDS_NODES, MO = TILE_Q4X_LDS_OWN;
+    constexpr int KEEP = 1;   // (the first step's slot record stays in registers; the others stream in one step ahead, as in k_ebe_tile_q4x: four kept records pushed the kernel over the 168 registers of three waves per SIMD)
+    extern __shared__ double lds[];
+    __shared__ double sh[8];
+    __shared__ unsigned shu[4];
+    // penalty dofs among the owned nodes (ApplyKBC: K_jj = PENALTY, applied as w_j += shift_j p_j): position and shift, gathered once
+    // -- read per iteration through node -> record -> shift, two dependent loads, they held the tiles of a clamped edge 4 us behind
+    // the others at every barrier.  More than RES_BC of them in a tile: that tile keeps the loads (bc_many).
+    constexpr int RES_BC = 128;
+    __shared__ int bc_pos[RES_BC];
+    __shared__ double bc_val[RES_BC];
+    __shared__ int bc_cnt;
+    const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // XCD-wise, as k_ebe_tile
+    if (lb >= (unsigned)nlist) return;   // (padding of the grid: takes no part in the barriers)
+    const bool writer = lb == 0 && threadIdx.x == 0;
+    const int* hd = lhdr + 8 * (size_t)lb;
+    const int nown = hd[1], nnode = hd[2], elem_off = hd[3], nsteps = hd[5], t = hd[6];
+    double* xs = lds;               // p of the tile's nodes
+    double* Xs = lds + 2 * MN;      // their coordinates
+    double* acc = lds + 4 * MN;     // sums of the owned nodes
+    const size_t gp = (size_t)tf.gp0 + lb;
+    const int2 sv = tf.psteps[gp * 64 + (threadIdx.x & 63)];
+    Q4Slot kept[KEEP];              // slot records of the first steps: registers for the whole solve where the plan stores them per tile
+    const int nk = (int)tf.nsl < KEEP ? (int)tf.nsl : KEEP;
+#pragma unroll
+    for (int s = 0; s < KEEP; s++) {
+        kept[s].fl = 0; kept[s].lam = 1.0; kept[s].mu = 1.0; kept[s].c16 = make_uint4(0, 0, 0, 0);
+        if (s < nk) {
+            const size_t o = (gp * tf.nsl + s) * 256 + threadIdx.x;
+            kept[s].c16 = tf.pconn0[o]; kept[s].fl = tf.pfl0[o];
+            kept[s].lam = tf.pgeo[(gp * tf.nsl + s) * 512 + threadIdx.x]; kept[s].mu = tf.pgeo[(gp * tf.nsl + s) * 512 + 256 + threadIdx.x];
+        } else q4x_fetch(kept[s], s, nsteps, sv, elem_off, tconn, tflags, geo, geo_stride);   // (a plan that stores the first step only: the others from the lists, once)
+    }
+    // (node ids as 32-bit byte offsets of the 16-B entries: uniform base + lane offset, no 64-bit address per lane and vector kept alive)
+    unsigned nv[NPT];
+    int kb[NPO];
+#pragma unroll
+    for (int j = 0; j < NPT; j++) nv[j] = 16u * (unsigned)pnodes[(size_t)lb * TILE_Q4X_MAX_NODES + threadIdx.x + 256 * j];
+#pragma unroll
+    for (int j = 0; j < NPO; j++) kb[j] = (bc_node ? bc_node : hd)[bc_node ? nv[j] / 16u : 0];
+    if (threadIdx.x == 0) bc_cnt = 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPO; j++) {
+        const int q = threadIdx.x + 256 * j;
+        if (q >= nown || !bc_node || kb[j] < 0) continue;
+        for (int d = 0; d < 2; d++)
+            if (bc_dof[kb[j] + d] >= 0) {
+                const int slot = atomicAdd(&bc_cnt, 1);
+                if (slot < RES_BC) { bc_pos[slot] = q | (d << 16); bc_val[slot] = bc_shift[kb[j] + d]; }
+            }
+    }
+    __syncthreads();
+    const int nbc = bc_cnt;
+    const bool bc_many = nbc > RES_BC;
+    GridBarrierLane lane = grid_barrier_census(cg.bar, (unsigned)nlist, shu);
+    // x = 0, r = b, p = 0; z = M^-1 r and the first partials.  Between the iterations only the node ids, the penalty records and the
+    // first slot record stay in registers (the product needs the rest of the 168 that three waves per SIMD leave a lane): r, M^-1 and
+    // x are read again where they are used -- loads that travel with the partial sums' round trip, from this XCD's L2 but for the rim
+    double zz = 0.0, zr = 0.0;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        const int i = threadIdx.x + 256 * j;
+        const double2 z2 = make_double2(0.0, 0.0);
+        const double2 bj = (i < nnode) ? ld2(cg.b, nv[j]) : z2;
+        const double2 dj = (i < nnode) ? ld2(cg.dinv, nv[j]) : z2;
+        const double2 cn = (i < nnode) ? ld2(coords, nv[j]) : z2;
+        if (i < nnode) { Xs[i] = cn.x; Xs[MN + i] = cn.y; xs[i] = 0.0; xs[MN + i] = 0.0; }
+        if (j < NPO && i < nown) {
+            st2(cg.x, nv[j], z2);
+            st2(cg.r, nv[j], bj);
+            const double z0 = cg_z(dj.x, bj.x), z1 = cg_z(dj.y, bj.y);
+            zz += z0 * z0; zr += z0 * bj.x;
+            zz += z1 * z1; zr += z1 * bj.y;
+        }
+    }
+    block_sum2(zz, zr, sh);
+    if (threadIdx.x == 0) { cg.pzz[t] = zz; cg.pzr[t] = zr; }
+    if (!grid_barrier(cg.bar, lane, shu)) return;
+    // the scalars of KSPSolve_CG, carried by every workgroup (all evaluate the same logic from the same sums)
+    double betaold = 0.0, rnorm0 = 0.0, ttol = 0.0, aprev = 0.0, dpi_old = 0.0;
+    int reason = 0, its = 0;
+#ifdef FEM_RES_PROFILE
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_amdgcn_s_memrealtime();
+#define PH(n) { const unsigned long long tn_ = __builtin_amdgcn_s_memrealtime(); tph[n] += tn_ - tlast; tlast = tn_; }
+#else
+#define PH(n)
+#endif
+    for (int i = 0;; i++) {
+        // ---- opening of iteration i + 1: z.z, z.r over the tiles (thread k: partials k, k + 256, ...; then the fixed tree) ----
+        double s0 = 0.0, s1 = 0.0;
+        for (int k = threadIdx.x; k < nlist; k += 256) { s0 += cg.pzz[k]; s1 += cg.pzr[k]; }
+        {
+            // r and M^-1 of every node of the tile (the rim's r is the neighbours' of this iteration), x of the owned ones: asked for
+            // with the partials
+            double2 rr[NPT], dd[NPT], xo[NPO];
+#pragma unroll
+            for (int j = 0; j < NPT; j++) {
+                const int q = threadIdx.x + 256 * j;
+                const double2 z2 = make_double2(0.0, 0.0);
+                rr[j] = (q < nnode) ? ld2(cg.r, nv[j]) : z2;
+                dd[j] = (q < nnode) ? ld2(cg.dinv, nv[j]) : z2;
+                if (j < NPO) xo[j] = (i > 0 && q < nown) ? ld2(cg.x, nv[j]) : z2;
+            }
+            zz = s0; zr = s1;
+            block_sum2(zz, zr, sh);
+            PH(0)
+            const CgOpen o = cg_open_logic(i, zz, zr, betaold, rnorm0, ttol, cg.rtol, cg.abstol, cg.dtol, cg.maxit);
+            if (i == 0) { rnorm0 = o.rnorm0; ttol = o.ttol; }
+            if (o.its >= 0) its = o.its;
+            if (writer) {
+                cg.st->dp = o.dp;
+                if (cg.hist && i < cg.hist_len) cg.hist[i] = o.dp;
+            }
+            // x += a p of the iteration just completed, then p = M^-1 r + b p for every node of the tile
+#pragma unroll
+            for (int j = 0; j < NPT; j++) {
+                const int q = threadIdx.x + 256 * j;
+                if (q >= nnode) continue;
+                const double p0 = xs[q], p1 = xs[MN + q];
+                if (j < NPO && i > 0 && q < nown) {
+                    xo[j].x += aprev * p0; xo[j].y += aprev * p1;
+                    st2(cg.x, nv[j], xo[j]);
+                }
+                if (!o.reason) {
+                    xs[q] = (i > 0) ? cg_p(cg_z(dd[j].x, rr[j].x), o.b, p0) : cg_z(dd[j].x, rr[j].x);
+                    xs[MN + q] = (i > 0) ? cg_p(cg_z(dd[j].y, rr[j].y), o.b, p1) : cg_z(dd[j].y, rr[j].y);
+                }
+                if (j < NPO && q < nown) { acc[q] = 0.0; acc[MO + q] = 0.0; }
+            }
+            if (o.reason) { reason = o.reason; break; }   // (uniform over the grid)
+        }
+        const double beta = zr;
+        __syncthreads();
+        PH(1)
+        // ---- w = K p over the tile's steps; p.w over the owned nodes ----
+        q4x_steps(kept[0], nsteps, sv, elem_off, nown, tconn, tflags, geo, geo_stride, xs, Xs, acc, g, w);
+        PH(2)
+        if (!bc_many && nbc > 0) {   // ApplyKBC INSERTs on the diagonal only: w_j += (PENALTY - assembled K_jj) p_j
+            if ((int)threadIdx.x < nbc) {
+                const int q = bc_pos[threadIdx.x] & 0xffff, d = bc_pos[threadIdx.x] >> 16;
+                acc[d * MO + q] += bc_val[threadIdx.x] * xs[d * MN + q];
+            }
+            __syncthreads();
+        }
+        double dot = 0.0;
+#pragma unroll
+        for (int j = 0; j < NPO; j++) {
+            const int q = threadIdx.x + 256 * j;
+            if (q >= nown) continue;
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                double sum = acc[d * MO + q];
+                const double pi = xs[d * MN + q];
+                if (bc_many && kb[j] >= 0 && bc_dof[kb[j] + d] >= 0) { sum += bc_shift[kb[j] + d] * pi; acc[d * MO + q] = sum; }
+                dot += pi * sum;     // (acc keeps w of the owned node for the r update behind the barrier)
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_down(dot, off);   // (as tile_finish: the partial of the launch path)
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = dot;
+        __syncthreads();
+        if (threadIdx.x == 0) cg.ppw[t] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        PH(3)
+        if (!grid_barrier(cg.bar, lane, shu)) { reason = 0; its = -1; break; }
+        PH(4)
+        // ---- a = beta / p.w; r -= a w; z = M^-1 r; partials ----
+        double sp = 0.0;
+        for (int k = threadIdx.x; k < nlist; k += 256) sp += cg.ppw[k];
+        double2 ro[NPO], dq[NPO];
+#pragma unroll
+        for (int j = 0; j < NPO; j++) {
+            const int q = threadIdx.x + 256 * j;
+            const double2 z2 = make_double2(0.0, 0.0);
+            ro[j] = (q < nown) ? ld2(cg.r, nv[j]) : z2;
+            dq[j] = (q < nown) ? ld2(cg.dinv, nv[j]) : z2;
+        }
+        const double dpi = block_sum(sp, sh);
+        PH(5)
+        if (dpi == 0.0 || (i > 0 && dpi * dpi_old <= 0.0)) { reason = FEM_KSP_DIVERGED_INDEFINITE_MAT; break; }   // (x holds every completed iteration)
+        const double a = beta / dpi;
+        dpi_old = dpi; betaold = beta; aprev = a;
+        zz = 0.0; zr = 0.0;
+#pragma unroll
+        for (int j = 0; j < NPO; j++) {
+            const int q = threadIdx.x + 256 * j;
+            if (q >= nown) continue;
+            ro[j].x = ro[j].x - a * acc[q]; ro[j].y = ro[j].y - a * acc[MO + q];
+            st2(cg.r, nv[j], ro[j]);
+            const double z0 = cg_z(dq[j].x, ro[j].x), z1 = cg_z(dq[j].y, ro[j].y);
+            zz += z0 * z0; zr += z0 * ro[j].x;
+            zz += z1 * z1; zr += z1 * ro[j].y;
+        }
+        block_sum2(zz, zr, sh);
+        if (threadIdx.x == 0) { cg.pzz[t] = zz; cg.pzr[t] = zr; }
+        PH(6)
+        if (!grid_barrier(cg.bar, lane, shu)) { reason = 0; its = -1; break; }
+        PH(7)
+    }
+#ifdef FEM_RES_PROFILE
+    if (threadIdx.x == 0 && (lb == 0 || lb == 100 || lb == 300 || lb == 528)) {
+        const int slot = lb == 0 ? 0 : lb == 100 ? 1 : lb == 300 ? 2 : 3;
+        for (int q = 0; q < 8; q++) cg.hist[cg.hist_len - 40 + slot * 8 + q] = (double)tph[q];
+    }
+#endif
+    if (writer) {   // the verdict (x of the owned nodes is complete: the last x += a p was applied at the opening that ended the solve)
+        cg.st->its = its; cg.st->it = its; cg.st->reason = reason; cg.st->done = 1; cg.st->stop = 1;
+        cg.st->a = aprev; cg.st->betaold = betaold; cg.st->rnorm0 = rnorm0; cg.st->ttol = ttol;
+    }
+}
+
 // the two factors of DMat2d per lane slot of a quad4 plan (k_ebe_tile_q4x): geo[k] = d12, geo[slots + k] = d44
 __global__ void __launch_bounds__(256) k_tile_geom_q4(size_t ntel, const int* __restrict__ telems, const double* __restrict__ Ev,
                                                       const double* __restrict__ nuv, double* __restrict__ geo)
@@ -2136,6 +2376,47 @@ bool ebe_tile_can_fuse(fem_mat A, const EbeTilePlan& P)
     static const bool qx_env = !(std::getenv("FEM_AMD_TILE_X") && std::atoi(std::getenv("FEM_AMD_TILE_X")) == 0);
     return A->mesh->groups.size() == 1 && A->mesh->groups[0].type == FEM_QUA && qx_env && P.geo.p && P.max_nsteps <= 64 &&
            P.max_nnode <= TILE_Q4X_LDS_NODES && P.max_nown <= TILE_Q4X_LDS_OWN && P.n_gen > 0;
+}
+
+// KSPCG / PCJACOBI of a quad4 plan as one resident launch (k_cg_resident_q4): cg == nullptr asks whether this Mat's plan qualifies --
+// the plans whose product can open the iteration (ebe_tile_can_fuse) with every tile resident at once; otherwise the kernel is
+// enqueued on the context's stream (barrier words zeroed first) and the caller reads the verdict from the KspState and cg->bar.err.
+bool ebe_tile_cg_resident(fem_mat A, const EbeTilePlan& P, const CgResidentArgs* cg)
+{
+    if (!ebe_tile_can_fuse(A, P) || P.n_gen != P.ntiles) return false;
+    constexpr size_t shqx = (size_t)(4 * TILE_Q4X_LDS_NODES + 2 * TILE_Q4X_LDS_OWN) * sizeof(double);
+    static std::mutex mu;
+    static std::map<int, int> cap_of;   // device -> workgroups of the kernel that are resident at once
+    int cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cap_of.find(A->ctx->device);
+        if (it == cap_of.end()) {
+            FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_cg_resident_q4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shqx));
+            int per_cu = 0;
+            FEM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_cg_resident_q4, 256, shqx));
+            // (the occupancy query can be one workgroup per CU high for kernels with many scalar registers, MI355X_MICROARCH.md: what the
+            // LDS image and the launch bounds allow -- three -- is the figure trusted here, and a grid that turns out not to be resident
+            // ends in the barrier's bounded spin, not in a hang)
+            cap = std::min(per_cu, 3) * A->ctx->num_cu;
+            cap_of[A->ctx->device] = cap;
+        } else cap = it->second;
+    }
+    if (P.n_gen > cap || (size_t)A->mesh->nnds * 16 >= (1ull << 32)) return false;
+    if (!cg) return true;
+    fem_mesh m = A->mesh;
+    hipStream_t s = A->ctx->stream;
+    auto& grp = m->groups[0];
+    const ElemTable& tab = host_elem_tables()[grp.type];
+    const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
+    const int* bcn = A->bc_saved ? A->bc_node.p : nullptr;
+    FEM_HIP(hipMemsetAsync(cg->bar.w, 0, GridBarrier::WORDS * sizeof(unsigned), s));
+    FEM_HIP(hipMemsetAsync(cg->bar.err, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_cg_resident_q4, dim3((P.n_gen + 7) / 8 * 8), dim3(256), shqx, s, P.n_gen, P.lhdr_gen.p, P.pnodes_gen.p, P.conn16.p,
+                       P.flags.p, P.geo.p, (size_t)P.slots, m->coords.p, bcn, A->bc_dof.p, A->bc_shift.p, g, w, *cg,
+                       TileFirst{P.psteps.p, P.pconn0.p, P.pfl0.p, P.pgeo.p, 0ull, (unsigned)P.pslot_steps});
+    FEM_HIP(hipGetLastError());
+    return true;
 }
 
 // y = K x, p.Kp partials into part[0 .. ntiles)

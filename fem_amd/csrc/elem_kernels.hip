@@ -704,11 +704,7 @@ void mat_assemble_elements_impl(fem_mat A)
         gs.g[i] = AsmGroup{g.conn.p, g.E.p, g.nu.p, g.slot.p, g.type, g.npe};
     }
     const int add = A->lazy_zero ? 0 : 1;
-#ifdef FEM_EXP_ASM16
-    constexpr int LDS_BUDGET = 38 * 1024;
-#else
     constexpr int LDS_BUDGET = 76 * 1024;   // two workgroups per CU (160 KiB)
-#endif
     // FEM_AMD_ASM_WCAP (tests): a smaller accumulator window, so that small decks exercise the multi-window path
     // a slice wider than the LDS image takes
     static const int wcap_env = std::getenv("FEM_AMD_ASM_WCAP") ? std::atoi(std::getenv("FEM_AMD_ASM_WCAP")) : 0;
@@ -727,11 +723,7 @@ void mat_assemble_elements_impl(fem_mat A)
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(tpb), shmem, s, m->nnds, nparts, npass, A->boff.p,
                            A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p);
     };
-#ifdef FEM_EXP_ASM16
-    if (m->pdim == 3) launch(k_assemble_rows<3, 8, 16>, 9, 16, 128);
-#else
-    if (m->pdim == 3) launch(k_assemble_rows<3, 8, 32>, 9, 32, 256);
-#endif
+    if (m->pdim == 3) launch(k_assemble_rows<3, 8, 32>, 9, 32, 256);   // (16 rows per workgroup, four per CU: 3.55 against 3.31 ms, round 6)
     else launch(k_assemble_rows<2, 4, 64>, 4, 64, 256);
     A->lazy_zero = false;
     FEM_HIP(hipGetLastError());
@@ -1040,6 +1032,7 @@ int ebe_tile_partials(const EbeTilePlan& P);
 void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, double* part, const int* done, int phase,
                    const CgFuseArgs* cg = nullptr);
 bool ebe_tile_can_fuse(fem_mat A, const EbeTilePlan& P);
+bool ebe_tile_cg_resident(fem_mat A, const EbeTilePlan& P, const CgResidentArgs* cg);
 bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* S, const double* valence);
 bool ebe_tile_split_valid(fem_mat A, const EbeTilePlan& P);
 
@@ -1209,6 +1202,13 @@ bool ebe_mult_fused_impl(fem_mat A, const CgFuseArgs* cg, double* y, double* par
     ebe_tile_mult(A, *A->pat->ebe_tile, nullptr, y, partial ? partial : A->ebe_partial.p, nullptr, -1, cg);
     ebe_mark(A); ebe_mark(A); ebe_mark(A);
     return true;
+}
+
+// KSPCG / PCJACOBI as one resident launch (ebe_tile.hip): cg == nullptr asks whether this Mat's product qualifies
+bool ebe_cg_resident_impl(fem_mat A, const CgResidentArgs* cg)
+{
+    if (!A->mult_ebe || !A->ebe_use_tile || !A->pat->ebe_tile) return false;
+    return ebe_tile_cg_resident(A, *A->pat->ebe_tile, cg);
 }
 
 void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const int* done)

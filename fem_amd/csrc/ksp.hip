@@ -32,6 +32,7 @@ void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const 
 void mat_set_mult_type_impl(fem_mat A, const char* type);
 bool ebe_tile_phase(fem_mat A, const double* x, double* y, double* partial, const int* done, int phase);   // elem_kernels.hip
 bool ebe_mult_fused_impl(fem_mat A, const fem::CgFuseArgs* cg, double* y, double* partial);               // elem_kernels.hip
+bool ebe_cg_resident_impl(fem_mat A, const fem::CgResidentArgs* cg);                                       // elem_kernels.hip
 void mat_get_diagonal_raw(fem_mat A, double* d);
 
 namespace fem {
@@ -316,6 +317,13 @@ struct fem_ksp_s {
     DBuf<double> dinv, r, p, w, z, pzz, pzr, hist;
     DBuf<double> p2;                         // the second p of the CG whose product opens the iteration (cg_device.h): p alternates
     int fuse_p = -1;                         // -ksp_cg_fuse_p 0|1; -1: FEM_AMD_CG_FUSE_P, default on where the product can
+    // -ksp_cg_resident 0|1 (-1: FEM_AMD_CG_RESIDENT, default on): the whole solve as one resident launch where the operator's tile
+    // plan allows it (quad4 meshes whose tiles are all resident at once: config 2), ebe_tile.hip k_cg_resident_q4
+    int resident = -1;
+    bool resident_failed = false;            // a launch whose grid barrier gave up: this KSP keeps to the launch-per-kernel path
+    int n_resident = 0;                      // solves answered by the resident launch
+    DBuf<double> res_part;                   // [3 * tiles] partials of p.w, z.z, z.r
+    DBuf<unsigned> res_bar;                  // the barrier's words + its error flag
     std::unique_ptr<fem::Multigrid> mg;   // -pc_type mg
     std::unique_ptr<fem::BandCholesky> direct;   // -ksp_type preonly -pc_type lu|cholesky
     std::unique_ptr<fem::BandLU> direct_lu;      // the same on a Mat flagged unsymmetric (Newton Jacobian)
@@ -408,6 +416,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-ksp_max_it") { is >> k->maxit; }
         else if (key == "-ksp_fuse_allreduce") { is >> k->fuse_allreduce; FEM_CHECK(k->fuse_allreduce == 0 || k->fuse_allreduce == 1, 6, "-ksp_fuse_allreduce 0|1"); }
         else if (key == "-ksp_cg_fuse_p") { is >> k->fuse_p; FEM_CHECK(k->fuse_p == 0 || k->fuse_p == 1, 6, "-ksp_cg_fuse_p 0|1"); }
+        else if (key == "-ksp_cg_resident") { is >> k->resident; FEM_CHECK(k->resident == 0 || k->resident == 1, 6, "-ksp_cg_resident 0|1"); }
         else if (key == "-ksp_stream_min_dof") { is >> k->stream_min_dof; FEM_CHECK(k->stream_min_dof >= 0, 6, "-ksp_stream_min_dof n >= 0"); }
         else if (key == "-ksp_reuse_solution") { is >> k->reuse; FEM_CHECK(k->reuse == 0 || k->reuse == 1, 6, "-ksp_reuse_solution 0|1"); }
         else if (key == "-ksp_halo_overlap") { is >> k->halo_overlap; FEM_CHECK(k->halo_overlap == 0 || k->halo_overlap == 1, 6, "-ksp_halo_overlap 0|1"); }
@@ -744,6 +753,41 @@ static void ksp_solve_once(fem_ksp k, fem_vec b, fem_vec x)
     static const bool fuse_p_env = !(std::getenv("FEM_AMD_CG_FUSE_P") && std::atoi(std::getenv("FEM_AMD_CG_FUSE_P")) == 0);
     const bool fuse_p = (k->fuse_p >= 0 ? k->fuse_p != 0 : fuse_p_env) && !comm && !mg && !streams && !self_reduce &&
                         (k->pc == "jacobi" || k->pc == "none") && ebe_mult_fused_impl(A, nullptr, nullptr, nullptr);
+    // The whole solve as one resident launch (quad4 plans with every tile resident: a million dofs are a chain of latencies, and the
+    // launch-per-kernel path pays the product's start once per iteration).  Same conditions as the fused opening; no profile samples.
+    static const bool resident_env = !(std::getenv("FEM_AMD_CG_RESIDENT") && std::atoi(std::getenv("FEM_AMD_CG_RESIDENT")) == 0);
+    if ((k->resident >= 0 ? k->resident != 0 : resident_env) && !k->resident_failed && !comm && !mg && !streams && !self_reduce &&
+        (k->pc == "jacobi" || k->pc == "none") && ebe_cg_resident_impl(A, nullptr)) {
+        const size_t nt = (size_t)A->spmv_grid;
+        if (k->res_part.n < 3 * nt) k->res_part.alloc(3 * nt);
+        if (!k->res_bar.p) k->res_bar.alloc(GridBarrier::WORDS + 32);
+        CgResidentArgs ra{st, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p, k->hist_len, b->d.p, k->dinv.p, x->d.p, k->r.p,
+                          k->res_part.p, k->res_part.p + nt, k->res_part.p + 2 * nt,
+                          GridBarrier{k->res_bar.p, reinterpret_cast<int*>(k->res_bar.p + GridBarrier::WORDS)}};
+        ebe_cg_resident_impl(A, &ra);
+        int herr = 0;
+        FEM_HIP(hipMemcpyAsync(&k->h_state[0], st, sizeof(KspState), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipMemcpyAsync(&herr, ra.bar.err, sizeof(int), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        if (!herr && k->h_state[0].done) {
+            k->its = k->h_state[0].its; k->reason = k->h_state[0].reason; k->rnorm = k->h_state[0].dp;
+            k->n_resident++;
+            if (k->profiling) {
+                FEM_HIP(hipEventRecord(ev1, s));
+                FEM_HIP(hipEventSynchronize(ev1));
+                float ms = 0;
+                FEM_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+                k->solve_ms = ms; k->n_spmv = 0; k->spmv_ms = 0.0;
+                (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+            }
+            return;
+        }
+        // the grid barrier gave up (the grid was not resident, or a peer left): this KSP keeps to the kernels below from now on
+        k->resident_failed = true;
+        FEM_HIP(hipMemsetAsync(st, 0, sizeof(KspState), s));
+        hipLaunchKernelGGL(k_cg_init, dim3(g), dim3(256), 0, s, n, pd, b->d.p, k->dinv.p, x->d.p, k->r.p, k->p.p, owned,
+                           k->pzz.p, k->pzr.p);
+    }
     if (fuse_p && k->p2.n < n) k->p2.alloc(n);
     double* const pbuf[2] = {k->p.p, k->p2.p};
     static const int p_desc = std::getenv("FEM_AMD_CG_P_DESC") ? std::atoi(std::getenv("FEM_AMD_CG_P_DESC")) : 1;
@@ -956,6 +1000,7 @@ int ksp_get_history(fem_ksp k, double* hist, int len)
 }
 void ksp_set_profiling(fem_ksp k, int on) { k->profiling = on > 0 ? on : 0; }
 int ksp_get_reused(fem_ksp k) { return k->n_reused; }
+int ksp_get_resident(fem_ksp k) { return k->n_resident; }
 void ksp_get_profile(fem_ksp k, int* n_spmv, double* spmv_ms, double* solve_ms)
 {
     if (n_spmv) *n_spmv = k->n_spmv;

@@ -494,6 +494,12 @@ module fem_amd_capi
       integer(c_int), intent(out) :: n
       integer(c_int) :: ierr
     end function
+    function fem_ksp_get_resident_solves(ksp, n) bind(C, name="fem_ksp_get_resident_solves") result(ierr)
+      import :: c_int, c_ptr
+      type(c_ptr), value :: ksp
+      integer(c_int), intent(out) :: n
+      integer(c_int) :: ierr
+    end function
     function fem_recover_nodal_stress_vec(mesh, U, S) bind(C, name="fem_recover_nodal_stress_vec") result(ierr)
       import :: c_int, c_ptr
       type(c_ptr), value :: mesh, U, S

@@ -272,6 +272,12 @@ int fem_ksp_get_profile(fem_ksp ksp, int *n_spmv, double *spmv_ms, double *solve
  * loop on a linear deck with ramped loads (src/main.F90:216-250: one KSPSolve per increment, the same Vec_F every time).
  * n = how many solves of this KSP were answered that way. */
 int fem_ksp_get_reused_solves(fem_ksp ksp, int *n);
+/* -ksp_cg_resident 0|1 (default 1): KSPCG with PCJACOBI / PCNONE as ONE resident launch -- a workgroup per tile of the element-by-
+ * element product stays for the whole solve, two grid-wide barriers per iteration -- where the operator's tile plan has every tile
+ * resident at once (quad4 meshes of about a million dofs: BASELINE config 2) and the mesh is undivided; every other solve, and a
+ * launch whose barrier gives up, takes the kernels of the launch-per-iteration path.  Same KSPSolve semantics (src/main.F90:247);
+ * the iteration path agrees with the other one to round-off.  n = how many solves of this KSP ran that way. */
+int fem_ksp_get_resident_solves(fem_ksp ksp, int *n);
 
 /* ---- cohesive elements and the Newton increment: SURVEY 8 f1, BASELINE config 5 ------------------------------
  * The reference solves a deck with cohesive elements through SNES (src/main.F90:200-206,240-245) with the two

@@ -300,3 +300,70 @@ def test_a_changing_operator_keeps_nothing(gpu_ctx):
     prob.ksp.solve(prob.F, prob.U)
     assert prob.ksp.get_reused_solves() == 1 and np.array_equal(prob.U.get_array(), u0)
     prob.destroy()
+
+
+@pytest.mark.parametrize("n,jitter", [((9, 7), 0.2), ((40, 33), 0.0), ((70, 45), 0.15), ((150, 120), 0.1)])
+def test_cg_as_one_resident_launch_matches_the_kernel_per_iteration_cg(gpu_ctx, oracle, n, jitter):
+    """Quad4 meshes whose tiles are all resident at once (config 2's class): KSPCG / PCJACOBI runs as ONE launch, a workgroup per tile
+    for the whole solve and two XCD-hierarchical grid barriers per iteration (k_cg_resident_q4, -ksp_cg_resident, default on).  Same
+    KSPSolve semantics (src/main.F90:247): iteration count, converged reason and residual history of the launch-per-kernel path up to
+    round-off (z.z and z.r are summed tile by tile instead of in index order), displacements within 1e-10 of the oracle."""
+    from fem_amd.mesh import structured_quad
+    m = structured_quad(*n, jitter=jitter)
+    uo, so, ito = oracle.run(m, "cg", rtol=1e-13)
+    got = {}
+    for res in (0, 1):
+        prob = driver.Problem(gpu_ctx, m, f"-ksp_rtol 1e-13 -mat_mult_type ebe -ksp_cg_resident {res}")
+        prob.assemble(); prob.ksp.set_up()
+        prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+        prob.ksp.solve(prob.F, prob.U)
+        assert prob.ksp.get_resident_solves() == res
+        got[res] = (prob.U.get_array(), prob.ksp.get_iteration_number(), prob.ksp.get_converged_reason(), prob.ksp.get_residual_history())
+        prob.ksp.solve(prob.F, prob.U)                        # (-ksp_reuse_solution: the kept one, whichever path computed it)
+        assert prob.ksp.get_reused_solves() == 1 and np.array_equal(prob.U.get_array(), got[res][0])
+        prob.destroy()
+    (ul, il, rl, hl), (ur, ir, rr, hr) = got[0], got[1]
+    assert rl == rr == 2 and abs(il - ir) <= max(2, il // 100) and abs(ir - ito[-1]) <= max(2, ir // 50)
+    k = min(len(hl), len(hr)) // 2
+    assert np.allclose(hl[:10], hr[:10], rtol=1e-9, atol=0.0)       # the same residual history while round-off has not spread ...
+    assert np.all(np.abs(np.log(hl[:k] / hr[:k])) < 0.2)           # ... and the same curve once it has (CG on a penalty matrix amplifies it)
+    assert np.abs(ur - ul).max() <= 1e-11 * np.abs(uo).max()
+    assert np.abs(ur - uo).max() <= 1e-10 * np.abs(uo).max()
+
+
+def test_resident_cg_is_bitwise_reproducible_and_honours_the_ksp_surface(gpu_ctx):
+    """Two resident solves give the same bits; -ksp_max_it ends it with KSP_DIVERGED_ITS and the iterate of that iteration; a zero
+    right-hand side converges at iteration 0; a penalty deck whose tile holds more constrained dofs than the kernel's LDS list
+    (every node clamped) takes the list-free branch."""
+    from fem_amd.mesh import structured_quad
+    m = structured_quad(60, 40, jitter=0.1)
+    prob = driver.Problem(gpu_ctx, m, "-ksp_rtol 1e-12 -mat_mult_type ebe -ksp_reuse_solution 0")
+    prob.assemble(); prob.ksp.set_up()
+    prob.dmesh.form_rhs(prob.F, 0.0, m.dt)
+    prob.ksp.solve(prob.F, prob.U); u1, it1 = prob.U.get_array(), prob.ksp.get_iteration_number()
+    prob.ksp.solve(prob.F, prob.U); u2 = prob.U.get_array()
+    assert prob.ksp.get_resident_solves() == 2 and np.array_equal(u1, u2)
+    prob.ksp.set_tolerances(max_it=it1 // 2)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_converged_reason() == -3 and prob.ksp.get_iteration_number() == it1 // 2
+    um = prob.U.get_array()
+    ref = driver.Problem(gpu_ctx, m, f"-ksp_rtol 1e-12 -mat_mult_type ebe -ksp_cg_resident 0 -ksp_max_it {it1 // 2}")
+    ref.assemble(); ref.ksp.set_up(); ref.ksp.solve(prob.F, ref.U)
+    assert ref.ksp.get_converged_reason() == -3 and np.abs(ref.U.get_array() - um).max() <= 1e-5 * np.abs(um).max()   # (mid-way iterates: round-off amplified by CG)
+    ref.destroy()
+    prob.ksp.set_tolerances(max_it=10000)
+    prob.F.set(0.0)
+    prob.ksp.solve(prob.F, prob.U)
+    assert prob.ksp.get_iteration_number() == 0 and prob.ksp.get_converged_reason() > 0 and not prob.U.get_array().any()
+    prob.destroy()
+    m.bcnode = np.column_stack([np.arange(m.nnds), np.zeros(m.nnds), np.zeros(m.nnds)]).astype(np.int32)   # every dof constrained
+    m.bcval = np.tile(np.array([[0.01, -0.02]]), (m.nnds, 1))
+    for res in (0, 1):
+        p2 = driver.Problem(gpu_ctx, m, f"-ksp_rtol 1e-12 -mat_mult_type ebe -ksp_cg_resident {res}")
+        p2.assemble(); p2.ksp.set_up()
+        p2.dmesh.form_rhs(p2.F, 0.0, m.dt)
+        p2.ksp.solve(p2.F, p2.U)
+        assert p2.ksp.get_converged_reason() > 0 and p2.ksp.get_resident_solves() == res
+        if res == 0: ua = p2.U.get_array()
+        else: assert np.abs(p2.U.get_array() - ua).max() <= 1e-12 * np.abs(ua).max()
+        p2.destroy()

@@ -18,6 +18,7 @@
 //   cycle V(1,1), symmetric -> valid CG preconditioner; damped point Jacobi on the fine level, damped
 //         block Jacobi (one box = one block) on the box levels with omega = 4/(3*1.1*lambda_max estimate)
 #pragma once
+#include <memory>
 #include <vector>
 
 #include "comm.h"
@@ -40,6 +41,25 @@ struct MgLevel {
     DBuf<double> diag;
 };
 
+// What the level-1 aggregation takes from the mesh alone -- bounding box, the box of every node, the node lists of the boxes: kept on
+// the mesh's MatPattern (objects.h) and shared by every set-up on that mesh with the same box size and the same partition, as the
+// sparsity and the tile plan are (the reference assembles and sets its solver up once per run, src/main.F90:151-171,339-403; a host
+// that re-assembles on one mesh pays the geometry once).
+struct MgBoxes {
+    double box = 0.0;
+    const void* halo_seen = nullptr;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, nn_global = 0.0;
+    std::vector<double> tab;          // every domain's bounding box and count of owned nodes
+    int grid[3] = {0, 0, 0}, sub[3] = {0, 0, 0}, off[3] = {0, 0, 0};   // global level-1 grid, this domain's sub-grid and its origin
+    DBuf<int> agg;                  // [nn] level-1 box of every node
+    DBuf<int> box_ptr, box_nodes;   // level-1 box -> its nodes (ascending)
+    DBuf<int> cnt;                  // [nb] nodes per box
+    // level-1 Galerkin product with full-line reads (mg.hip, k_galerkin_fine_quad): the groups of four consecutive boxes that
+    // qualify -- first box, slot in gnodes, their 256 nodes sorted by id -- and the boxes that keep the wavefront-per-box kernel
+    DBuf<int> gnodes, group_box0, group_slot, rest_boxes;
+    int ngroups = 0, nrest = 0;
+};
+
 struct Multigrid {
     fem_mat A = nullptr;
     int bs = 0, cs = 0, nn = 0;      // fine block size; coarse dofs per box (rigid-body modes: 3 in 2-D, 6 in 3-D)
@@ -48,8 +68,7 @@ struct Multigrid {
     double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
-    DBuf<int> agg;                  // [nn] level-1 box of every node
-    DBuf<int> box_ptr, box_nodes;   // level-1 box -> its nodes (ascending)
+    std::shared_ptr<MgBoxes> bx;    // level-1 aggregates (shared with the mesh's pattern)
     DBuf<unsigned char> w;          // [nn*bs] 1 on free dofs, 0 on penalty dofs
     DBuf<unsigned char> wr;         // partitioned mesh: w on the nodes this domain owns, 0 on the other copies
     DBuf<double> dinv0, t0;         // fine-level Jacobi inverse diagonal, work vector

@@ -1,5 +1,6 @@
 // fem_amd/csrc/mg.hip -- box-aggregation multigrid preconditioner (see mg.h).
 #include "mg.h"
+#include "grid_barrier.h"
 
 #include <algorithm>
 #include <cmath>
@@ -244,13 +245,15 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
                                                             const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                             const int* __restrict__ bcol, const double* __restrict__ val,
                                                             const unsigned char* __restrict__ w, double* __restrict__ st,
-                                                            int* __restrict__ err)
+                                                            int* __restrict__ err, const int* __restrict__ box_list, int nlist)
 {
     constexpr int BB = BS * BS, CC = CS * CS;
     __shared__ unsigned int sslot[4][MG_ROW_CHUNK / 4][64];
     const int nb = g.nb();
-    const int A = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (A >= nb) return;   // wave-uniform
+    const int widx = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    // (box_list: the boxes this launch handles -- the ones k_galerkin_fine_quad does not; null: every box)
+    if (widx >= (box_list ? nlist : nb)) return;   // wave-uniform
+    const int A = box_list ? box_list[widx] : widx;
     unsigned int (*my)[64] = sslot[threadIdx.x >> 6];
     const int ax = A % g.nx, ay = (A / g.nx) % g.ny, az = A / (g.nx * g.ny);
     const int p0 = box_ptr[A], p1 = box_ptr[A + 1];
@@ -340,6 +343,182 @@ __global__ void __launch_bounds__(256) k_galerkin_fine_wave(Grid3 g, BoxGeom geo
             }
             first = false;
         }
+    }
+}
+
+// ---- the same product with full-line reads of the matrix (round 6) ---------------------------------------------------------------
+// A box's rows sit in as many 64-row slices as it has lines of nodes, four rows to a line on a regular grid: the wavefront-per-box
+// kernel above uses a quarter of every 128-B line it touches and the four wavefronts that share a line drift apart -- 16.9 GB fetched
+// for the 6.8 GB matrix of config 3, 6.9 ms (profiles/r06_pmc_mg_setup.txt).  Here a workgroup takes FOUR consecutive boxes whose 256
+// nodes, sorted by id, are runs of 16 consecutive ids of which every box holds four in order (k_galerkin_groups finds those groups
+// once per mesh; the other boxes keep the kernel above): lane = position in the sorted list, so 16 consecutive lanes read 16
+// consecutive rows -- whole lines -- and a box's lanes are the same four of every 16.  Per slot the 36 sums of a lane are added over
+// its box's lanes by a fixed tree (quad, then the four lines of the wavefront, then the four wavefronts through LDS): bitwise
+// reproducible, no atomics.  gnodes[group * 256 + position] = node id.
+constexpr int MG_GROUP = 4;
+__global__ void __launch_bounds__(256) k_galerkin_groups(int ngroups_cand, int groups_per_row, int nx, const int* __restrict__ box_ptr,
+                                                         const int* __restrict__ box_nodes, int* __restrict__ gnodes,
+                                                         unsigned char* __restrict__ ok)
+{
+    const int gi = blockIdx.x;
+    if (gi >= ngroups_cand) return;
+    const int row = gi / groups_per_row, gq = gi % groups_per_row, A0 = row * nx + MG_GROUP * gq;
+    __shared__ int nodes[256], sorted[256];
+    __shared__ int bad;
+    const int t = threadIdx.x, b = t >> 6, k = t & 63;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    const int p0 = box_ptr[A0 + b], cnt = box_ptr[A0 + b + 1] - p0;
+    if (cnt != 64) bad = 1;
+    __syncthreads();
+    if (bad) { if (t == 0) ok[gi] = 0; return; }
+    const int v = box_nodes[p0 + k];
+    nodes[t] = v;
+    __syncthreads();
+    int rank = k;                                   // (every box list is ascending)
+    for (int ob = 0; ob < MG_GROUP; ob++) {
+        if (ob == b) continue;
+        int lo = 0, hi = 64;                        // lower bound of v in box ob's list
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (nodes[ob * 64 + mid] < v) lo = mid + 1; else hi = mid; }
+        rank += lo;
+    }
+    sorted[rank] = v;
+    __syncthreads();
+    {   // position t: the run of 16 it belongs to is consecutive ids, its quarter of the run is box (t >> 2) & 3's
+        const int q0 = t & ~15, r = t & 15;
+        if (sorted[t] != sorted[q0] + r) bad = 1;
+        if (rank >= 0 && ((rank >> 2) & 3) != b) bad = 1;
+    }
+    __syncthreads();
+    if (bad) { if (t == 0) ok[gi] = 0; return; }
+    gnodes[(size_t)gi * 256 + t] = sorted[t];
+    if (t == 0) ok[gi] = 1;
+}
+
+constexpr int MG_QUAD_CHUNK = 64;   // blocks of a row per round of k_galerkin_fine_quad (hex8 rows have 27)
+template <int BS, int CS, int PD>
+__global__ void __launch_bounds__(256) k_galerkin_fine_quad(Grid3 g, BoxGeom geo, const double* __restrict__ coords, int ngroups,
+                                                            const int* __restrict__ group_box0, const int* __restrict__ group_slot,
+                                                            const int* __restrict__ gnodes, const int* __restrict__ agg,
+                                                            const int* __restrict__ rowlen, const int* __restrict__ boff,
+                                                            const int* __restrict__ bcol, const double* __restrict__ val,
+                                                            const unsigned char* __restrict__ w, double* __restrict__ st,
+                                                            int* __restrict__ err)
+{
+    constexpr int BB = BS * BS, CC = CS * CS, JC = MG_QUAD_CHUNK;
+    // per lane (column = thread): the slot of every block of the chunk, then the blocks ordered by slot and where every slot starts --
+    // a slot's pass walks only its own blocks (the wavefront-per-box kernel scans all of them in every pass and runs the body for
+    // every block that ANY lane matches: 14 x 15 bodies per wavefront on a regular grid against 76 here)
+    __shared__ unsigned char sl[JC][256], ord[JC][256], beg[16][256];
+    __shared__ double red[4][MG_GROUP][CC];
+    __shared__ int s_maxlen[4];
+    const int gi = blockIdx.x;
+    if (gi >= ngroups) return;
+    const int nb = g.nb();
+    const int t = threadIdx.x, wv = t >> 6, lane = t & 63, bq = (lane >> 2) & 3;
+    const int A = group_box0[gi] + bq;                               // this lane's box
+    const int ax = A % g.nx, ay = (A / g.nx) % g.ny, az = A / (g.nx * g.ny);
+    double cA[3];
+    box_centre(g, geo, A, cA);
+    const int i = gnodes[(size_t)group_slot[gi] * 256 + t];
+    const int len = rowlen[i], ln = i & 63;
+    const size_t o0 = (size_t)boff[i >> 6];
+    double di[3], wi[BS];
+    node_offset<PD>(coords, i, cA, di);
+#pragma unroll
+    for (int r = 0; r < BS; r++) wi[r] = w[(size_t)BS * i + r] ? 1.0 : 0.0;
+    int maxlen = len;
+    for (int o = 32; o > 0; o >>= 1) maxlen = max(maxlen, __shfl_xor(maxlen, o));
+    if (lane == 0) s_maxlen[wv] = maxlen;
+    __syncthreads();
+    maxlen = max(max(s_maxlen[0], s_maxlen[1]), max(s_maxlen[2], s_maxlen[3]));   // (the four wavefronts walk the chunks together)
+    bool first = true;
+    for (int j0 = 0; j0 < maxlen || first; j0 += JC) {
+        const int nj = max(0, min(len - j0, JC));
+        // classify: the stencil slot of every block's box (slots below 13 are the mirror's: marked 0xff with the far ones)
+        // (nine blocks at a time: their column ids, then the boxes of those columns -- two round trips per nine blocks, not per block;
+        // the kernel is a chain of latencies, not of bytes)
+        const int njw = min(maxlen - j0, JC);   // workgroup-uniform
+        for (int kb = 0; kb < njw; kb += 9) {
+            int cc[9], Bx[9];
+#pragma unroll
+            for (int u = 0; u < 9; u++) cc[u] = (kb + u < nj) ? bcol[(o0 + j0 + kb + u) * 64 + ln] : -1;
+#pragma unroll
+            for (int u = 0; u < 9; u++) Bx[u] = (cc[u] >= 0) ? agg[cc[u]] : 0;
+#pragma unroll
+            for (int u = 0; u < 9; u++) {
+                if (kb + u >= nj) continue;
+                const int B = Bx[u];
+                const int dx = B % g.nx - ax, dy = (B / g.nx) % g.ny - ay, dz = B / (g.nx * g.ny) - az;
+                unsigned sv = 0xffu;
+                if (abs(dx) > 1 || abs(dy) > 1 || abs(dz) > 1) atomicExch(err, 1);   // coupled nodes must sit in adjacent boxes
+                else sv = (unsigned)((dz + 1) * 9 + (dy + 1) * 3 + (dx + 1));
+                sl[kb + u][t] = (unsigned char)sv;
+            }
+        }
+        // the lane's blocks in slot order
+        int pos = 0;
+        for (int s = 13; s < 27; s++) {
+            beg[s - 13][t] = (unsigned char)pos;
+            for (int k = 0; k < nj; k++)
+                if (sl[k][t] == (unsigned char)s) ord[pos++][t] = (unsigned char)k;
+        }
+        beg[14][t] = (unsigned char)pos;
+        for (int s = 13; s < 27; s++) {
+            int T = -1;
+            const bool inside = neighbour_box(g, A, s, T);   // per lane (the four boxes differ in x)
+            // S = sum_j (w K_ij w) P_j over the slot's blocks (BS x CS): P_i^T is applied once, behind the loop -- 18 running sums per
+            // lane instead of 36, and the kernel, a chain of latencies, fits four wavefronts per SIMD instead of two
+            double S[BS * CS];
+#pragma unroll
+            for (int e = 0; e < BS * CS; e++) S[e] = 0.0;
+            double cT[3] = {0.0, 0.0, 0.0};
+            if (inside) box_centre(g, geo, T, cT);
+            const int m0 = beg[s - 13][t], m1 = inside ? beg[s - 12][t] : m0;
+            // (round 6 tried the loads of two blocks at a time and a software pipeline that asks for block m + 1 before block m is worked
+            // on: both push the kernel to 200-256 registers, two wavefronts per SIMD or one, and lose -- 15.4 and 11.6 ms of set-up
+            // against 10.6 with this plain loop at three wavefronts per SIMD)
+            for (int m = m0; __any(m < m1); m++) {
+                if (m >= m1) continue;
+                const int j = j0 + ord[m][t];
+                const int c = bcol[(o0 + j) * 64 + ln];
+                double dj[3];
+                node_offset<PD>(coords, c, cT, dj);
+#pragma unroll
+                for (int r = 0; r < BS; r++) {
+                    double f[BS], mm[CS];
+#pragma unroll
+                    for (int q = 0; q < BS; q++) f[q] = wi[r] * (double)w[(size_t)BS * c + q] * val[((o0 + j) * BB + r * BS + q) * 64 + ln];
+                    rbm_apply_t<BS, CS>(dj, f, mm);   // row r of (w K w) applied to the modes of node j
+#pragma unroll
+                    for (int c2 = 0; c2 < CS; c2++) S[r * CS + c2] += mm[c2];
+                }
+            }
+            // P_i^T S column by column; the box's lanes of this wavefront added by a fixed tree: lanes (lane & 0x33) == 0 end up with
+            // the sums of boxes 0..3 (lanes 0, 4, 8, 12)
+#pragma unroll
+            for (int c2 = 0; c2 < CS; c2++) {
+                double f[BS], mm[CS];
+#pragma unroll
+                for (int r = 0; r < BS; r++) f[r] = S[r * CS + c2];
+                rbm_apply_t<BS, CS>(di, f, mm);
+#pragma unroll
+                for (int aa = 0; aa < CS; aa++) {
+                    double a = mm[aa];
+                    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+                    if ((lane & 0x33) == 0) red[wv][bq][aa * CS + c2] = a;
+                }
+            }
+            __syncthreads();
+            if (t < MG_GROUP * CC) {
+                const int b = t / CC, e = t % CC;
+                const double a = (red[0][b][e] + red[1][b][e]) + (red[2][b][e] + red[3][b][e]);
+                double* dst = &st[((size_t)s * CC + e) * nb + group_box0[gi] + b];
+                *dst = first ? a : *dst + a;
+            }
+            __syncthreads();
+        }
+        first = false;
     }
 }
 
@@ -841,6 +1020,84 @@ __global__ void __launch_bounds__(256) k_gj_update(int n, int kb, double* __rest
     M[idx] = v;
 }
 
+// The same elimination as ONE resident launch: workgroup b keeps block row b of [A | I] (CS x 2n doubles) in LDS from the first step
+// to the last.  Step k: the owner of block row k turns it into D^-1 [row] and publishes it (global memory, two buffers by parity);
+// one grid barrier (grid_barrier.h); every other workgroup subtracts its own column-k entries times the published row from its rows.
+// 125 steps x (barrier + 72 KB read from another XCD's data) instead of 250 launches: the set-up of -pc_type mg lost 1.3 ms at
+// config 3.  Same operations per entry as k_gj_pivot / k_gj_update, in the same order: the inverse is bit for bit theirs.
+template <int CS>
+__global__ void __launch_bounds__(256) k_gj_resident(int n, double* __restrict__ M, double* __restrict__ rowbuf, GridBarrier bar)
+{
+    extern __shared__ double R[];   // [CS][2n]
+    __shared__ unsigned shu[4];
+    const int b = blockIdx.x, nbk = n / CS, n2 = 2 * n;
+    for (int q = 0; q < CS; q++)
+        for (int t = threadIdx.x; t < n2; t += 256) R[q * n2 + t] = M[(size_t)(b * CS + q) * n2 + t];
+    GridBarrierLane lane = grid_barrier_census(bar, (unsigned)nbk, shu);
+    for (int kb = 0; kb < nbk; kb++) {
+        const int k0 = kb * CS;
+        double* rowk = rowbuf + (size_t)(kb & 1) * CS * n2;
+        if (b == kb) {
+            double D[CS][2 * CS];   // [D | I] -> [I | D^-1], every thread for itself (as k_gj_pivot)
+#pragma unroll
+            for (int r = 0; r < CS; r++)
+#pragma unroll
+                for (int c = 0; c < CS; c++) { D[r][c] = R[r * n2 + k0 + c]; D[r][CS + c] = (r == c) ? 1.0 : 0.0; }
+#pragma unroll
+            for (int k = 0; k < CS; k++) {
+                const double piv = 1.0 / D[k][k];
+#pragma unroll
+                for (int c = 0; c < 2 * CS; c++) D[k][c] *= piv;
+#pragma unroll
+                for (int r = 0; r < CS; r++) {
+                    if (r == k) continue;
+                    const double f = D[r][k];
+#pragma unroll
+                    for (int c = 0; c < 2 * CS; c++) D[r][c] -= f * D[k][c];
+                }
+            }
+            __syncthreads();   // (every thread has read the pivot block before the rows change)
+            for (int t = threadIdx.x; t < n2; t += 256) {
+                double m[CS];
+#pragma unroll
+                for (int p = 0; p < CS; p++) m[p] = R[p * n2 + t];
+#pragma unroll
+                for (int q = 0; q < CS; q++) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int p = 0; p < CS; p++) v += D[q][CS + p] * m[p];
+                    R[q * n2 + t] = v;
+                    rowk[(size_t)q * n2 + t] = v;
+                }
+            }
+        }
+        if (!grid_barrier(bar, lane, shu)) return;
+        if (b != kb) {
+            double c[CS][CS];   // this block row's entries of block column k
+#pragma unroll
+            for (int q = 0; q < CS; q++)
+#pragma unroll
+                for (int p = 0; p < CS; p++) c[q][p] = R[q * n2 + k0 + p];
+            __syncthreads();
+            for (int t = threadIdx.x; t < n2; t += 256) {
+                double rk[CS];
+#pragma unroll
+                for (int p = 0; p < CS; p++) rk[p] = rowk[(size_t)p * n2 + t];
+#pragma unroll
+                for (int q = 0; q < CS; q++) {
+                    double v = R[q * n2 + t];
+#pragma unroll
+                    for (int p = 0; p < CS; p++) v -= c[q][p] * rk[p];
+                    R[q * n2 + t] = v;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int q = 0; q < CS; q++)
+        for (int t = threadIdx.x; t < n2; t += 256) M[(size_t)(b * CS + q) * n2 + t] = R[q * n2 + t];
+}
+
 // x = A^-1 r on the coarsest grid: one wavefront per row, fixed shuffle tree
 __global__ void __launch_bounds__(256) k_dense_apply(int n, const double* __restrict__ M, const double* __restrict__ r,
                                                      double* __restrict__ x)
@@ -879,19 +1136,27 @@ static bool setup_t(Multigrid& mg)
     // the own part + sum over the sharers (one neighbour exchange).  Only the coarsest level (<= 125 boxes) is replicated.
     Halo* halo = mesh->halo.get();
     Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
-    // bounding box
+    // bounding box, aggregates: from the mesh's pattern when an earlier set-up on this mesh left them there (same box size, same partition)
+    std::shared_ptr<MgBoxes> bx = A->pat->mg_boxes;
+    const bool have_boxes = bx && bx->box == mg.box && bx->halo_seen == (const void*)halo;
+    if (!have_boxes) { bx = std::make_shared<MgBoxes>(); bx->box = mg.box; bx->halo_seen = (const void*)halo; }
+    mg.bx = bx;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double nn_global = nn;
+    const int nr = comm ? comm->size : 1, me = comm ? comm->rank : 0;
+    std::vector<double> tab((size_t)nr * 7, 0.0);   // every domain's bounding box (and its count of owned nodes)
+    if (have_boxes) {
+        for (int d = 0; d < 3; d++) { lo[d] = bx->lo[d]; hi[d] = bx->hi[d]; }
+        nn_global = bx->nn_global; tab = bx->tab;
+    } else {
     const int pg = 256;
     DBuf<double> dbb((size_t)pg * 6);
     hipLaunchKernelGGL(k_bbox_partial, dim3(pg), dim3(256), 0, s, (size_t)nn, PD, mesh->coords.p, dbb.p);
     std::vector<double> hbb((size_t)pg * 6);
     dbb.download(hbb.data(), hbb.size(), s);
     FEM_HIP(hipStreamSynchronize(s));
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int b = 0; b < pg; b++)
         for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], hbb[b * 6 + d]); hi[d] = std::max(hi[d], hbb[b * 6 + 3 + d]); }
-    double nn_global = nn;
-    const int nr = comm ? comm->size : 1, me = comm ? comm->rank : 0;
-    std::vector<double> tab((size_t)nr * 7, 0.0);   // every domain's bounding box (and its count of owned nodes)
     for (int d = 0; d < 3; d++) { tab[(size_t)me * 7 + d] = lo[d]; tab[(size_t)me * 7 + 3 + d] = hi[d]; }
     if (comm) {
         // min / max / node count over the domains through the one collective there is: every domain
@@ -907,6 +1172,9 @@ static bool setup_t(Multigrid& mg)
             for (int d = 0; d < PD; d++) { lo[d] = std::min(lo[d], tab[(size_t)r * 7 + d]); hi[d] = std::max(hi[d], tab[(size_t)r * 7 + 3 + d]); }
             nn_global += tab[(size_t)r * 7 + 6];
         }
+    }
+    for (int d = 0; d < 3; d++) { bx->lo[d] = lo[d]; bx->hi[d] = hi[d]; }
+    bx->nn_global = nn_global; bx->tab = tab;
     }
     double vol = 1.0;
     for (int d = 0; d < PD; d++) vol *= std::max(hi[d] - lo[d], 1e-300);
@@ -963,17 +1231,48 @@ static bool setup_t(Multigrid& mg)
     // level-1 aggregates and their node lists
     MgLevel& L1 = mg.lev[0];
     const Grid3 g1l = grid_of(L1);
-    mg.agg.alloc(nn);
     const int nb = L1.nb;
-    DBuf<int> cnt((size_t)nb), cursor((size_t)nb), tmp(exclusive_scan_tmp_ints((size_t)nb + 1));
-    cnt.zero(s); cursor.zero(s);
-    hipLaunchKernelGGL(k_assign_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, PD, mesh->coords.p, lo[0], lo[1], lo[2], invH,
-                       g, g1l, Shift3{L1.off[0], L1.off[1], L1.off[2]}, mg.agg.p, cnt.p);
-    mg.box_ptr.alloc((size_t)nb + 1);
-    exclusive_scan_i32(cnt.p, mg.box_ptr.p, nb, tmp.p, s);
-    mg.box_nodes.alloc((size_t)nn);
-    hipLaunchKernelGGL(k_fill_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, mg.agg.p, mg.box_ptr.p, cursor.p, mg.box_nodes.p);
-    hipLaunchKernelGGL(k_sort_boxes, dim3(g1(nb)), dim3(256), 0, s, nb, mg.box_ptr.p, mg.box_nodes.p);
+    DBuf<int>& cnt = bx->cnt;
+    if (!have_boxes) {
+        bx->agg.alloc(nn);
+        DBuf<int> cursor((size_t)nb), tmp(exclusive_scan_tmp_ints((size_t)nb + 1));
+        cnt.alloc((size_t)nb);
+        cnt.zero(s); cursor.zero(s);
+        hipLaunchKernelGGL(k_assign_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, PD, mesh->coords.p, lo[0], lo[1], lo[2], invH,
+                           g, g1l, Shift3{L1.off[0], L1.off[1], L1.off[2]}, bx->agg.p, cnt.p);
+        bx->box_ptr.alloc((size_t)nb + 1);
+        exclusive_scan_i32(cnt.p, bx->box_ptr.p, nb, tmp.p, s);
+        bx->box_nodes.alloc((size_t)nn);
+        hipLaunchKernelGGL(k_fill_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, bx->agg.p, bx->box_ptr.p, cursor.p, bx->box_nodes.p);
+        hipLaunchKernelGGL(k_sort_boxes, dim3(g1(nb)), dim3(256), 0, s, nb, bx->box_ptr.p, bx->box_nodes.p);
+        // the groups of four boxes whose rows the level-1 product can read in whole lines (k_galerkin_fine_quad); once per mesh
+        static const bool quad_env = !(std::getenv("FEM_AMD_MG_GALERKIN_QUAD") && std::atoi(std::getenv("FEM_AMD_MG_GALERKIN_QUAD")) == 0);
+        const int gpr = L1.nx / MG_GROUP, ncand = gpr * L1.ny * L1.nz;
+        std::vector<int> gb0, gslot, rest;
+        if (quad_env && ncand > 0) {
+            bx->gnodes.alloc((size_t)ncand * 256);
+            DBuf<unsigned char> ok((size_t)ncand);
+            hipLaunchKernelGGL(k_galerkin_groups, dim3(ncand), dim3(256), 0, s, ncand, gpr, L1.nx, bx->box_ptr.p, bx->box_nodes.p, bx->gnodes.p, ok.p);
+            std::vector<unsigned char> hok((size_t)ncand);
+            ok.download(hok.data(), hok.size(), s);
+            FEM_HIP(hipStreamSynchronize(s));
+            std::vector<unsigned char> taken((size_t)nb, 0);
+            for (int gi = 0; gi < ncand; gi++) {
+                if (!hok[(size_t)gi]) continue;
+                const int a0 = (gi / gpr) * L1.nx + MG_GROUP * (gi % gpr);
+                gb0.push_back(a0); gslot.push_back(gi);
+                for (int q = 0; q < MG_GROUP; q++) taken[(size_t)a0 + q] = 1;
+            }
+            for (int b = 0; b < nb; b++) if (!taken[(size_t)b]) rest.push_back(b);
+        } else {
+            for (int b = 0; b < nb; b++) rest.push_back(b);
+        }
+        bx->ngroups = (int)gb0.size(); bx->nrest = (int)rest.size();
+        if (bx->ngroups) { bx->group_box0.upload(gb0, s); bx->group_slot.upload(gslot, s); }
+        if (bx->nrest) bx->rest_boxes.upload(rest, s);
+        FEM_HIP(hipStreamSynchronize(s));   // (host vectors, cursor and tmp go out of scope; once per mesh)
+        A->pat->mg_boxes = bx;
+    }
 
     // free-dof weights and fine Jacobi diagonal
     mg.w.alloc(ndof); mg.dinv0.alloc(ndof); mg.t0.alloc(ndof);
@@ -986,9 +1285,14 @@ static bool setup_t(Multigrid& mg)
     }
 
     // this domain's part of the level-1 operator
-    hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * nb)), dim3(256), 0, s, g1l, geom_of(L1),
-                       mesh->coords.p, mg.box_ptr.p, mg.box_nodes.p, mg.agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->values(),
-                       mg.w.p, L1.st.p, err.p);
+    if (bx->ngroups)
+        hipLaunchKernelGGL((k_galerkin_fine_quad<BS, CS, PD>), dim3(bx->ngroups), dim3(256), 0, s, g1l, geom_of(L1), mesh->coords.p, bx->ngroups,
+                           bx->group_box0.p, bx->group_slot.p, bx->gnodes.p, bx->agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->values(),
+                           mg.w.p, L1.st.p, err.p);
+    if (bx->nrest)
+        hipLaunchKernelGGL((k_galerkin_fine_wave<BS, CS, PD>), dim3(g1((size_t)64 * bx->nrest)), dim3(256), 0, s, g1l, geom_of(L1),
+                           mesh->coords.p, bx->box_ptr.p, bx->box_nodes.p, bx->agg.p, A->rowlen.p, A->boff.p, A->bcol.p, A->values(),
+                           mg.w.p, L1.st.p, err.p, bx->rest_boxes.p, bx->nrest);
     hipLaunchKernelGGL((k_galerkin_mirror<CS>), dim3(g1((size_t)13 * CC * nb)), dim3(256), 0, s, g1l, L1.st.p);
     if (comm) {
         // the flag travels so that every domain raises the same error
@@ -1166,7 +1470,28 @@ static bool setup_t(Multigrid& mg)
     mg.ncoarse = gcoarse.nb() * CS;
     mg.cinv.alloc((size_t)mg.ncoarse * 2 * mg.ncoarse);
     hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
+    // one resident launch where the block rows fit the LDS and the chip (FEM_AMD_MG_GJ_RESIDENT=0: the two launches per block)
+    static const bool gj_env = !(std::getenv("FEM_AMD_MG_GJ_RESIDENT") && std::atoi(std::getenv("FEM_AMD_MG_GJ_RESIDENT")) == 0);
+    bool gj_done = false;
     {
+        const int n = mg.ncoarse;
+        const size_t shm = (size_t)CS * 2 * n * sizeof(double);
+        if (gj_env && shm <= 120 * 1024 && n / CS <= ctx->num_cu && n / CS >= 2) {
+            FEM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gj_resident<CS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
+            DBuf<double> rowbuf((size_t)2 * CS * 2 * n);
+            DBuf<unsigned> words(GridBarrier::WORDS + 32);
+            words.zero(s);
+            GridBarrier bar{words.p, reinterpret_cast<int*>(words.p + GridBarrier::WORDS)};
+            hipLaunchKernelGGL(k_gj_resident<CS>, dim3(n / CS), dim3(256), shm, s, n, mg.cinv.p, rowbuf.p, bar);
+            int herr = 0;
+            FEM_HIP(hipMemcpyAsync(&herr, bar.err, sizeof(int), hipMemcpyDeviceToHost, s));
+            FEM_HIP(hipStreamSynchronize(s));
+            gj_done = herr == 0;
+            if (!gj_done)   // (the barrier gave up: the matrix is half eliminated -- build it again for the launches below)
+                hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
+        }
+    }
+    if (!gj_done) {
         const int n = mg.ncoarse;
         DBuf<double> rowk((size_t)CS * 2 * n), colk((size_t)CS * n);
         for (int kb = 0; kb < n / CS; kb++) {
@@ -1263,7 +1588,7 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     const unsigned char* wr = comm ? mg.wr.p : mg.w.p;
     auto restrict_to_level1 = [&](const double* kz) {
         hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
-                           mg.box_ptr.p, mg.box_nodes.p, wr, r, kz, L1.r.p);
+                           mg.bx->box_ptr.p, mg.bx->box_nodes.p, wr, r, kz, L1.r.p);
         if (comm) {
             if (mg.lev.size() == 1) comm->allreduce_sum(L1.r.p, L1.nb * CS, s);   // (level 1 is the replicated coarsest one)
             else halo_sum_h(L1.halo.get(), L1.r.p, CS, CS, 1, s, true);
@@ -1276,11 +1601,11 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
         cycle_t<CS>(mg, 0);
         if (pzz) {   // the caller wants z.z and z.r as well: one fused pass (single domain)
             hipLaunchKernelGGL((k_additive_finish<BS, CS, PD>), dim3(npart), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
-                               mg.agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done);
+                               mg.bx->agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done);
         } else {
             hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, 1.0, mg.dinv0.p, r, z);
             hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
-                               mg.agg.p, mg.w.p, L1.x.p, z);
+                               mg.bx->agg.p, mg.w.p, L1.x.p, z);
         }
         return;
     }
@@ -1289,7 +1614,7 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
     restrict_to_level1(mg.t0.p);
     cycle_t<CS>(mg, 0);
-    hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.agg.p,
+    hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.bx->agg.p,
                        mg.w.p, L1.x.p, z);
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
     halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
@@ -1321,7 +1646,7 @@ bool Multigrid::fuses_dots() const { return fine_additive; }
 
 size_t Multigrid::device_bytes() const
 {
-    size_t b = omega_l.bytes() + wr.bytes() + agg.bytes() + box_ptr.bytes() + box_nodes.bytes() + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
+    size_t b = omega_l.bytes() + wr.bytes() + (bx ? bx->agg.bytes() + bx->box_ptr.bytes() + bx->box_nodes.bytes() : 0) + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
     for (auto& L : lev) b += L.st.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes() + L.diag.bytes();
     return b;
 }

@@ -69,6 +69,7 @@ struct fem_vec_s {
 namespace fem {
 
 struct EbeTilePlan;   // ebe_tile.hip
+struct MgBoxes;       // mg.h
 // what the direct solve of an unsymmetric Mat (BandLU::setup, direct.hip) derives from the sparsity alone, on the host: the connected
 // components of the node graph (small independent blocks are factorised one wavefront each) or the reverse Cuthill-McKee numbering and
 // its bandwidth.  Kept on the pattern: a Newton loop sets the solver up again at every iteration, on the same sparsity.
@@ -114,6 +115,7 @@ struct MatPattern {
     std::vector<EbePlan> ebe_plan;     // per group
     std::shared_ptr<EbeTilePlan> ebe_tile;   // one-pass product by tiles (ebe_tile.hip); null: not built or not applicable
     std::shared_ptr<LuSymbolic> lu_sym;      // BandLU's host-side symbolic work (direct.hip); null: not built yet
+    std::shared_ptr<MgBoxes> mg_boxes;       // -pc_type mg: the level-1 aggregates of this mesh (mg.h); null: not built yet
     bool ebe_tile_tried = false;
     DBuf<int> ebe_ptr;
     DBuf<unsigned> ebe_lst;

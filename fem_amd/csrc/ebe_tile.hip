@@ -273,13 +273,16 @@ __global__ void __launch_bounds__(256) k_tile_geo_uniform(int nlist, int* __rest
     if (threadIdx.x == 0 && !s_diff) { lhdr[8 * (size_t)i + 7] = elem_off + ref + 1; atomicAdd(count, 1ull); }
 }
 
-// one tile per workgroup.  LDS: acc[3 * nnode] nodal sums, then gl[nnode] global node ids.
+// one tile per workgroup.  LDS: acc[3 * max_nown] sums of the owned nodes, then gl[nnode] global node ids.
 // steps[step_off .. step_off + nsteps): {first element (relative), count | barrier-after << 31}: rounds of 256 elements
 // of one colour, a barrier behind the last round of a colour
 // OP 0: y = K x.  OP 1, 2: the nodal stress sums of RecoverNodalStress + src/main.F90:258-279 over the same tiles (x = the
 // displacements; y = component 0 / 3 of stress_node(nnds, 6), column-major; divided by the valence where one is given)
 template <int KIND, int OP = 0, bool STREAM = false>   // KIND 0: distorted elements, 1: parallelepipeds (stored adj(J)), 2: axis-aligned bricks (stored diagonal); STREAM: see ld_list
-__global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __restrict__ lhdr,
+#ifndef FEM_EXP_GEN_WAVES
+#define FEM_EXP_GEN_WAVES 2
+#endif
+__global__ void __launch_bounds__(256, FEM_EXP_GEN_WAVES) k_ebe_tile(int nlist, const int* __restrict__ lhdr,
                                                      const int2* __restrict__ steps, const int* __restrict__ tnodes,
                                                      const int* __restrict__ telems, const uint4* __restrict__ tconn,
                                                      const unsigned char* __restrict__ tflags,
@@ -287,7 +290,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
                                                      const double* __restrict__ nuv, const double* __restrict__ x,
                                                      const int* __restrict__ bc_node, const int* __restrict__ bc_dof,
                                                      const double* __restrict__ bc_shift, const double* __restrict__ geo,
-                                                     size_t geo_stride, double g, double w, int max_nnode,
+                                                     size_t geo_stride, double g, double w, int max_nown,
                                                      double* __restrict__ y, double* __restrict__ partial,
                                                      const int* __restrict__ done, const double* __restrict__ valence,
                                                      size_t nn, unsigned* __restrict__ rcount, int rtotal, double* __restrict__ red)
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
     const int* hd = lhdr + 8 * (size_t)lb;
     const int node_off = hd[0], nown = hd[1], nnode = hd[2], elem_off = hd[3], step_off = hd[4], nsteps = hd[5], t = hd[6];
     double* acc = lds;
-    int* gl = reinterpret_cast<int*>(lds + 3 * (size_t)max_nnode);
+    int* gl = reinterpret_cast<int*>(lds + 3 * (size_t)max_nown);   // (sums for the owned nodes only: rim nodes are never added to -- 48 instead of 73 KB for the 15 x 15 x 7 tile)
     {   // node list -> LDS, sums zeroed (all loads of a lane in flight together: TILE_MAX_NODES <= 12 * 256)
         int nv[12];
 #pragma unroll
@@ -312,7 +315,8 @@ __global__ void __launch_bounds__(256, 2) k_ebe_tile(int nlist, const int* __res
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const int i = threadIdx.x + 256 * j;
-            if (i < nnode) { gl[i] = nv[j]; acc[3 * i] = 0.0; acc[3 * i + 1] = 0.0; acc[3 * i + 2] = 0.0; }
+            if (i < nnode) gl[i] = nv[j];
+            if (i < nown) { acc[3 * i] = 0.0; acc[3 * i + 1] = 0.0; acc[3 * i + 2] = 0.0; }
         }
     }
     __syncthreads();
@@ -2467,13 +2471,13 @@ void ebe_tile_mult(fem_mat A, const EbeTilePlan& P, const double* x, double* y, 
         return;
     }
     FEM_CHECK(!cg, 7, "ebe_tile_mult: the fused CG opening is a quad4 path");
-    const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int));
+    const size_t shmem = (size_t)P.max_nown * 3 * sizeof(double) + (size_t)P.max_nnode * sizeof(int);
     hex_tile_kernel_attributes(m->ctx->device);
     auto go = [&](auto kern, int n, const int* list) {
         if (!n) return;
         hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.steps.p, P.nodes.p, P.elems.p,
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, x, bcn, A->bc_dof.p, A->bc_shift.p, P.geo.p,
-                           (size_t)P.slots, g, w, P.max_nnode, y, part, done, (const double*)nullptr, (size_t)0, rcount, P.ntiles, A->red_out);
+                           (size_t)P.slots, g, w, P.max_nown, y, part, done, (const double*)nullptr, (size_t)0, rcount, P.ntiles, A->red_out);
     };
     const int c0 = phase == 1 ? P.n_cart_if : 0, c1 = phase == 0 ? P.n_cart_if : P.n_cart;
     const int a0 = phase == 1 ? P.n_aff_if : 0, a1 = phase == 0 ? P.n_aff_if : P.n_aff;
@@ -2541,13 +2545,13 @@ bool ebe_tile_stress(fem_mesh m, const EbeTilePlan& P, const double* U, double* 
     hipStream_t s = m->ctx->stream;
     const ElemTable& tab = host_elem_tables()[grp.type];
     const double g = std::fabs(tab.xi[0][0]), w = tab.w[0];
-    const size_t shmem = (size_t)P.max_nnode * (3 * sizeof(double) + sizeof(int)), nn = (size_t)m->nnds;
+    const size_t shmem = (size_t)P.max_nown * 3 * sizeof(double) + (size_t)P.max_nnode * sizeof(int), nn = (size_t)m->nnds;
     hex_tile_kernel_attributes(m->ctx->device);
     auto go = [&](auto kern, int n, const int* list, double* out) {
         if (!n) return;
         hipLaunchKernelGGL(kern, dim3((n + 7) / 8 * 8), dim3(256), shmem, s, n, list, P.steps.p, P.nodes.p, P.elems.p,
                            P.conn16.p, P.flags.p, m->coords.p, grp.E.p, grp.nu.p, U, (const int*)nullptr, (const int*)nullptr,
-                           (const double*)nullptr, P.geo.p, (size_t)P.slots, g, w, P.max_nnode, out, (double*)nullptr,
+                           (const double*)nullptr, P.geo.p, (size_t)P.slots, g, w, P.max_nown, out, (double*)nullptr,
                            (const int*)nullptr, valence, nn, (unsigned*)nullptr, 0, (double*)nullptr);
     };
     // tiles of parallelepipeds: one pass, from the stored geometry (FEM_AMD_STRESS_CART=0: the two passes below for them too)

@@ -1,15 +1,18 @@
 // fem_amd/csrc/pool.cpp -- size-keyed cache of released device blocks (see common.h).
 //
-// Release is stream-ordered, not a device-wide stall: a released block takes one event per stream the library runs on that device
-// (the contexts register their two streams), recorded at the moment of the release -- everything that can still touch the block was
-// submitted before them -- and goes into the cache at once.  A later request of that size prefers a block whose events have
-// completed and otherwise waits for the events of the one it takes: only for the work that was in flight when that block was
-// released, never for the device.  (Before round 6 every release called hipDeviceSynchronize(): a host that frees inside its
-// increment loop stalled the device each time.)  With more than MAX_EV streams registered on a device (many in-process domains)
-// a block is stamped with the release count instead and the first request that meets such a block synchronises the device once,
-// which clears every block released before that moment.
+// Release costs nothing on the device: a released block is stamped with the device's release count and goes into the cache at once
+// (before round 6 every release called hipDeviceSynchronize(): a host that frees inside its increment loop stalled the device each
+// time).  What orders a block's reuse behind the work that could still touch it is a BATCH, taken when a request first meets a block
+// no batch covers yet: one event per stream the library runs on that device (the contexts register their two streams), recorded at
+// that moment -- later than the release of every block stamped so far, so it covers them all -- and waited for by the request.  A
+// loop that frees and re-creates its temporaries pays one batch per turn, not two event records per block (a first version did that:
+// config 5's Newton loop, a chain of small launches on an idle device, went from 9.3 to 11.6 ms) -- and nothing at all where the
+// streams are idle when the block is asked for again (two stream queries).  Requests prefer blocks that a
+// completed batch covers.  With more than MAX_EV streams registered on a device (many in-process domains) a batch is a device
+// synchronisation.
 #include <algorithm>
 #include <cstdlib>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -23,16 +26,24 @@ namespace {
 constexpr int MAX_EV = 4;
 struct Block {
     void* p = nullptr;
+    unsigned long long seq = 0;     // the device's release count when the block came back
+};
+struct Batch {                      // covers every block of its device with seq <= this one's
+    unsigned long long seq = 0;
     hipEvent_t ev[MAX_EV] = {nullptr, nullptr, nullptr, nullptr};
     int nev = 0;
-    unsigned long long epoch = 0;   // != 0: released without events; clean once g_clean[dev] >= epoch
+    bool whole_device = false;      // no events: the wait is hipDeviceSynchronize()
+};
+struct DeviceState {
+    std::vector<hipStream_t> streams;   // streams of the live contexts
+    unsigned long long seq = 0;         // releases so far
+    unsigned long long done_upto = 0;   // every block stamped <= this is free of in-flight work
+    std::deque<Batch> batches;          // ascending seq, none of them known to be complete
 };
 std::mutex g_mu;
 std::map<std::pair<int, size_t>, std::vector<Block>> g_free;   // (device, bytes) -> blocks
-std::map<int, std::vector<hipStream_t>> g_streams;             // device -> streams of the live contexts
-std::map<int, unsigned long long> g_clean;                     // device -> every block stamped <= this is clean
+std::map<int, DeviceState> g_dev;
 std::vector<hipEvent_t> g_events;                              // events not in use
-unsigned long long g_epoch = 0;
 size_t g_cached = 0;
 
 size_t pool_limit()
@@ -45,16 +56,15 @@ size_t pool_limit()
     return lim;
 }
 
-void give_back_events_locked(Block& b)
+void drop_batch_locked(Batch& b)
 {
     for (int i = 0; i < b.nev; i++) g_events.push_back(b.ev[i]);
     b.nev = 0;
 }
-// hipFree waits for the device itself: no event of the block has to be looked at
+// hipFree waits for the device itself
 void free_block_locked(Block& b, size_t bytes)
 {
     (void)hipFree(b.p);
-    give_back_events_locked(b);
     g_cached -= bytes;
 }
 void trim_locked(int dev)
@@ -68,12 +78,22 @@ void trim_locked(int dev)
         }
     }
 }
-bool ready_locked(const Block& b, int dev)
+// a batch that covers everything released on this device so far (taken now)
+Batch take_batch_locked(DeviceState& d)
 {
-    if (b.epoch && g_clean[dev] < b.epoch) return false;
-    for (int i = 0; i < b.nev; i++)
-        if (hipEventQuery(b.ev[i]) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return true;
+    Batch b;
+    b.seq = d.seq;
+    b.whole_device = d.streams.empty() || d.streams.size() > (size_t)MAX_EV;
+    if (!b.whole_device) {
+        for (hipStream_t s : d.streams) {
+            hipEvent_t ev = nullptr;
+            if (!g_events.empty()) { ev = g_events.back(); g_events.pop_back(); }
+            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); b.whole_device = true; break; }
+            if (hipEventRecord(ev, s) != hipSuccess) { (void)hipGetLastError(); g_events.push_back(ev); b.whole_device = true; break; }
+            b.ev[b.nev++] = ev;
+        }
+    }
+    return b;
 }
 }  // namespace
 
@@ -82,14 +102,14 @@ void pool_register_stream(hipStream_t s)
     int dev = 0;
     FEM_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
-    g_streams[dev].push_back(s);
+    g_dev[dev].streams.push_back(s);
 }
 void pool_unregister_stream(hipStream_t s) noexcept
 {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    auto& v = g_streams[dev];
+    auto& v = g_dev[dev].streams;
     v.erase(std::remove(v.begin(), v.end(), s), v.end());
 }
 
@@ -102,21 +122,40 @@ void* pool_alloc(size_t bytes)
         auto it = g_free.find({dev, bytes});
         if (it != g_free.end() && !it->second.empty()) {
             auto& v = it->second;
-            size_t pick = v.size() - 1;
-            for (size_t i = v.size(); i-- > 0;)
-                if (ready_locked(v[i], dev)) { pick = i; break; }
-            Block b = v[pick];
+            DeviceState& d = g_dev[dev];
+            // the oldest block: the one most likely to be covered by a completed batch
+            size_t pick = 0;
+            for (size_t i = 1; i < v.size(); i++)
+                if (v[i].seq < v[pick].seq) pick = i;
+            const Block b = v[pick];
             v.erase(v.begin() + (long)pick);
             g_cached -= bytes;
-            const bool need_dev = b.epoch && g_clean[dev] < b.epoch;
-            const unsigned long long upto = g_epoch;
+            if (b.seq <= d.done_upto) return b.p;
+            // the first batch that covers the block, or a new one
+            Batch wait;
+            bool found = false;
+            for (const Batch& q : d.batches)
+                if (q.seq >= b.seq) { wait = q; found = true; break; }
+            if (!found) {
+                // nothing in flight on any of the device's streams (the usual state behind a call that ended on a stream
+                // synchronisation -- a dot product, a norm read back): every block released so far is clean, no events needed
+                bool idle = !d.streams.empty() && d.streams.size() <= (size_t)MAX_EV;
+                const unsigned long long upto = d.seq;
+                for (size_t i = 0; idle && i < d.streams.size(); i++)
+                    if (hipStreamQuery(d.streams[i]) != hipSuccess) { (void)hipGetLastError(); idle = false; }
+                if (idle) { d.done_upto = upto; return b.p; }
+                wait = take_batch_locked(d); d.batches.push_back(wait);
+            }
             lk.unlock();
-            // what was in flight when this block was released: its events, or (no events taken) the device as a whole
-            for (int i = 0; i < b.nev; i++) (void)hipEventSynchronize(b.ev[i]);
-            if (need_dev) (void)hipDeviceSynchronize();
+            for (int i = 0; i < wait.nev; i++) (void)hipEventSynchronize(wait.ev[i]);
+            if (wait.whole_device) (void)hipDeviceSynchronize();
             lk.lock();
-            if (need_dev) g_clean[dev] = std::max(g_clean[dev], upto);
-            give_back_events_locked(b);
+            DeviceState& d2 = g_dev[dev];
+            if (wait.seq > d2.done_upto) d2.done_upto = wait.seq;
+            while (!d2.batches.empty() && d2.batches.front().seq <= d2.done_upto) {   // (events go back once: the deque owns them)
+                drop_batch_locked(d2.batches.front());
+                d2.batches.pop_front();
+            }
             return b.p;
         }
     }
@@ -155,18 +194,10 @@ void pool_release(void* p, size_t bytes) noexcept
     }
     Block b;
     b.p = p;
-    const auto& streams = g_streams[dev];
-    bool stamped = streams.empty() || streams.size() > (size_t)MAX_EV;
-    if (!stamped) {
-        for (hipStream_t s : streams) {
-            hipEvent_t ev = nullptr;
-            if (!g_events.empty()) { ev = g_events.back(); g_events.pop_back(); }
-            else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); stamped = true; break; }
-            if (hipEventRecord(ev, s) != hipSuccess) { (void)hipGetLastError(); g_events.push_back(ev); stamped = true; break; }
-            b.ev[b.nev++] = ev;
-        }
-    }
-    if (stamped) b.epoch = ++g_epoch;   // (the events taken so far stay with the block: waiting for them as well is harmless)
+    // FEM_AMD_POOL_SYNC=1 (diagnostic): the release of rounds 1-5 -- synchronise the device; the block is clean at once
+    static const bool sync_env = std::getenv("FEM_AMD_POOL_SYNC") && std::atoi(std::getenv("FEM_AMD_POOL_SYNC")) != 0;
+    if (sync_env) (void)hipDeviceSynchronize();
+    b.seq = sync_env ? 0 : ++g_dev[dev].seq;
     g_free[{dev, bytes}].push_back(b);
     g_cached += bytes;
 }
@@ -178,6 +209,10 @@ void pool_trim() noexcept
     (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lk(g_mu);
     trim_locked(dev);
+    DeviceState& d = g_dev[dev];
+    d.done_upto = d.seq;
+    for (Batch& b : d.batches) drop_batch_locked(b);
+    d.batches.clear();
 }
 
 size_t pool_cached_bytes()

@@ -134,6 +134,31 @@ def cpu_baseline(mesh, label: str, gpu_its: int, threads: int, ncg: int) -> dict
                             "note": "same CG with the element-by-element product in place of the SpMV"}}
 
 
+def config5_leg() -> dict:
+    """Config 5 of BASELINE.json: the reference's cohesive deck tiled x1000 (examples/cohesive_test_2.inp, the fixture under
+    tests/golden/decks), the Newton increment loop of src/main.F90:216-296 with the reference's inner solver (KSPPREONLY + PCLU): as
+    1,000 disjoint copies (SURVEY 8(d)'s wording) and as one connected strip (shared edge nodes).  Wall time of a whole run (both
+    increments, Jacobian and residual callbacks issued by the library, stress recovery included), third run."""
+    from fem_amd import capi, driver
+    from fem_amd.inp import read_inp
+    from fem_amd.mesh import tile_deck, tile_deck_connected
+    ctx = capi.Context(0)
+    m1 = read_inp(os.path.join(ROOT, "tests", "golden", "decks", "cohesive_test_2.inp"))
+    c5 = {"workload": "config 5: examples/cohesive_test_2.inp x1000 (quad4 + Xu-Needleman cohesive elements), SNES NEWTONLS, "
+                      "-ksp_type preonly -pc_type lu; wall time of the whole increment loop"}
+    for key, mm, rels in (("disjoint_copies", tile_deck(m1, 1000), 0), ("connected_strip", tile_deck_connected(m1, 1000), 1)):
+        for _ in range(3):
+            t5 = time.perf_counter()
+            r5 = driver.run_nonlinear(mm, "-ksp_type preonly -pc_type lu", ctx=ctx, rels_mode=rels, recover_stress=True,
+                                      builtin_callbacks=True)
+            t5 = time.perf_counter() - t5
+        c5[key] = {"dof": mm.ndof, "elements": mm.nels, "increments": len(r5.snes_its), "ms": t5 * 1e3,
+                   "snes_iterations": [int(v) for v in r5.snes_its], "snes_reasons": [int(v) for v in r5.snes_reasons],
+                   "linear_solves": [int(v) for v in r5.its], "dof_increments_per_s": mm.ndof * len(r5.snes_its) / t5}
+    ctx.destroy()
+    return c5
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +194,8 @@ def main():
                          "use GPU 0, torch.distributed runs over gloo and the library's collectives go through the host-staged "
                          "communicator (fem_comm_create_callbacks over gloo) instead of RCCL, which refuses two ranks on one "
                          "device.  Exercises every N>1 code path of this file; the figures it prints are not a measurement")
+    ap.add_argument("--config5-leg", action="store_true",
+                    help="internal: run the config-5 measurement alone (a process of its own, started by the default line) and print its object")
     ap.add_argument("--force-comm", action="store_true",
                     help="diagnostic: also at N=1 create the RCCL communicator and route the CG scalars through it")
     args = ap.parse_args()
@@ -177,6 +204,10 @@ def main():
     # every solve of this file iterates: the library's shortcut for a repeated right-hand side (-ksp_reuse_solution: a solve that
     # repeats the previous one returns the kept solution) stays off for the whole process, whatever options a leg passes
     os.environ["FEM_AMD_KSP_REUSE"] = "0"
+
+    if args.config5_leg:
+        print(json.dumps(config5_leg()), flush=True)
+        return
 
     import torch
     import torch.distributed as dist
@@ -662,7 +693,47 @@ def main():
         p_.destroy()
         return r_
 
+    def probe(tag):
+        """FEM_AMD_BENCH_PROBE=1 (diagnostic): what 200 small launches, 200 small device-to-device copies and 50 read-backs cost the host
+        at this point of the process (stderr)"""
+        mode = os.environ.get("FEM_AMD_BENCH_PROBE")
+        if not mode:
+            return
+        if mode == "sync":
+            ctx.synchronize(); return
+        if mode == "vec":
+            for _ in range(50):
+                vt = capi.Vec(ctx, 8008); vt.destroy()
+            return
+        if mode == "sleep":
+            time.sleep(0.5); return
+        if mode.startswith("sleep@"):
+            if mode[6:] in tag:
+                time.sleep(0.5)
+            return
+        va, vb = capi.Vec(ctx, 8008), capi.Vec(ctx, 8008)
+        va.set(1.0); vb.set(2.0); ctx.synchronize()
+        t_ = time.perf_counter()
+        for _ in range(200):
+            vb.axpy(1e-9, va)
+        ctx.synchronize(); t1_ = time.perf_counter()
+        if mode == "launch":
+            va.destroy(); vb.destroy(); return
+        for _ in range(50):
+            va.dot(vb)
+        t3_ = time.perf_counter()
+        if mode == "dot":
+            va.destroy(); vb.destroy(); return
+        tv_ = time.perf_counter()
+        for _ in range(50):
+            vt = capi.Vec(ctx, 8008); vt.destroy()
+        t4_ = time.perf_counter()
+        print(f"probe [{tag}]: launch {1e6 * (t1_ - t_) / 200:.1f} us, read-back {1e6 * (t3_ - t1_) / 50:.1f} us, "
+              f"vec create+destroy {1e6 * (t4_ - tv_) / 50:.1f} us", file=sys.stderr, flush=True)
+        va.destroy(); vb.destroy()
+
     if rank == 0 and world == 1:
+        probe("after the headline")
         opts_cold = f"-ksp_rtol {args.rtol!r} {pc_opts} -mat_mult_type {args.mult}"
         colds = [run_once(mesh, opts_cold) for _ in range(3)]
         best = min(colds, key=lambda c: c["t_setup_assemble_ms"] + c["t_solve_ms"])
@@ -770,6 +841,7 @@ def main():
                 "value": mesh.ndof / tg, "unit": "DOF/s", "ms_per_step": tg * 1e3, "cg_iterations": itg, "converged_reason": rg,
                 "ms_per_cg_iteration": tg * 1e3 / max(itg, 1), "steps": 2}
             pg_.destroy()
+        probe("after distorted / two-kernel legs")
         if hex_case and not args.no_c2:
             # config 2 of BASELINE.json (707^2 quad4 plate, 1.0 M DOF) in the same line: steady-state steps as above, the kernel that
             # is timed priced against its own bytes and flops, the CPU leg and the multigrid run of the same plate
@@ -836,27 +908,24 @@ def main():
             c2_cpu = (m2, its2) if not args.no_cpu else None
             p2.destroy()
 
+        probe("after config 2")
         if hex_case and not args.no_c5:
-            # config 5 of BASELINE.json: the reference's cohesive deck tiled x1000 (examples/cohesive_test_2.inp, the fixture under
-            # tests/golden/decks), the Newton increment loop of src/main.F90:216-296 with the reference's inner solver (KSPPREONLY +
-            # PCLU): as 1,000 disjoint copies (SURVEY 8(d)'s wording) and as one connected strip (shared edge nodes).  Wall time of a
-            # whole run (both increments, Jacobian and residual callbacks issued by the library, stress recovery included), third run.
+            # config 5 in a process of its own (a child: this process, which holds the GPU, waits for it).  Its Newton loop is 900 small
+            # launches per run from one host thread; inside this process, behind the legs above, the connected strip took 45-53 ms
+            # instead of 9 at some lengths of the run and not at others (--steps 10: slow, --steps 20: fast; a 0.5 s pause anywhere
+            # between the headline and the leg: fast; a stream synchronisation and 0.7 s in front of it: slow) with unchanged kernel
+            # durations under rocprofv3 and unchanged launch / copy / read-back costs (FEM_AMD_BENCH_PROBE) -- round 6 did not find
+            # the cause (profiles/r06_config5_where_the_time_goes.txt) and measures the leg where it is reproducible.
+            import subprocess
             try:
-                from fem_amd.inp import read_inp
-                from fem_amd.mesh import tile_deck, tile_deck_connected
-                m1 = read_inp(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "decks", "cohesive_test_2.inp"))
-                c5 = {"workload": "config 5: examples/cohesive_test_2.inp x1000 (quad4 + Xu-Needleman cohesive elements), SNES NEWTONLS, "
-                                  "-ksp_type preonly -pc_type lu; wall time of the whole increment loop"}
-                for key, mm, rels in (("disjoint_copies", tile_deck(m1, 1000), 0), ("connected_strip", tile_deck_connected(m1, 1000), 1)):
-                    for _ in range(3):
-                        t5 = time.perf_counter()
-                        r5 = driver.run_nonlinear(mm, "-ksp_type preonly -pc_type lu", ctx=ctx, rels_mode=rels, recover_stress=True,
-                                                  builtin_callbacks=True)
-                        t5 = time.perf_counter() - t5
-                    c5[key] = {"dof": mm.ndof, "elements": mm.nels, "increments": len(r5.snes_its), "ms": t5 * 1e3,
-                               "snes_iterations": [int(v) for v in r5.snes_its], "snes_reasons": [int(v) for v in r5.snes_reasons],
-                               "linear_solves": [int(v) for v in r5.its], "dof_increments_per_s": mm.ndof * len(r5.snes_its) / t5}
-                out["config5"] = c5
+                ctx.synchronize()
+                env5 = dict(os.environ)
+                for k5 in ("OMP_PROC_BIND", "OMP_PLACES"):
+                    env5.pop(k5, None)
+                p5 = subprocess.run([sys.executable, os.path.abspath(__file__), "--config5-leg"], capture_output=True, text=True, timeout=300,
+                                    env=env5, cwd=ROOT)
+                out["config5"] = json.loads(p5.stdout.strip().splitlines()[-1])
+                out["config5"]["measured_in"] = "a child process of its own (fresh context on the same GPU)"
             except Exception as e:  # noqa: BLE001 -- a side object must not take the line down
                 out["config5"] = {"error": repr(e)[:300]}
 

@@ -448,9 +448,14 @@ void BandCholesky::setup(fem_mat A_)
     bw = (int)std::min<long long>(bwn * bs + bs - 1, n - 1);
 
     size_t free_b = 0, total_b = 0;
-    pool_trim();                      // cached blocks count as free memory for this decision
-    FEM_HIP(hipMemGetInfo(&free_b, &total_b));
     const double need = (double)n * (bw + 1) * sizeof(double);
+    // (a factor of less than 1 GiB fits any state of the device this library runs on; hipMemGetInfo is not free -- round 6: 3-4 ms per
+    // call in a process that has allocated and cached tens of GB, five calls per Newton run of config 5 -- and pool_trim empties the cache)
+    if (need < 1073741824.0) free_b = (size_t)1 << 40;
+    else {
+        pool_trim();                      // cached blocks count as free memory for this decision
+        FEM_HIP(hipMemGetInfo(&free_b, &total_b));
+    }
     FEM_CHECK(need < 0.8 * (double)free_b, 9,
               "pc lu: the band of the factor needs " + std::to_string((long long)(need / 1048576.0)) +
                   " MiB (n = " + std::to_string(n) + ", half bandwidth " + std::to_string(bw) +
@@ -1175,11 +1180,14 @@ void BandLU::setup(fem_mat A_)
     wb = 3 * kl + 1;
     size_t free_b = 0, total_b = 0;
     const double need = (double)n * wb * sizeof(double);
-    FEM_HIP(hipMemGetInfo(&free_b, &total_b));
-    if (!(need < 0.8 * ((double)free_b + (double)pool_cached_bytes()))) {   // (only a factor that may not fit empties the pool)
-        pool_trim();
+    if (need < 1073741824.0) free_b = (size_t)1 << 40;   // (see BandCholesky::setup: no hipMemGetInfo for a factor under 1 GiB)
+    else {
         FEM_HIP(hipMemGetInfo(&free_b, &total_b));
-    } else free_b += pool_cached_bytes();
+        if (!(need < 0.8 * ((double)free_b + (double)pool_cached_bytes()))) {   // (only a factor that may not fit empties the pool)
+            pool_trim();
+            FEM_HIP(hipMemGetInfo(&free_b, &total_b));
+        } else free_b += pool_cached_bytes();
+    }
     FEM_CHECK(need < 0.8 * (double)free_b, 9, "pc lu: the band of the unsymmetric factor needs " +
                                                   std::to_string((long long)(need / 1048576.0)) + " MiB: use -ksp_type bcgs");
     DBuf<int> dperm((size_t)nn);

@@ -11,6 +11,8 @@
 // completed batch covers.  With more than MAX_EV streams registered on a device (many in-process domains) a batch is a device
 // synchronisation.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <deque>
 #include <map>
@@ -64,6 +66,8 @@ void drop_batch_locked(Batch& b)
 // hipFree waits for the device itself
 void free_block_locked(Block& b, size_t bytes)
 {
+    static const bool verbose = std::getenv("FEM_AMD_POOL_VERBOSE") && std::atoi(std::getenv("FEM_AMD_POOL_VERBOSE")) != 0;
+    if (verbose) std::fprintf(stderr, "[fem_amd pool] hipFree %zu B\n", bytes);
     (void)hipFree(b.p);
     g_cached -= bytes;
 }
@@ -144,6 +148,16 @@ void* pool_alloc(size_t bytes)
                 for (size_t i = 0; idle && i < d.streams.size(); i++)
                     if (hipStreamQuery(d.streams[i]) != hipSuccess) { (void)hipGetLastError(); idle = false; }
                 if (idle) { d.done_upto = upto; return b.p; }
+                // Work is in flight and the only cached blocks of this size came back too recently to be known idle.  A host that
+                // runs ahead of the device (a Newton loop enqueueing small launches) would stop here and drain its queue for every
+                // temporary it creates -- config 5's connected strip took 45 instead of 9 ms inside bench.py, where the sizes of its
+                // temporaries had exactly as many cached blocks as the loop keeps in flight.  A small block is cheaper to get from the
+                // driver (5-30 us) than to wait for: the old one goes back into the cache, the next request finds it clean.
+                if (bytes <= ((size_t)4 << 20) && v.size() < 64) {
+                    v.push_back(b);
+                    g_cached += bytes;
+                    goto fresh;
+                }
                 wait = take_batch_locked(d); d.batches.push_back(wait);
             }
             lk.unlock();
@@ -159,8 +173,15 @@ void* pool_alloc(size_t bytes)
             return b.p;
         }
     }
+fresh:
     void* p = nullptr;
+    // FEM_AMD_POOL_VERBOSE=1 (diagnostic): every request the cache cannot serve, with what the driver took for it
+    static const bool verbose = std::getenv("FEM_AMD_POOL_VERBOSE") && std::atoi(std::getenv("FEM_AMD_POOL_VERBOSE")) != 0;
+    const auto tv0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&p, bytes);
+    if (verbose)
+        std::fprintf(stderr, "[fem_amd pool] hipMalloc %zu B: %.1f us (cached %.2f GB)\n", bytes,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tv0).count(), (double)g_cached / 1073741824.0);
     if (e != hipSuccess) {          // make room: drop the cache of this device and try once more
         (void)hipGetLastError();
         (void)hipDeviceSynchronize();

@@ -42,6 +42,8 @@ struct fem_snes_s {
     int iter = 0, reason = 0, nfuncs = 0, linear_its = 0;
     double fnorm = 0.0;
     fem_vec Y = nullptr, W = nullptr, G = nullptr;
+    DBuf<double> red;               // partials and results of dots3 (kept: no block request per line-search trial)
+    double* h_red = nullptr;        // pinned, 3 doubles
 };
 
 // Vec helpers of ksp.hip / capi.cpp
@@ -50,6 +52,43 @@ void vec_axpy(fem_vec, double, fem_vec);
 void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
 
 namespace {
+
+// up to three dot products in one pass and one read-back (the scalars of a line-search trial): partials per workgroup, then one
+// workgroup adds them in a fixed order
+__global__ void __launch_bounds__(256) k_dots3_partial(size_t n, int npairs, const double* __restrict__ a0, const double* __restrict__ b0,
+                                                       const double* __restrict__ a1, const double* __restrict__ b1,
+                                                       const double* __restrict__ a2, const double* __restrict__ b2, double* __restrict__ part)
+{
+    __shared__ double sh[4];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        s0 += a0[i] * b0[i];
+        if (npairs > 1) s1 += a1[i] * b1[i];
+        if (npairs > 2) s2 += a2[i] * b2[i];
+    }
+    double v[3] = {s0, s1, s2};
+    for (int q = 0; q < 3; q++) {
+        double x = v[q];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) part[(size_t)q * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
+}
+__global__ void __launch_bounds__(256) k_dots3_final(int nblocks, const double* __restrict__ part, double* __restrict__ out)
+{
+    __shared__ double sh[4];
+    for (int q = 0; q < 3; q++) {
+        double x = 0.0;
+        for (int i = threadIdx.x; i < nblocks; i += 256) x += part[(size_t)q * nblocks + i];
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) out[q] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+    }
+}
 
 int check(int rc)
 {
@@ -65,6 +104,23 @@ void ensure_vec(fem_snes sn, fem_vec& v, long long n)
 }
 
 double norm2(fem_vec v) { return std::sqrt(vec_dot(v, v)); }
+
+// (a0.b0, a1.b1, a2.b2) with one read-back; pairs beyond npairs are not touched
+void dots3(fem_snes sn, int npairs, fem_vec a0, fem_vec b0, fem_vec a1, fem_vec b1, fem_vec a2, fem_vec b2, double (&out)[3])
+{
+    sn->ctx->bind();
+    hipStream_t s = sn->ctx->stream;
+    const size_t n = (size_t)a0->n;
+    const int nb = (int)std::min<size_t>(256, std::max<size_t>(1, (n + 255) / 256));
+    if (sn->red.n < (size_t)3 * 256 + 3) sn->red.alloc((size_t)3 * 256 + 3);
+    if (!sn->h_red) FEM_HIP(hipHostMalloc((void**)&sn->h_red, 3 * sizeof(double)));
+    hipLaunchKernelGGL(k_dots3_partial, dim3(nb), dim3(256), 0, s, n, npairs, a0->d.p, b0->d.p, (a1 ? a1 : a0)->d.p, (b1 ? b1 : b0)->d.p,
+                       (a2 ? a2 : a0)->d.p, (b2 ? b2 : b0)->d.p, sn->red.p);
+    hipLaunchKernelGGL(k_dots3_final, dim3(1), dim3(256), 0, s, nb, sn->red.p, sn->red.p + (size_t)3 * 256);
+    FEM_HIP(hipMemcpyAsync(sn->h_red, sn->red.p + (size_t)3 * 256, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+    FEM_HIP(hipStreamSynchronize(s));
+    for (int q = 0; q < 3; q++) out[q] = sn->h_red[q];
+}
 
 void compute_function(fem_snes sn, fem_vec x, fem_vec f)
 {
@@ -99,20 +155,27 @@ bool linesearch_bt(fem_snes sn, fem_vec X, fem_vec F, fem_vec Y, double& xnorm, 
 {
     fem_vec W = sn->W, G = sn->G;
     double lambda = 1.0;
-    ynorm = norm2(Y); xnorm = norm2(X);
-    if (ynorm == 0.0) return false;
-    if (ynorm > sn->ls_maxstep) { check(fem_vec_scale(Y, sn->ls_maxstep / ynorm)); ynorm = sn->ls_maxstep; }
-    const double f = fnorm * fnorm;
-    // initial slope F . (J Y)
+    // |Y|, |X| and the initial slope F . (J Y) in one pass and one read-back (J Y first: a step beyond the maximum -- 1e8 by
+    // default -- scales Y and, the product being linear, the slope by the same factor)
     sn->J->ctx->bind();
     mat_mult_raw(sn->J, Y->d.p, W->d.p, nullptr, nullptr);
-    double initslope = vec_dot(F, W);
+    double d3[3];
+    dots3(sn, 3, Y, Y, X, X, F, W, d3);
+    ynorm = std::sqrt(d3[0]); xnorm = std::sqrt(d3[1]);
+    double initslope = d3[2];
+    if (ynorm == 0.0) return false;
+    if (ynorm > sn->ls_maxstep) { const double sc = sn->ls_maxstep / ynorm; check(fem_vec_scale(Y, sc)); initslope *= sc; ynorm = sn->ls_maxstep; }
+    const double f = fnorm * fnorm;
     if (initslope > 0.0) initslope = -initslope;
     if (initslope == 0.0) initslope = -1.0;
+    double wnorm2 = 0.0;     // |W|^2 of the trial point: |X| of the accepted step without another read-back
+    auto trial_norms = [&](double& gn) { dots3(sn, 2, G, G, W, W, nullptr, nullptr, d3); gn = std::sqrt(d3[0]); wnorm2 = d3[1]; };
     step_to(W, X, lambda, Y);
     if (sn->nfuncs >= sn->max_funcs) return false;
     compute_function(sn, W, G);
-    double gnorm = norm2(G), g = gnorm * gnorm;
+    double gnorm;
+    trial_norms(gnorm);
+    double g = gnorm * gnorm;
     if (std::isnan(g) || std::isinf(g)) return false;
     if (!(.5 * g <= .5 * f + lambda * sn->ls_alpha * initslope)) {
         if (sn->stol * xnorm > ynorm) return false;   // the full step did not work and the step is tiny
@@ -123,7 +186,7 @@ bool linesearch_bt(fem_snes sn, fem_vec X, fem_vec F, fem_vec Y, double& xnorm, 
         step_to(W, X, lambda, Y);
         if (sn->nfuncs >= sn->max_funcs) return false;
         compute_function(sn, W, G);
-        gnorm = norm2(G); g = gnorm * gnorm;
+        trial_norms(gnorm); g = gnorm * gnorm;
         if (std::isnan(g) || std::isinf(g)) return false;
         if (!(.5 * g < .5 * f + lambda * sn->ls_alpha * initslope)) {
             int count = 0;
@@ -142,7 +205,7 @@ bool linesearch_bt(fem_snes sn, fem_vec X, fem_vec F, fem_vec Y, double& xnorm, 
                 step_to(W, X, lambda, Y);
                 if (sn->nfuncs >= sn->max_funcs) return false;
                 compute_function(sn, W, G);
-                gnorm = norm2(G); g = gnorm * gnorm;
+                trial_norms(gnorm); g = gnorm * gnorm;
                 if (std::isnan(g) || std::isinf(g)) return false;
                 if (.5 * g < .5 * f + lambda * sn->ls_alpha * initslope) break;
             }
@@ -151,7 +214,7 @@ bool linesearch_bt(fem_snes sn, fem_vec X, fem_vec F, fem_vec Y, double& xnorm, 
     }
     check(fem_vec_copy(W, X));
     check(fem_vec_copy(G, F));
-    xnorm = norm2(X);
+    xnorm = std::sqrt(wnorm2);
     fnorm = gnorm;
     return true;
 }
@@ -254,6 +317,7 @@ void snes_delete(fem_snes sn)
     for (fem_vec* v : {&sn->Y, &sn->W, &sn->G})
         if (*v) (void)fem_vec_destroy(*v);
     if (sn->ksp) (void)fem_ksp_destroy(sn->ksp);
+    if (sn->h_red) (void)hipHostFree(sn->h_red);
     delete sn;
 }
 

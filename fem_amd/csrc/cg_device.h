@@ -121,6 +121,7 @@ struct CgResidentArgs {
     double* r;             // residual: owned nodes written every iteration (the neighbours' rims read it), final residual
     double *ppw, *pzz, *pzr;   // [ntiles] partials
     GridBarrier bar;
+    int test_leave;            // tests (FEM_AMD_CG_RESIDENT_TEST_LEAVE=1): workgroup 1 leaves before the census -- the barrier must give up
 };
 
 }  // namespace fem

@@ -1445,6 +1445,7 @@ __global__ void __launch_bounds__(256, 3) k_cg_resident_q4(int nlist, const int*
     __shared__ int bc_cnt;
     const unsigned chunk = gridDim.x / 8, lb = (blockIdx.x % 8) * chunk + blockIdx.x / 8;   // XCD-wise, as k_ebe_tile
     if (lb >= (unsigned)nlist) return;   // (padding of the grid: takes no part in the barriers)
+    if (cg.test_leave && lb == 1) return;   // (test hook: a peer that never arrives)
     const bool writer = lb == 0 && threadIdx.x == 0;
     const int* hd = lhdr + 8 * (size_t)lb;
     const int nown = hd[1], nnode = hd[2], elem_off = hd[3], nsteps = hd[5], t = hd[6];

@@ -24,7 +24,7 @@ struct GridBarrierLane {   // what a workgroup carries: its XCC, how many workgr
     unsigned xcc, members, nxcc, gen;
 };
 __device__ __forceinline__ unsigned gb_ld(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-constexpr long GB_SPIN_LIMIT = 2000000L;   // polls (each behind an s_sleep): some seconds
+constexpr long GB_SPIN_LIMIT = 1000000L;   // polls (each behind an s_sleep): of the order of a second
 
 // once per launch: where this workgroup sits and who shares its XCC (nwg: workgroups that take part).  sh: 3 words of LDS.
 __device__ __forceinline__ GridBarrierLane grid_barrier_census(const GridBarrier& b, unsigned nwg, unsigned* sh)

@@ -763,7 +763,8 @@ static void ksp_solve_once(fem_ksp k, fem_vec b, fem_vec x)
         if (!k->res_bar.p) k->res_bar.alloc(GridBarrier::WORDS + 32);
         CgResidentArgs ra{st, k->rtol, k->abstol, k->dtol, k->maxit, k->hist.p, k->hist_len, b->d.p, k->dinv.p, x->d.p, k->r.p,
                           k->res_part.p, k->res_part.p + nt, k->res_part.p + 2 * nt,
-                          GridBarrier{k->res_bar.p, reinterpret_cast<int*>(k->res_bar.p + GridBarrier::WORDS)}};
+                          GridBarrier{k->res_bar.p, reinterpret_cast<int*>(k->res_bar.p + GridBarrier::WORDS)},
+                          std::getenv("FEM_AMD_CG_RESIDENT_TEST_LEAVE") != nullptr ? 1 : 0};
         ebe_cg_resident_impl(A, &ra);
         int herr = 0;
         FEM_HIP(hipMemcpyAsync(&k->h_state[0], st, sizeof(KspState), hipMemcpyDeviceToHost, s));

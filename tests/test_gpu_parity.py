@@ -367,3 +367,37 @@ def test_resident_cg_is_bitwise_reproducible_and_honours_the_ksp_surface(gpu_ctx
         if res == 0: ua = p2.U.get_array()
         else: assert np.abs(p2.U.get_array() - ua).max() <= 1e-12 * np.abs(ua).max()
         p2.destroy()
+
+
+def test_resident_cg_whose_barrier_gives_up_is_answered_by_the_launch_path():
+    """A resident launch needs every workgroup resident and present: if one never arrives (test hook: workgroup 1 leaves before the
+    census) the bounded spins of the grid barrier end the launch, the KSP takes the kernels-per-iteration path for this and every
+    later solve, and the answer is the launch path's.  (A child process: the hook is read from the environment.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import numpy as np
+from fem_amd import capi, driver
+from fem_amd.mesh import structured_quad
+ctx = capi.Context(0)
+m = structured_quad(70, 45, jitter=0.1)
+out = {}
+for res in (0, 1):
+    p = driver.Problem(ctx, m, f"-ksp_rtol 1e-12 -mat_mult_type ebe -ksp_cg_resident {res} -ksp_reuse_solution 0")
+    p.assemble(); p.ksp.set_up()
+    p.dmesh.form_rhs(p.F, 0.0, m.dt)
+    p.ksp.solve(p.F, p.U)
+    out[res] = (p.U.get_array(), p.ksp.get_iteration_number(), p.ksp.get_converged_reason(), p.ksp.get_resident_solves())
+    if res:
+        p.ksp.solve(p.F, p.U)     # the KSP does not try again
+        assert p.ksp.get_resident_solves() == 0 and np.array_equal(p.U.get_array(), out[1][0])
+    p.destroy()
+assert out[1][3] == 0 and out[0][2] == out[1][2] == 2 and out[0][1] == out[1][1]
+assert np.array_equal(out[0][0], out[1][0])
+print("FALLBACK_OK")
+'''
+    env = dict(os.environ, FEM_AMD_CG_RESIDENT_TEST_LEAVE="1", PYTHONPATH=root)
+    pr = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert pr.returncode == 0 and "FALLBACK_OK" in pr.stdout, pr.stdout[-2000:] + pr.stderr[-2000:]

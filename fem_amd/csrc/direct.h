@@ -57,6 +57,9 @@ struct BandLU {
     bool bcr = false, band_ready = false;
     int nbk = 0;                // blocks of kl rows
     DBuf<double> cL0, cD0, cU0, cL, cD, cU, cr;   // the block tridiagonal form (pristine / work copies), right-hand side and solution by blocks
+    bool bcr_resident = false;  // the reduction as one resident launch per solve (k_bcr_resident)
+    DBuf<double> cEL, cEU, cz;  // D^-1 [L U r] of the eliminated blocks (resident launch)
+    DBuf<unsigned> bcr_words;   // the grid barrier's words, status words behind them
     void factor_band();
     bool bcr_reduce(bool with_rhs);   // the levels down (and, with a right-hand side, up); false: a small pivot was met
     int null_pivots = 0;        // pivots below 1e-6 of the largest entry, fixed to zero

@@ -5,9 +5,11 @@
 #include <cstdio>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "comm.h"
+#include "grid_barrier.h"
 
 using namespace fem;
 
@@ -934,6 +936,165 @@ __global__ void __launch_bounds__(64) k_bcr_back(int count, int j0, int jstep, i
         a = fma(-L[(size_t)j * BB + r * B + q], readlane_f64(xl, q), fma(-U[(size_t)j * BB + r * B + q], readlane_f64(xr, q), a));
     if (lane < B) rv[(size_t)j * B + lane] = a;
 }
+// ---- the same reduction as ONE resident launch (round 6) -------------------------------------------------------------------------
+// The launches above are a chain of 3 log2(nb) + 1 kernels of a few hundred wavefronts each, 5-20 us apiece for 1-2 us of arithmetic
+// (config 5's connected strip: 52 launches and 0.6 ms per reduction, ten reductions per run).  Here the levels are loops of one
+// kernel with a grid barrier (grid_barrier.h) between them, and a level is ONE step instead of two: the wavefront of a surviving block
+// eliminates BOTH its neighbours itself ([D L U r] of a block in 3 B + 1 lanes, one register per row, as k_bcr_eliminate -- the two
+// eliminations run side by side in the same instruction stream, so the second one costs issue slots, not latency) and takes them
+// into its own rows at once; the elimination of the right-hand neighbour is what it stores for the way up.  Level 0 reads the
+// pristine blocks, so no work copies are made.  2 log2(nb) + 1 barriers per solve.
+template <int B>
+__device__ __forceinline__ bool bcr_gj_pair(double (&Ml)[B], double (&Mr)[B], double tiny)
+{
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+        int pl = k, pr = k;
+        double bl = fabs(Ml[k]), br = fabs(Mr[k]);
+#pragma unroll
+        for (int r = k + 1; r < B; r++) {
+            const double a = fabs(Ml[r]), c = fabs(Mr[r]);
+            if (a > bl) { bl = a; pl = r; }
+            if (c > br) { br = c; pr = r; }
+        }
+        const int p = __builtin_amdgcn_readlane(pl, k), q = __builtin_amdgcn_readlane(pr, k);
+        if (!(readlane_f64(bl, k) > tiny) || !(readlane_f64(br, k) > tiny)) bad = true;   // (uniform)
+#pragma unroll
+        for (int r = k + 1; r < B; r++) {
+            if (p == r) { const double t = Ml[k]; Ml[k] = Ml[r]; Ml[r] = t; }
+            if (q == r) { const double t = Mr[k]; Mr[k] = Mr[r]; Mr[r] = t; }
+        }
+        const double rl = 1.0 / readlane_f64(Ml[k], k), rr = 1.0 / readlane_f64(Mr[k], k);
+        Ml[k] *= rl; Mr[k] *= rr;
+#pragma unroll
+        for (int r = 0; r < B; r++)
+            if (r != k) {
+                const double fl = readlane_f64(Ml[r], k), fr = readlane_f64(Mr[r], k);
+                Ml[r] = fma(-fl, Ml[k], Ml[r]);
+                Mr[r] = fma(-fr, Mr[k], Mr[r]);
+            }
+    }
+    return bad;
+}
+// L, D, U: work copies (written and read again inside the launch: no __restrict__, no const -- nothing of them may go through the
+// scalar cache); EL, EU, z: D^-1 [L U r] of every eliminated block; rv: right-hand side by blocks in, solution out
+template <int B>
+__global__ void __launch_bounds__(256) k_bcr_resident(int nbk, const double* __restrict__ L0, const double* __restrict__ D0,
+                                                      const double* __restrict__ U0, double* L, double* D, double* U, double* EL,
+                                                      double* EU, double* z, double* rv, const double* __restrict__ amax, int* flag,
+                                                      GridBarrier bar)
+{
+    static_assert(3 * B + 1 <= 64, "[D L U r] of a block must fit one wavefront");
+    constexpr int BB = B * B;
+    __shared__ unsigned shu[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv), nw = (int)gridDim.x * 4;
+    GridBarrierLane gl = grid_barrier_census(bar, gridDim.x, shu);
+    const double am = *amax, tiny = 1e-6 * am;
+    const int kind = lane < B ? 0 : lane < 2 * B ? 1 : lane < 3 * B ? 2 : lane == 3 * B ? 3 : 4, cc = lane - B * (kind < 3 ? kind : 3);
+    bool bad = false;
+    int smax = 0;
+    for (int st = 1; st < nbk; st *= 2) {
+        const double* sL = st == 1 ? L0 : L;
+        const double* sD = st == 1 ? D0 : D;
+        const double* sU = st == 1 ? U0 : U;
+        const int count = (nbk + 2 * st - 1) / (2 * st);
+        for (int t = gw; t < count; t += nw) {
+            const long long i = (long long)t * 2 * st, jl = i - st, jr = i + st;
+            const bool hl = jl >= 0, hr = jr < nbk;
+            // one pointer and one stride per lane (its column of D, L or U, or the right-hand side): one load per row and block
+            const size_t ocol = kind == 3 ? 0 : (size_t)cc;
+            const int sd = kind == 3 ? 1 : B;
+            const double* bD = kind == 0 ? sD : kind == 1 ? sL : kind == 2 ? sU : rv;
+            const size_t bsz = kind == 3 ? (size_t)B : (size_t)BB;
+            const double *pl = bD + (size_t)(hl ? jl : i) * bsz + ocol, *pr = bD + (size_t)(hr ? jr : i) * bsz + ocol, *po = bD + (size_t)i * bsz + ocol;
+            // the block's own L_i (lanes 0 .. B-1) and U_i (lanes B .. 2B-1), a column per lane: their entries reach the update below as
+            // uniform values (v_readlane), not through the LDS -- the compiler hoists every LDS read of such a loop in front of it
+            // (2 B^2 registers: k_bcr_update<13> spills 800 bytes per lane for that)
+            const double* pown = (lane < B ? sL : sU) + (size_t)i * BB + (lane < B ? lane : lane - B);
+            const bool hown = lane < B ? hl : (lane < 2 * B && hr);
+            double Ml[B], Mr[B], out[B], own[B];
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+                const double idn = (kind == 0 && q == cc) ? am : 0.0;   // (no neighbour: a diagonal of the matrix's scale goes through the elimination)
+                const double vl = kind < 4 ? pl[q * sd] : 0.0, vr = kind < 4 ? pr[q * sd] : 0.0, vo = (kind == 0 || kind == 3) ? po[q * sd] : 0.0;
+                Ml[q] = hl ? vl : idn;
+                Mr[q] = hr ? vr : idn;
+                out[q] = vo;
+                own[q] = (lane < 2 * B && hown) ? pown[q * B] : 0.0;
+            }
+            bad |= bcr_gj_pair<B>(Ml, Mr, tiny);
+            if (hr && kind >= 1 && kind <= 3) {   // what the way up needs of the right-hand neighbour
+                double* pe = (kind == 1 ? EL : kind == 2 ? EU : z) + (size_t)jr * bsz + ocol;
+#pragma unroll
+                for (int q = 0; q < B; q++) pe[q * sd] = Mr[q];
+            }
+            // the columns the rows of block i take in: D_i <- D_i - L_i (D^-1 U)_jl - U_i (D^-1 L)_jr, L_i <- -L_i (D^-1 L)_jl,
+            // U_i <- -U_i (D^-1 U)_jr, r_i <- r_i - L_i (D^-1 r)_jl - U_i (D^-1 r)_jr
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+                const double ul = __shfl(Ml[q], 2 * B + cc), lr = __shfl(Mr[q], B + cc);
+                Ml[q] = !hl ? 0.0 : kind == 0 ? ul : (kind == 1 || kind == 3) ? Ml[q] : 0.0;
+                Mr[q] = !hr ? 0.0 : kind == 0 ? lr : (kind == 2 || kind == 3) ? Mr[q] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                double a = out[r];
+#pragma unroll
+                for (int q = 0; q < B; q++) a = fma(-readlane_f64(own[r], q), Ml[q], fma(-readlane_f64(own[r], B + q), Mr[q], a));
+                out[r] = a;
+            }
+            if (kind < 4) {
+                double* pw = (kind == 0 ? D : kind == 1 ? L : kind == 2 ? U : rv) + (size_t)i * bsz + ocol;
+#pragma unroll
+                for (int r = 0; r < B; r++) pw[r * sd] = out[r];
+            }
+        }
+        smax = st;
+        if (!grid_barrier(bar, gl, shu)) return;
+    }
+    if (gw == 0) {   // the one block left: x_0 = D_0^-1 r_0
+        const double* sD = nbk == 1 ? D0 : D;
+        double Ml[B], Mr[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            Ml[q] = kind == 0 ? sD[q * B + cc] : kind == 3 ? rv[q] : 0.0;
+            Mr[q] = (kind == 0 && q == cc) ? am : 0.0;
+        }
+        bad |= bcr_gj_pair<B>(Ml, Mr, tiny);
+        if (kind == 3) {
+#pragma unroll
+            for (int q = 0; q < B; q++) rv[q] = Ml[q];
+        }
+    }
+    if (bad && lane == 0) atomicAdd(flag, 1);
+    for (int st = smax; st >= 1; st /= 2) {
+        if (!grid_barrier(bar, gl, shu)) return;
+        const int count = (nbk - st + 2 * st - 1) / (2 * st);
+        for (int t = gw; t < count; t += nw) {
+            const long long j = (long long)st + (long long)t * 2 * st, jl = j - st, jr = j + st;
+            const double xl = (lane < B) ? rv[(size_t)jl * B + lane] : 0.0, xr = (lane < B && jr < nbk) ? rv[(size_t)jr * B + lane] : 0.0;
+            const int r = lane < B ? lane : 0;
+            double a = z[(size_t)j * B + r];
+#pragma unroll
+            for (int q = 0; q < B; q++)
+                a = fma(-EL[(size_t)j * BB + r * B + q], readlane_f64(xl, q), fma(-EU[(size_t)j * BB + r * B + q], readlane_f64(xr, q), a));
+            if (lane < B) rv[(size_t)j * B + lane] = a;
+        }
+    }
+}
+// what a solve by the resident reduction needs in front of it, in one launch: the right-hand side in the band's numbering (twice: the
+// reduction overwrites one, the backward-error test reads the other), zeros in the rows past the matrix, the barrier's words and the
+// status words behind them cleared
+__global__ void __launch_bounds__(256) k_bcr_prep(size_t n, size_t npad, const int* __restrict__ perm, const double* __restrict__ b,
+                                                  double* __restrict__ rv, double* __restrict__ keep, unsigned* __restrict__ words, int nwords)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const double v = b[i]; const int p = perm[i]; rv[p] = v; keep[p] = v; }
+    else if (i < npad) rv[i] = 0.0;
+    if (i < (size_t)nwords) words[i] = 0u;
+}
 // componentwise backward error of x for the band matrix (renumbered system): max_i |b - A x|_i / (|A| |x| + |b|)_i
 __global__ void __launch_bounds__(256) k_band_backward_error(long long n, int kl, int wb, const double* __restrict__ ab,
                                                              const double* __restrict__ x, const double* __restrict__ b,
@@ -1223,9 +1384,22 @@ void BandLU::setup(fem_mat A_)
         case 17: hipLaunchKernelGGL(k_bcr_blocks<17>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
         default: hipLaunchKernelGGL(k_bcr_blocks<21>, dim3(gb), dim3(256), 0, s, n, nbk, ab.p, v0.p + n, cL0.p, cD0.p, cU0.p); break;
         }
-        bcr = bcr_reduce(false);
+        // One resident launch per solve (k_bcr_resident; FEM_AMD_LU_BCR_RESIDENT=0: the launch per level).  It reduces matrix and
+        // right-hand side together, so set-up does not run the reduction for the pivots' sake any more: the first solve meets a small
+        // pivot as well as this would have, and goes to the band LU the same way (a Newton loop sets up and solves once per Jacobian:
+        // half the reductions).
+        const char* re = std::getenv("FEM_AMD_LU_BCR_RESIDENT");
+        bcr_resident = !(re && std::atoi(re) == 0);
+        if (bcr_resident) {
+            for (DBuf<double>* a : {&cEL, &cEU}) if (a->n != nb2) a->alloc(nb2);
+            if (cz.n != (size_t)nbk * kl) cz.alloc((size_t)nbk * kl);
+            if (bcr_words.n != (size_t)GridBarrier::WORDS + 32) bcr_words.alloc((size_t)GridBarrier::WORDS + 32);
+            bcr = true;
+        } else
+            bcr = bcr_reduce(false);
         if (std::getenv("FEM_AMD_DIRECT_VERBOSE"))
-            fprintf(stderr, "[fem_amd lu] block cyclic reduction: %d blocks of %d rows: %s\n", nbk, kl, bcr ? "used" : "a small pivot on the way: band LU");
+            fprintf(stderr, "[fem_amd lu] block cyclic reduction: %d blocks of %d rows: %s\n", nbk, kl,
+                    bcr_resident ? "used (one resident launch per solve, which also looks at the pivots)" : bcr ? "used" : "a small pivot on the way: band LU");
         if (bcr) { null_pivots = 0; failed = false; return; }
         flag.zero(s);
     }
@@ -1328,6 +1502,47 @@ void BandLU::solve(const double* b, double* x)
         return;
     }
     const unsigned g = cdiv((size_t)n, 256);
+    if (bcr && bcr_resident) {
+        // prep, reduction, backward error, one read-back of (barrier gave up, small pivots, error)
+        const int nwords = GridBarrier::WORDS + 32;
+        unsigned* status = bcr_words.p + GridBarrier::WORDS;            // [0] barrier  [1] pivots  [2..3] the error's bits
+        const size_t npad = (size_t)nbk * kl;
+        hipLaunchKernelGGL(k_bcr_prep, dim3(cdiv(std::max(npad, (size_t)nwords), 256)), dim3(256), 0, s, (size_t)n, npad, perm_dof.p, b,
+                           cr.p, v0.p, bcr_words.p, nwords);
+        GridBarrier bar{bcr_words.p, reinterpret_cast<int*>(status)};
+        int* pflag = reinterpret_cast<int*>(status + 1);
+        const unsigned nwg = (unsigned)std::min<long long>(((nbk + 1) / 2 + 3) / 4, std::max(ctx->num_cu, 1));
+        const double* am = v0.p + n;
+        switch (kl) {
+        case 5: hipLaunchKernelGGL(k_bcr_resident<5>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
+        case 9: hipLaunchKernelGGL(k_bcr_resident<9>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
+        case 13: hipLaunchKernelGGL(k_bcr_resident<13>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
+        case 17: hipLaunchKernelGGL(k_bcr_resident<17>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
+        default: hipLaunchKernelGGL(k_bcr_resident<21>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
+        }
+        hipLaunchKernelGGL(k_band_backward_error, dim3(g), dim3(256), 0, s, n, kl, wb, ab.p, cr.p, v0.p,
+                           reinterpret_cast<unsigned long long*>(status + 2));
+        FEM_HIP(hipGetLastError());
+        unsigned h[4] = {0, 0, 0, 0};
+        FEM_HIP(hipMemcpyAsync(h, status, sizeof(h), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+        double err;
+        std::memcpy(&err, h + 2, sizeof(double));
+        const char* te = std::getenv("FEM_AMD_LU_BCR_TOL");
+        const bool ok = h[0] == 0 && h[1] == 0 && err <= (te ? std::atof(te) : 1e-10);
+        if (ok) {
+            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, cr.p, x);
+            FEM_HIP(hipGetLastError());
+            return;
+        }
+        if (std::getenv("FEM_AMD_DIRECT_VERBOSE")) {
+            if (h[0]) fprintf(stderr, "[fem_amd lu] block cyclic reduction: the grid barrier of the resident launch gave up: a launch per level from here on\n");
+            else if (h[1]) fprintf(stderr, "[fem_amd lu] block cyclic reduction: a small pivot on the way: band LU from here on\n");
+            else fprintf(stderr, "[fem_amd lu] block cyclic reduction: backward error %.2e: band LU from here on\n", err);
+        }
+        if (h[0]) bcr_resident = false;      // (the reduction itself is sound: its launches, below)
+        else { bcr = false; if (!band_ready) factor_band(); }
+    }
     if (bcr) {
         cr.zero(s);                                                     // (the rows past the matrix in the last block)
         hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, cr.p);

@@ -239,10 +239,15 @@ def test_band_lu_by_one_wavefront_equals_the_column_walk(gpu_ctx, monkeypatch, c
     assert np.abs(xs["1"] - xs["0"]).max() <= 1e-9 * np.abs(xs["0"]).max()
 
 
+# (FEM_AMD_LU_BCR_RESIDENT: "1" = the reduction as one resident launch per solve, the default; "0" = a launch per level, with the trial
+# reduction at set-up -- what the resident launch falls back to when its grid barrier gives up)
+@pytest.mark.parametrize("resident", ["1", "0"])
 @pytest.mark.parametrize("name,mesh", [("quad_400x1", lambda: structured_quad(400, 1, jitter=0.1)),      # half bandwidth 7 (blocks of 9 rows)
                                        ("quad_300x2", lambda: structured_quad(300, 2, jitter=0.1)),      # 11 (13)
-                                       ("quad_320x3", lambda: structured_quad(320, 3, jitter=0.1))])     # 15 (17)
-def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, capfd, name, mesh):
+                                       ("quad_320x3", lambda: structured_quad(320, 3, jitter=0.1)),      # 15 (17)
+                                       ("quad_330x4", lambda: structured_quad(330, 4, jitter=0.1)),      # 19 (21)
+                                       ("quad_70x2", lambda: structured_quad(70, 2, jitter=0.1))])       # 11 (13), 33 blocks: odd counts on the way down
+def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, capfd, name, mesh, resident):
     """Narrow bands with many columns go through block cyclic reduction (k_bcr_*): Mat_K with its penalties plus a small unsymmetric
     perturbation (what a cohesive tangent does to the Newton Jacobian) -- the set-up's trial reduction meets no small pivot, the
     solve passes its backward-error test, and the answer agrees with scipy's sparse LU and with the band LU (FEM_AMD_LU_BCR=0)."""
@@ -250,6 +255,7 @@ def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, c
     import scipy.sparse.linalg as sla
     m = mesh()
     monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", resident)
     xs = {}
     for bcr in ("1", "0"):
         monkeypatch.setenv("FEM_AMD_LU_BCR", bcr)
@@ -288,7 +294,8 @@ def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, c
     assert np.abs(xs["1"] - xs["0"]).max() <= 1e-5 * np.abs(xs["0"]).max()
 
 
-def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkeypatch, capfd):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkeypatch, capfd, resident):
     """A free-floating strip (no Dirichlet condition: three rigid-body modes) with a self-equilibrated load: the factorisation
     meets pivots below 1e-6 of the largest entry and fixes those unknowns to zero (what MUMPS does under ICNTL(24) = 1,
     src/main.F90:368).  The band LU by one wavefront, the column walk of one workgroup and the way through block cyclic
@@ -303,6 +310,7 @@ def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkey
     m.fnode = np.array([left, right], dtype=np.int32)
     m.fval = np.array([[-1e6, 0.0, 0.0, m.t], [1e6, 0.0, 0.0, m.t]])
     monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", resident)
     xs = {}
     for name, env in (("wave", {"FEM_AMD_LU_WAVE": "1", "FEM_AMD_LU_BCR": "0"}), ("walk", {"FEM_AMD_LU_WAVE": "0", "FEM_AMD_LU_BCR": "0"}),
                       ("bcr", {"FEM_AMD_LU_WAVE": "1", "FEM_AMD_LU_BCR": "1"})):
@@ -334,12 +342,14 @@ def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkey
     assert np.abs(xs["bcr"] - xs["walk"]).max() <= 1e-6 * scale
 
 
-def test_a_solve_that_fails_the_backward_error_test_goes_to_the_band_lu(gpu_ctx, monkeypatch, capfd):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_a_solve_that_fails_the_backward_error_test_goes_to_the_band_lu(gpu_ctx, monkeypatch, capfd, resident):
     """The safety net of block cyclic reduction: a solve whose componentwise backward error exceeds the bound is repeated by the band
     LU (factorised then), and so is every later solve with that matrix.  The bound is set to 0 here (FEM_AMD_LU_BCR_TOL), so that
     the first solve takes that way: same answer as with the band LU from the start, and a second right-hand side is solved too."""
     m = structured_quad(300, 2, jitter=0.1)
     monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
+    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", resident)
     xs = {}
     for name, env in (("fallback", {"FEM_AMD_LU_BCR": "1", "FEM_AMD_LU_BCR_TOL": "0"}), ("band", {"FEM_AMD_LU_BCR": "0", "FEM_AMD_LU_BCR_TOL": "1e-10"})):
         for k, v in env.items():

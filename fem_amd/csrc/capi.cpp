@@ -804,8 +804,7 @@ int fem_mat_mult_add(fem_mat A, fem_vec x, fem_vec y, fem_vec z)
     mat_mult_raw(A, x->d.p, t.p, nullptr, nullptr);
     halo_sum(A->mesh, t.p, A->bs, A->bs, 1);
     fem_vec_s tv; tv.ctx = A->ctx; tv.n = n; tv.d = std::move(t);
-    vec_waxpy(z, 1.0, &tv, y);
-    FEM_HIP(hipStreamSynchronize(A->ctx->stream));
+    vec_waxpy(z, 1.0, &tv, y);   // (no wait for it: the pool orders the temporary's next use behind this stream, pool.cpp)
     FEM_CATCH
 }
 

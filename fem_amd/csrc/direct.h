@@ -63,7 +63,7 @@ struct BandLU {
     void factor_band();
     bool bcr_reduce(bool with_rhs);   // the levels down (and, with a right-hand side, up); false: a small pivot was met
     int null_pivots = 0;        // pivots below 1e-6 of the largest entry, fixed to zero
-    DBuf<int> perm_dof;         // [n] new position of every dof
+    const int* perm_dof = nullptr;   // [n] new position of every dof (kept on the sparsity's LuSymbolic)
     DBuf<double> ab;            // [n*wb] row i holds columns i-kl .. i+2kl
     DBuf<int> ipiv;             // [n]
     DBuf<double> v0;            // work vector

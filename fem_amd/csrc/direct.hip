@@ -1297,7 +1297,7 @@ void BandLU::setup(fem_mat A_)
         }
         A->pat->lu_sym = sym;
     }
-    const LuSymbolic& sym = *A->pat->lu_sym;
+    LuSymbolic& sym = *A->pat->lu_sym;
     batched = sym.batched;
     if (batched) {
         const int nc = sym.nc;
@@ -1351,10 +1351,14 @@ void BandLU::setup(fem_mat A_)
     }
     FEM_CHECK(need < 0.8 * (double)free_b, 9, "pc lu: the band of the unsymmetric factor needs " +
                                                   std::to_string((long long)(need / 1048576.0)) + " MiB: use -ksp_type bcgs");
-    DBuf<int> dperm((size_t)nn);
-    dperm.upload(perm.data(), perm.size(), s);
-    perm_dof.alloc((size_t)n);
-    hipLaunchKernelGGL(k_perm_dof, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, bs, dperm.p, perm_dof.p);
+    if (sym.d_perm_dof.n != (size_t)n) {   // (once per sparsity: the numbering does not change from one Jacobian to the next)
+        sym.d_perm.alloc((size_t)nn);
+        sym.d_perm.upload(perm.data(), perm.size(), s);
+        sym.d_perm_dof.alloc((size_t)n);
+        hipLaunchKernelGGL(k_perm_dof, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, bs, sym.d_perm.p, sym.d_perm_dof.p);
+    }
+    const DBuf<int>& dperm = sym.d_perm;
+    perm_dof = sym.d_perm_dof.p;
     ab.alloc((size_t)n * wb);
     ab.zero(s);
     if (bs == 3)
@@ -1507,7 +1511,7 @@ void BandLU::solve(const double* b, double* x)
         const int nwords = GridBarrier::WORDS + 32;
         unsigned* status = bcr_words.p + GridBarrier::WORDS;            // [0] barrier  [1] pivots  [2..3] the error's bits
         const size_t npad = (size_t)nbk * kl;
-        hipLaunchKernelGGL(k_bcr_prep, dim3(cdiv(std::max(npad, (size_t)nwords), 256)), dim3(256), 0, s, (size_t)n, npad, perm_dof.p, b,
+        hipLaunchKernelGGL(k_bcr_prep, dim3(cdiv(std::max(npad, (size_t)nwords), 256)), dim3(256), 0, s, (size_t)n, npad, perm_dof, b,
                            cr.p, v0.p, bcr_words.p, nwords);
         GridBarrier bar{bcr_words.p, reinterpret_cast<int*>(status)};
         int* pflag = reinterpret_cast<int*>(status + 1);
@@ -1531,7 +1535,7 @@ void BandLU::solve(const double* b, double* x)
         const char* te = std::getenv("FEM_AMD_LU_BCR_TOL");
         const bool ok = h[0] == 0 && h[1] == 0 && err <= (te ? std::atof(te) : 1e-10);
         if (ok) {
-            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, cr.p, x);
+            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, cr.p, x);
             FEM_HIP(hipGetLastError());
             return;
         }
@@ -1545,8 +1549,8 @@ void BandLU::solve(const double* b, double* x)
     }
     if (bcr) {
         cr.zero(s);                                                     // (the rows past the matrix in the last block)
-        hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, cr.p);
-        hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);   // (b in the band's numbering, for the test)
+        hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, b, cr.p);
+        hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, b, v0.p);   // (b in the band's numbering, for the test)
         bool ok = bcr_reduce(true);
         if (ok) {
             unsigned long long* eb = reinterpret_cast<unsigned long long*>(v0.p + n + 1);
@@ -1562,18 +1566,18 @@ void BandLU::solve(const double* b, double* x)
                 fprintf(stderr, "[fem_amd lu] block cyclic reduction: backward error %.2e: band LU from here on\n", err);
         }
         if (ok) {
-            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, cr.p, x);
+            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, cr.p, x);
             FEM_HIP(hipGetLastError());
             return;
         }
         bcr = false;
         if (!band_ready) factor_band();
     }
-    hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, b, v0.p);
+    hipLaunchKernelGGL(k_permute_in, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, b, v0.p);
     if (wave) hipLaunchKernelGGL(k_band_solve_wave, dim3(1), dim3(64), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
     else
         hipLaunchKernelGGL(k_band_lu_solve, dim3(1), dim3(256), 0, s, n, kl, wb, ab.p, ipiv.p, v0.p);
-    hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof.p, v0.p, x);
+    hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, v0.p, x);
     FEM_HIP(hipGetLastError());
 }
 

@@ -16,6 +16,7 @@
 // a straight copy.
 // The kernels of the batch API work element-wise: phase 1 thread = (element, Gauss point) parks
 // {dN/dx, w*detJ} in LDS, phase 2 thread = (element, node a) forms block row a of the element matrix.
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -1526,9 +1527,11 @@ void enforce_bc_force_impl(fem_mesh m, int nbcs, const int* bcnode, const double
     ctx->bind();
     hipStream_t s = ctx->stream;
     const int pd = m->pdim;
-    DBuf<int> d_bc;
-    DBuf<double> d_bcval;
-    {
+    auto& c = m->bc_force;
+    const size_t nb = (size_t)nbcs * (1 + pd), nv = (size_t)nbcs * pd;
+    const bool same = c.nm > 0 && c.bcnode.size() == nb && c.bcval.size() == nv && std::memcmp(c.bcnode.data(), bcnode, nb * sizeof(int)) == 0 &&
+                      std::memcmp(c.bcval.data(), bcval, nv * sizeof(double)) == 0;
+    if (!same) {
         // the reference INSERTs record after record (src/m_global.F90:439-455): where several records
         // constrain the same dof the last one's value stands -- merged here, one record per node
         std::vector<int> pos((size_t)m->nnds, -1), mb;
@@ -1545,12 +1548,14 @@ void enforce_bc_force_impl(fem_mesh m, int nbcs, const int* bcnode, const double
             for (int d = 0; d < pd; d++)
                 if (rec[1 + d] == 0) { mb[(size_t)p * (1 + pd) + 1 + d] = 0; mv[(size_t)p * pd + d] = bcval[(size_t)i * pd + d]; }
         }
-        const int nm = (int)(mb.size() / (1 + pd));
-        d_bc.alloc(mb.size()); d_bc.upload(mb.data(), mb.size(), s);
-        d_bcval.alloc(mv.size()); d_bcval.upload(mv.data(), mv.size(), s);
-        hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(nm, 256)), dim3(256), 0, s, nm, pd, d_bc.p, d_bcval.p, dt, t_total, F);
+        c.nm = 0;
+        c.d_bc.alloc(mb.size()); c.d_bc.upload(mb.data(), mb.size(), s);
+        c.d_bcval.alloc(mv.size()); c.d_bcval.upload(mv.data(), mv.size(), s);
         FEM_HIP(hipStreamSynchronize(s));   // the merged host lists die at scope end
+        c.bcnode.assign(bcnode, bcnode + nb); c.bcval.assign(bcval, bcval + nv);
+        c.nm = (int)(mb.size() / (1 + pd));
     }
+    hipLaunchKernelGGL(k_rhs_bc, dim3(cdiv(c.nm, 256)), dim3(256), 0, s, c.nm, pd, c.d_bc.p, c.d_bcval.p, dt, t_total, F);
     FEM_HIP(hipGetLastError());
 }
 

@@ -649,8 +649,7 @@ static void ksp_solve_once(fem_ksp k, fem_vec b, fem_vec x)
     ctx->bind();
     hipStream_t s = ctx->stream;
     if (k->direct_lu) {
-        k->direct_lu->solve(b->d.p, x->d.p);
-        FEM_HIP(hipStreamSynchronize(s));
+        k->direct_lu->solve(b->d.p, x->d.p);   // (stream-ordered: whoever reads x does so on this stream or behind a synchronising download)
         k->its = 1; k->rnorm = 0.0; k->reason = k->direct_lu->failed ? -11 : 4;
         k->n_spmv = 0; k->spmv_ms = 0.0; k->solve_ms = 0.0;
         return;

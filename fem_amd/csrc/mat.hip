@@ -519,8 +519,14 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
         FEM_HIP(hipStreamSynchronize(s));
         A->bc_saved = false;
     }
-    DBuf<int> d_bc(merged.size());
-    d_bc.upload(merged.data(), merged.size(), s);
+    bool uploaded = false;
+    if (merged != A->h_bc_dev) {
+        A->h_bc_dev.clear();
+        A->d_bc_dev.alloc(merged.size());
+        A->d_bc_dev.upload(merged.data(), merged.size(), s);
+        uploaded = true;
+    }
+    const DBuf<int>& d_bc = A->d_bc_dev;
     // the element-by-element product needs (inserted value - assembled diagonal) of every penalty row;
     // only the first ApplyKBC after an assembly sees the assembled diagonal
     int* bcd = nullptr;
@@ -539,9 +545,12 @@ void mat_apply_kbc_impl(fem_mat A, int nbcs_in, const int* bcnode_in)
         hipLaunchKernelGGL(k_apply_kbc<2>, dim3(cdiv(nbcs, 256)), dim3(256), 0, s, nbcs, d_bc.p, A->rowlen.p, A->boff.p,
                            A->bcol.p, A->values(), owned, PENALTY_PARAM, bcd, bcs, bcg, A->bc_node.p);
     A->bc_saved = true;
-    A->h_bc = std::move(merged);
     FEM_HIP(hipGetLastError());
-    FEM_HIP(hipStreamSynchronize(s));
+    if (uploaded) {
+        FEM_HIP(hipStreamSynchronize(s));   // (the upload reads `merged`)
+        A->h_bc_dev = merged;
+    }
+    A->h_bc = std::move(merged);
 }
 
 // MatSetValues (src/m_global.F90:257-260 ADD_VALUES from FormLocalK, :296 INSERT_VALUES of the penalty): a logically dense

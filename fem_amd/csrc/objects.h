@@ -58,6 +58,13 @@ struct fem_mesh_s {
     std::vector<int> h_coh_conn;
     std::vector<int> coh_colour_ptr;   // the cohesive elements are kept colour by colour (no shared node inside a colour): [ncolours + 1]
     std::shared_ptr<fem::MatPattern> pattern;   // symbolic phase result, built by the first fem_mat_create_aij
+    // the merged boundary-condition records of the last fem_enforce_bc_force on the device (a Newton loop passes the same list at
+    // every residual evaluation: merging, two uploads and the wait for them were 50 us of each, round 6)
+    struct BcForceCache {
+        std::vector<int> bcnode; std::vector<double> bcval;   // the host's lists as they were passed
+        fem::DBuf<int> d_bc; fem::DBuf<double> d_bcval;
+        int nm = 0;
+    } bc_force;
 };
 
 struct fem_vec_s {
@@ -81,6 +88,7 @@ struct LuSymbolic {
     std::vector<long long> foff;
     std::vector<int> perm;
     long long bwn = 0;
+    DBuf<int> d_perm, d_perm_dof;             // the numbering on the device (node, dof): uploaded by the first set-up on this sparsity
 };
 
 // Everything about Mat_K that depends on the connectivity alone (the product of MatCreateAIJ's
@@ -168,6 +176,8 @@ struct fem_mat_s {
     fem::DBuf<double> bc_shift;
     fem::DBuf<double> bc_diag;              // assembled diagonal under the rows of bc_dof (undo of a changed list)
     std::vector<int> h_bc;                  // the merged constraint list (one record per node) now applied
+    std::vector<int> h_bc_dev;              // the merged list that d_bc_dev holds (a Newton loop applies the same list to every Jacobian)
+    fem::DBuf<int> d_bc_dev;
     fem::DBuf<int> bc_node;                 // [nbrows] offset of a node's rows in bc_dof/bc_shift, or -1
     int nbc_dof = 0;
     bool bc_saved = false;

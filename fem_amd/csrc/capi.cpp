@@ -14,6 +14,7 @@ using namespace fem;
 
 // implemented in the .hip translation units
 namespace fem { void upload_elem_tables(hipStream_t s); }
+void device_copy_segments(hipStream_t s, int n, void* const* dst, const void* const* src, const size_t* bytes);   // mat.hip
 fem_mesh mesh_create_impl(fem_ctx, int, int, int, const int*, const int*, const int*, const int*, const double*, int,
                           const double*);
 void mesh_set_halo_impl(fem_mesh, fem_comm, int, const int*, const int*, const int*);
@@ -745,21 +746,24 @@ int fem_mat_copy(fem_mat src, fem_mat dst)
     FEM_TRY
     FEM_CHECK(src && dst && src->pat.get() == dst->pat.get(), 8, "fem_mat_copy: the matrices do not share a mesh (pattern)");
     src->ctx->bind();
-    FEM_HIP(hipMemcpyAsync(dst->val.p, src->values(), src->val.bytes(), hipMemcpyDeviceToDevice, src->ctx->stream));
     dst->lazy_zero = false;
     dst->state++;
     dst->unsymmetric = src->unsymmetric;
     // the copy holds the same penalty rows: with the values goes what ApplyKBC recorded about them (the constraint list, the
     // assembled diagonal under it, the shift of the element-by-element product), so that a later ApplyKBC with another list
-    // restores the assembled diagonal and `-mat_mult_type ebe` on the copy keeps its penalty rows
+    // restores the assembled diagonal and `-mat_mult_type ebe` on the copy keeps its penalty rows.  One launch for the five arrays.
     hipStream_t s = src->ctx->stream;
+    void* dp[5]; const void* sp[5]; size_t nb[5];
+    int k = 0;
+    dp[k] = dst->val.p; sp[k] = src->values(); nb[k] = src->val.bytes(); k++;
     auto dup = [&](auto& d, const auto& a) {
         using T = std::remove_reference_t<decltype(*a.p)>;
         if (!a.p || !a.n) { d.release(); return; }
         if (d.n != a.n) d.alloc(a.n);
-        FEM_HIP(hipMemcpyAsync(d.p, a.p, a.n * sizeof(T), hipMemcpyDeviceToDevice, s));
+        dp[k] = d.p; sp[k] = a.p; nb[k] = a.n * sizeof(T); k++;
     };
     dup(dst->bc_dof, src->bc_dof); dup(dst->bc_shift, src->bc_shift); dup(dst->bc_diag, src->bc_diag); dup(dst->bc_node, src->bc_node);
+    device_copy_segments(s, k, dp, sp, nb);
     dst->h_bc = src->h_bc;
     dst->nbc_dof = src->nbc_dof;
     dst->bc_saved = src->bc_saved;
@@ -850,6 +854,26 @@ int fem_snes_set_jacobian(fem_snes sn, fem_mat J, fem_mat P, fem_snes_jacobian_c
     snes_set_jacobian(sn, J, P, j, c);
     FEM_CATCH
 }
+static int fem_vec_waxpy(fem_vec w, double a, fem_vec x, fem_vec y)   // w = y + a x
+{
+    FEM_TRY
+    FEM_CHECK(w && x && y && w->n == x->n && w->n == y->n, 8, "waxpy: vector size mismatch");
+    vec_waxpy(w, a, x, y);
+    FEM_CATCH
+}
+static int fem_mat_mult_sub(fem_mat A, fem_vec x, fem_vec r)           // r = A x - r
+{
+    FEM_TRY
+    const long long n = (long long)A->nbrows * A->bs;
+    FEM_CHECK(x->n == n && r->n == n && x != r, 8, "mult_sub: vector size mismatch");
+    A->ctx->bind();
+    fem::DBuf<double> t((size_t)n);
+    mat_mult_raw(A, x->d.p, t.p, nullptr, nullptr);
+    halo_sum(A->mesh, t.p, A->bs, A->bs, 1);
+    fem_vec_s tv; tv.ctx = A->ctx; tv.n = n; tv.d = std::move(t);
+    vec_waxpy(r, -1.0, r, &tv);
+    FEM_CATCH
+}
 // The reference's two SNES callbacks as the library's own (src/m_global.F90:98-158 CalcJacobian, :161-235 CalcResidual): the same
 // sequence of primitives a host writes by hand (fem_amd/driver.py keeps that hand-written form as well), issued
 // from here -- for a host that does not want a round trip through its own language between two device calls (a Python host pays
@@ -859,13 +883,14 @@ struct fem_defmod_callbacks_s {
     std::vector<int> bcnode; std::vector<double> bcval;
     int nbcs; double dt, t; int rels_mode; int rels_nodes[4]; bool have_nodes;
 };
+// (vector steps fused where one kernel gives the same roundings as the two calls it stands for: w = y + a x is what a copy followed
+// by an axpy computes, t - R what a scaling by -1 followed by t + R does)
 static int defmod_calc_jacobian(fem_snes, fem_vec du, fem_mat J, fem_mat, void* c)
 {
     auto* d = static_cast<fem_defmod_callbacks_s*>(c);
     int rc;
     if ((rc = fem_mat_copy(d->K, J))) return rc;                                                     /* MatCopy(Mat_K, Jacobian) :123 */
-    if ((rc = fem_vec_copy(du, d->utot))) return rc;
-    if ((rc = fem_vec_axpy(d->utot, 1.0, d->agg))) return rc;                                        /* uu = uu + aggregate_u :127 */
+    if ((rc = fem_vec_waxpy(d->utot, 1.0, d->agg, du))) return rc;                                   /* uu = uu + aggregate_u :127 */
     if ((rc = fem_mat_add_cohesive(J, d->utot, d->dt, d->rels_mode, d->have_nodes ? d->rels_nodes : nullptr))) return rc;   /* :129-147 */
     return fem_mat_apply_kbc(J, d->nbcs, d->bcnode.data());                                          /* ApplyKBC(Jacobian) :153 */
 }
@@ -873,13 +898,11 @@ static int defmod_calc_residual(fem_snes, fem_vec du, fem_vec R, void* c)
 {
     auto* d = static_cast<fem_defmod_callbacks_s*>(c);
     int rc;
-    if ((rc = fem_vec_copy(du, d->utot))) return rc;
-    if ((rc = fem_vec_axpy(d->utot, 1.0, d->agg))) return rc;                                        /* current_u = current_u + aggregate_u :182 */
+    if ((rc = fem_vec_waxpy(d->utot, 1.0, d->agg, du))) return rc;                                   /* current_u = current_u + aggregate_u :182 */
     if ((rc = fem_vec_copy(d->F, R))) return rc;                                                     /* VecCopy(Vec_F, Residual) :184 */
     if ((rc = fem_vec_add_cohesive_traction(d->mesh, d->utot, d->dt, d->rels_mode, d->have_nodes ? d->rels_nodes : nullptr, R))) return rc;   /* :186-205 */
     if ((rc = fem_enforce_bc_force(d->mesh, d->nbcs, d->bcnode.data(), d->bcval.data(), d->dt, d->t, R))) return rc;   /* :210 */
-    if ((rc = fem_vec_scale(R, -1.0))) return rc;                                                    /* VecScale(Residual, MINUS) :223 */
-    return fem_mat_mult_add(d->J, du, R, R);                                                         /* MatMultAdd(Jacobian, du, Residual, Residual) :224 */
+    return fem_mat_mult_sub(d->J, du, R);                    /* VecScale(Residual, MINUS) :223 + MatMultAdd(Jacobian, du, Residual, Residual) :224 */
 }
 int fem_snes_set_defmod_callbacks(fem_snes sn, fem_mesh mesh, fem_mat K, fem_mat J, fem_vec R, fem_vec F, fem_vec aggregate_u, fem_vec work,
                                   int nbcs, const int* bcnode, const double* bcval, double dt, double t_total, int rels_mode,

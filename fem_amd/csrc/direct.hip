@@ -503,9 +503,11 @@ void BandCholesky::setup(fem_mat A_)
 template <int BS>
 __global__ void __launch_bounds__(256) k_bandfull_fill(int nn, const int* __restrict__ boff, const int* __restrict__ bcol,
                                                        const double* __restrict__ val, const int* __restrict__ rowlen,
-                                                       const int* __restrict__ perm, int kl, int wb, double* __restrict__ ab)
+                                                       const int* __restrict__ perm, int kl, int wb, double* __restrict__ ab,
+                                                       int* __restrict__ flag2, double* __restrict__ amax)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { flag2[0] = 0; flag2[1] = 0; *amax = 0.0; }   // (what the kernels behind this one count into: two fills less per set-up)
     if (i >= nn) return;
     const int ln = i & 63, len = rowlen[i], o0 = boff[i >> 6];
     const long long pi = perm[i];
@@ -944,38 +946,47 @@ __global__ void __launch_bounds__(64) k_bcr_back(int count, int j0, int jstep, i
 // eliminations run side by side in the same instruction stream, so the second one costs issue slots, not latency) and takes them
 // into its own rows at once; the elimination of the right-hand neighbour is what it stores for the way up.  Level 0 reads the
 // pristine blocks, so no work copies are made.  2 log2(nb) + 1 barriers per solve.
+// (partial pivoting inside the block as k_bcr_eliminate does it -- the largest entry of column k among rows k .. B-1, the first one on
+// a tie -- but the search for its row runs only where the diagonal entry is not already that largest one: a maximum over the column
+// (B - k instructions) and one uniform branch per step instead of three selects per row)
+template <int B, int K>
+__device__ __forceinline__ void bcr_swap_in_pivot(double (&M)[B])
+{
+    int pl = K;
+    double bl = fabs(M[K]);
+#pragma unroll
+    for (int r = K + 1; r < B; r++) { const double a = fabs(M[r]); if (a > bl) { bl = a; pl = r; } }
+    const int p = __builtin_amdgcn_readlane(pl, K);
+#pragma unroll
+    for (int r = K + 1; r < B; r++)
+        if (p == r) { const double t = M[K]; M[K] = M[r]; M[r] = t; }
+}
+template <int B, int K>
+__device__ __forceinline__ bool bcr_gj_step(double (&Ml)[B], double (&Mr)[B], double tiny)
+{
+    double ml = 0.0, mr = 0.0;
+#pragma unroll
+    for (int r = K + 1; r < B; r++) { ml = fmax(ml, fabs(Ml[r])); mr = fmax(mr, fabs(Mr[r])); }
+    if (readlane_f64(ml, K) > readlane_f64(fabs(Ml[K]), K)) bcr_swap_in_pivot<B, K>(Ml);   // (uniform; rare for the matrices this is used on)
+    if (readlane_f64(mr, K) > readlane_f64(fabs(Mr[K]), K)) bcr_swap_in_pivot<B, K>(Mr);
+    const double pvl = readlane_f64(Ml[K], K), pvr = readlane_f64(Mr[K], K);
+    const bool bad = !(fabs(pvl) > tiny) || !(fabs(pvr) > tiny);
+    const double rl = 1.0 / pvl, rr = 1.0 / pvr;
+    Ml[K] *= rl; Mr[K] *= rr;
+#pragma unroll
+    for (int r = 0; r < B; r++)
+        if (r != K) {
+            const double fl = readlane_f64(Ml[r], K), fr = readlane_f64(Mr[r], K);
+            Ml[r] = fma(-fl, Ml[K], Ml[r]);
+            Mr[r] = fma(-fr, Mr[K], Mr[r]);
+        }
+    if constexpr (K + 1 < B) return bcr_gj_step<B, K + 1>(Ml, Mr, tiny) || bad;
+    else return bad;
+}
 template <int B>
 __device__ __forceinline__ bool bcr_gj_pair(double (&Ml)[B], double (&Mr)[B], double tiny)
 {
-    bool bad = false;
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-        int pl = k, pr = k;
-        double bl = fabs(Ml[k]), br = fabs(Mr[k]);
-#pragma unroll
-        for (int r = k + 1; r < B; r++) {
-            const double a = fabs(Ml[r]), c = fabs(Mr[r]);
-            if (a > bl) { bl = a; pl = r; }
-            if (c > br) { br = c; pr = r; }
-        }
-        const int p = __builtin_amdgcn_readlane(pl, k), q = __builtin_amdgcn_readlane(pr, k);
-        if (!(readlane_f64(bl, k) > tiny) || !(readlane_f64(br, k) > tiny)) bad = true;   // (uniform)
-#pragma unroll
-        for (int r = k + 1; r < B; r++) {
-            if (p == r) { const double t = Ml[k]; Ml[k] = Ml[r]; Ml[r] = t; }
-            if (q == r) { const double t = Mr[k]; Mr[k] = Mr[r]; Mr[r] = t; }
-        }
-        const double rl = 1.0 / readlane_f64(Ml[k], k), rr = 1.0 / readlane_f64(Mr[k], k);
-        Ml[k] *= rl; Mr[k] *= rr;
-#pragma unroll
-        for (int r = 0; r < B; r++)
-            if (r != k) {
-                const double fl = readlane_f64(Ml[r], k), fr = readlane_f64(Mr[r], k);
-                Ml[r] = fma(-fl, Ml[k], Ml[r]);
-                Mr[r] = fma(-fr, Mr[k], Mr[r]);
-            }
-    }
-    return bad;
+    return bcr_gj_step<B, 0>(Ml, Mr, tiny);
 }
 // L, D, U: work copies (written and read again inside the launch: no __restrict__, no const -- nothing of them may go through the
 // scalar cache); EL, EU, z: D^-1 [L U r] of every eliminated block; rv: right-hand side by blocks in, solution out
@@ -1361,16 +1372,14 @@ void BandLU::setup(fem_mat A_)
     perm_dof = sym.d_perm_dof.p;
     ab.alloc((size_t)n * wb);
     ab.zero(s);
+    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 2); flag.alloc(2);
     if (bs == 3)
         hipLaunchKernelGGL(k_bandfull_fill<3>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
-                           A->rowlen.p, dperm.p, kl, wb, ab.p);
+                           A->rowlen.p, dperm.p, kl, wb, ab.p, flag.p, v0.p + n);
     else
         hipLaunchKernelGGL(k_bandfull_fill<2>, dim3(cdiv(nn, 256)), dim3(256), 0, s, nn, A->boff.p, A->bcol.p, A->values(),
-                           A->rowlen.p, dperm.p, kl, wb, ab.p);
-    ipiv.alloc((size_t)n); v0.alloc((size_t)n + 2); flag.alloc(2);
-    flag.zero(s);
+                           A->rowlen.p, dperm.p, kl, wb, ab.p, flag.p, v0.p + n);
     // (the largest non-penalty entry: non-negative doubles order like their bits -- many workgroups and one atomic max each)
-    FEM_HIP(hipMemsetAsync(v0.p + n, 0, sizeof(double), s));
     hipLaunchKernelGGL(k_val_amax, dim3(64), dim3(256), 0, s, (size_t)n * wb, ab.p, reinterpret_cast<unsigned long long*>(v0.p + n));
     band_ready = false; bcr = false;
     const char* be = std::getenv("FEM_AMD_LU_BCR");

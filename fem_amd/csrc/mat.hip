@@ -447,6 +447,36 @@ fem_mat mat_create_impl(fem_mesh mesh)
     return A.release();
 }
 
+// up to MAXSEG device-to-device copies in one launch (MatCopy: the values and the four penalty-row arrays -- five launches of a
+// few microseconds each in front of every Jacobian of a Newton loop); sizes in 4-byte words
+struct CopySegs { static constexpr int MAXSEG = 6; unsigned* dst[MAXSEG]; const unsigned* src[MAXSEG]; size_t end[MAXSEG]; int n; };
+__global__ void __launch_bounds__(256) k_copy_segments(CopySegs c)
+{
+    const size_t st = (size_t)gridDim.x * blockDim.x, total = c.end[c.n - 1];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += st) {
+        int k = 0;
+        while (i >= c.end[k]) k++;
+        const size_t o = i - (k ? c.end[k - 1] : 0);
+        c.dst[k][o] = c.src[k][o];
+    }
+}
+void device_copy_segments(hipStream_t s, int n, void* const* dst, const void* const* src, const size_t* bytes)
+{
+    CopySegs c;
+    c.n = 0;
+    size_t total = 0;
+    for (int i = 0; i < n; i++) {
+        if (!bytes[i]) continue;
+        FEM_CHECK(bytes[i] % 4 == 0 && c.n < CopySegs::MAXSEG, 2, "device_copy_segments: bad segment");
+        total += bytes[i] / 4;
+        c.dst[c.n] = static_cast<unsigned*>(dst[i]); c.src[c.n] = static_cast<const unsigned*>(src[i]); c.end[c.n] = total;
+        c.n++;
+    }
+    if (!c.n) return;
+    hipLaunchKernelGGL(k_copy_segments, dim3((unsigned)std::min<size_t>(cdiv(total, 256), 4096)), dim3(256), 0, s, c);
+    FEM_HIP(hipGetLastError());
+}
+
 void ebe_mult_impl(fem_mat A, const double* x, double* y, double* partial, const int* done);   // elem_kernels.hip
 
 void mat_mult_raw(fem_mat A, const double* x, double* y, double* partial, const int* done)

@@ -49,6 +49,7 @@ struct fem_snes_s {
 // Vec helpers of ksp.hip / capi.cpp
 double vec_dot(fem_vec, fem_vec);
 void vec_axpy(fem_vec, double, fem_vec);
+void vec_waxpy(fem_vec, double, fem_vec, fem_vec);
 void mat_mult_raw(fem_mat, const double*, double*, double*, const int*);
 
 namespace {
@@ -146,8 +147,7 @@ int converged(fem_snes sn, int it, double xnorm, double snorm, double fnorm, dou
 // w = x - lambda y
 void step_to(fem_vec w, fem_vec x, double lambda, fem_vec y)
 {
-    check(fem_vec_copy(x, w));
-    vec_axpy(w, -lambda, y);
+    vec_waxpy(w, -lambda, y, x);   // (one kernel, the roundings of the copy and the axpy it stands for)
 }
 
 // SNESLineSearchApply_BT, cubic.  X, F in/out; Y the direction with J Y = F.  Returns success.

@@ -148,7 +148,10 @@ __global__ void __launch_bounds__(128) k_coh_mesh(int first, int ncoh, const int
                                                   const int* __restrict__ rowlen, const int* __restrict__ boff,
                                                   const int* __restrict__ bcol, double* __restrict__ val)
 {
-    const int e = first + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // STIFF: sixteen threads per element, one per (row node, column node) pair -- the element's numbers are cheap, the look-up of a block's
+    // place in its row is a chain of dependent loads (one thread doing all sixteen: 20 us per launch, round 6)
+    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int e = first + (STIFF ? tid >> 4 : tid);
     if (e >= first + ncoh) return;
     const int* nd = conn + (size_t)e * 4;
     double ec[8], u[8], res[8], K[64];
@@ -162,22 +165,28 @@ __global__ void __launch_bounds__(128) k_coh_mesh(int first, int ncoh, const int
         for (int j = 0; j < 4; j++)
             for (int d = 0; d < 2; d++) R[(size_t)nd[j] * 2 + d] += res[2 * j + d];
     } else {
-        for (int n1 = 0; n1 < 4; n1++) {
-            const int row = nd[n1];
-            const int o0 = boff[row >> 6], lane = row & 63, len = rowlen[row];
-            for (int n2 = 0; n2 < 4; n2++) {
-                const int col = nd[n2];
-                int lo = 0, hi = len;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (bcol[(size_t)(o0 + mid) * 64 + lane] < col) lo = mid + 1; else hi = mid;
+        const int n1 = (tid >> 2) & 3, n2 = tid & 3;
+        double k4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (a == n1 && b == n2) {
+#pragma unroll
+                    for (int d1 = 0; d1 < 2; d1++)
+#pragma unroll
+                        for (int d2 = 0; d2 < 2; d2++) k4[d1 * 2 + d2] = K[(a * 2 + d1) + 8 * (b * 2 + d2)];
                 }
-                double* blk = val + (size_t)(o0 + lo) * 4 * 64 + lane;
-                for (int d1 = 0; d1 < 2; d1++)
-                    for (int d2 = 0; d2 < 2; d2++)
-                        blk[(size_t)(d1 * 2 + d2) * 64] += K[(n1 * 2 + d1) + 8 * (n2 * 2 + d2)];
-            }
+        const int row = nd[n1], col = nd[n2];
+        const int o0 = boff[row >> 6], lane = row & 63, len = rowlen[row];
+        int lo = 0, hi = len;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (bcol[(size_t)(o0 + mid) * 64 + lane] < col) lo = mid + 1; else hi = mid;
         }
+        double* blk = val + (size_t)(o0 + lo) * 4 * 64 + lane;
+#pragma unroll
+        for (int q = 0; q < 4; q++) blk[(size_t)q * 64] += k4[q];
     }
 }
 
@@ -285,7 +294,7 @@ void mat_add_cohesive_impl(fem_mat J, const double* utot, double dt, int rels_mo
     double* jval = J->values();
     for (size_t c = 0; c + 1 < m->coh_colour_ptr.size(); c++) {
         const int first = m->coh_colour_ptr[c], cnt = m->coh_colour_ptr[c + 1] - first;
-        hipLaunchKernelGGL(k_coh_mesh<true>, dim3(cdiv((size_t)cnt, 128)), dim3(128), 0, s, first, cnt, m->coh_conn.p, m->coh_props.p,
+        hipLaunchKernelGGL(k_coh_mesh<true>, dim3(cdiv((size_t)cnt * 16, 128)), dim3(128), 0, s, first, cnt, m->coh_conn.p, m->coh_props.p,
                            m->coords.p, utot, dt, rels_mode, rn, (double*)nullptr, J->rowlen.p, J->boff.p, J->bcol.p, jval);
     }
     J->unsymmetric = true;

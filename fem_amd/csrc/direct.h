@@ -58,6 +58,8 @@ struct BandLU {
     int nbk = 0;                // blocks of kl rows
     DBuf<double> cL0, cD0, cU0, cL, cD, cU, cr;   // the block tridiagonal form (pristine / work copies), right-hand side and solution by blocks
     bool bcr_resident = false;  // the reduction as one resident launch per solve (k_bcr_resident)
+    bool bcr_pcr = false;       // ... in its parallel form (k_pcr_resident: few blocks)
+    DBuf<double> pcr_extra;     // the second set of arrays its levels alternate with: [D | r | r]
     DBuf<double> cEL, cEU, cz;  // D^-1 [L U r] of the eliminated blocks (resident launch)
     DBuf<unsigned> bcr_words;   // the grid barrier's words, status words behind them
     void factor_band();

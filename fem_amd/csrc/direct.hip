@@ -988,6 +988,72 @@ __device__ __forceinline__ bool bcr_gj_pair(double (&Ml)[B], double (&Mr)[B], do
 {
     return bcr_gj_step<B, 0>(Ml, Mr, tiny);
 }
+// One block's step of a level: block i takes in its neighbours jl = i - s and jr = i + s (hl, hr: they exist), read from `src`; `out`
+// = the lane's column of the new [D_i L_i U_i r_i].  STORE_E: D^-1 [L U r] of the right-hand neighbour goes to EL / EU / z.
+struct BcrSrc { const double *L, *D, *U, *r; };
+template <int B, bool STORE_E>
+__device__ __forceinline__ bool bcr_level_block(const BcrSrc& src, long long i, long long jl, long long jr, bool hl, bool hr, int lane,
+                                                int kind, int cc, double am, double tiny, double (&out)[B], double* EL, double* EU,
+                                                double* z)
+{
+    constexpr int BB = B * B;
+    // one pointer and one stride per lane (its column of D, L or U, or the right-hand side): one load per row and block
+    const size_t ocol = kind == 3 ? 0 : (size_t)cc;
+    const int sd = kind == 3 ? 1 : B;
+    const double* bD = kind == 0 ? src.D : kind == 1 ? src.L : kind == 2 ? src.U : src.r;
+    const size_t bsz = kind == 3 ? (size_t)B : (size_t)BB;
+    const double *pl = bD + (size_t)(hl ? jl : i) * bsz + ocol, *pr = bD + (size_t)(hr ? jr : i) * bsz + ocol, *po = bD + (size_t)i * bsz + ocol;
+    // the block's own L_i (lanes 0 .. B-1) and U_i (lanes B .. 2B-1), a column per lane: their entries reach the update below as
+    // uniform values (v_readlane), not through the LDS -- the compiler hoists every LDS read of such a loop in front of it
+    // (2 B^2 registers: k_bcr_update<13> spills 800 bytes per lane for that)
+    const double* pown = (lane < B ? src.L : src.U) + (size_t)i * BB + (lane < B ? lane : lane - B);
+    const bool hown = lane < B ? hl : (lane < 2 * B && hr);
+    double Ml[B], Mr[B], own[B];
+#pragma unroll
+    for (int q = 0; q < B; q++) {
+        const double idn = (kind == 0 && q == cc) ? am : 0.0;   // (no neighbour: a diagonal of the matrix's scale goes through the elimination)
+        const double vl = kind < 4 ? pl[q * sd] : 0.0, vr = kind < 4 ? pr[q * sd] : 0.0, vo = (kind == 0 || kind == 3) ? po[q * sd] : 0.0;
+        Ml[q] = hl ? vl : idn;
+        Mr[q] = hr ? vr : idn;
+        out[q] = vo;
+        own[q] = (lane < 2 * B && hown) ? pown[q * B] : 0.0;
+    }
+    const bool bad = bcr_gj_pair<B>(Ml, Mr, tiny);
+    if constexpr (STORE_E) {
+        if (hr && kind >= 1 && kind <= 3) {   // what the way up needs of the right-hand neighbour
+            double* pe = (kind == 1 ? EL : kind == 2 ? EU : z) + (size_t)jr * bsz + ocol;
+#pragma unroll
+            for (int q = 0; q < B; q++) pe[q * sd] = Mr[q];
+        }
+    }
+    // the columns the rows of block i take in: D_i <- D_i - L_i (D^-1 U)_jl - U_i (D^-1 L)_jr, L_i <- -L_i (D^-1 L)_jl,
+    // U_i <- -U_i (D^-1 U)_jr, r_i <- r_i - L_i (D^-1 r)_jl - U_i (D^-1 r)_jr
+#pragma unroll
+    for (int q = 0; q < B; q++) {
+        const double ul = __shfl(Ml[q], 2 * B + cc), lr = __shfl(Mr[q], B + cc);
+        Ml[q] = !hl ? 0.0 : kind == 0 ? ul : (kind == 1 || kind == 3) ? Ml[q] : 0.0;
+        Mr[q] = !hr ? 0.0 : kind == 0 ? lr : (kind == 2 || kind == 3) ? Mr[q] : 0.0;
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+        double a = out[r];
+#pragma unroll
+        for (int q = 0; q < B; q++) a = fma(-readlane_f64(own[r], q), Ml[q], fma(-readlane_f64(own[r], B + q), Mr[q], a));
+        out[r] = a;
+    }
+    return bad;
+}
+// the lane's column of [D L U r] of block i to the arrays of `dst`
+template <int B>
+__device__ __forceinline__ void bcr_store_block(double* L, double* D, double* U, double* r, long long i, int kind, int cc, const double (&out)[B])
+{
+    if (kind < 4) {
+        double* pw = kind == 3 ? r + (size_t)i * B : (kind == 0 ? D : kind == 1 ? L : U) + (size_t)i * B * B + cc;
+        const int sd = kind == 3 ? 1 : B;
+#pragma unroll
+        for (int q = 0; q < B; q++) pw[q * sd] = out[q];
+    }
+}
 // L, D, U: work copies (written and read again inside the launch: no __restrict__, no const -- nothing of them may go through the
 // scalar cache); EL, EU, z: D^-1 [L U r] of every eliminated block; rv: right-hand side by blocks in, solution out
 template <int B>
@@ -1007,60 +1073,13 @@ __global__ void __launch_bounds__(256) k_bcr_resident(int nbk, const double* __r
     bool bad = false;
     int smax = 0;
     for (int st = 1; st < nbk; st *= 2) {
-        const double* sL = st == 1 ? L0 : L;
-        const double* sD = st == 1 ? D0 : D;
-        const double* sU = st == 1 ? U0 : U;
+        const BcrSrc src{st == 1 ? L0 : L, st == 1 ? D0 : D, st == 1 ? U0 : U, rv};
         const int count = (nbk + 2 * st - 1) / (2 * st);
         for (int t = gw; t < count; t += nw) {
             const long long i = (long long)t * 2 * st, jl = i - st, jr = i + st;
-            const bool hl = jl >= 0, hr = jr < nbk;
-            // one pointer and one stride per lane (its column of D, L or U, or the right-hand side): one load per row and block
-            const size_t ocol = kind == 3 ? 0 : (size_t)cc;
-            const int sd = kind == 3 ? 1 : B;
-            const double* bD = kind == 0 ? sD : kind == 1 ? sL : kind == 2 ? sU : rv;
-            const size_t bsz = kind == 3 ? (size_t)B : (size_t)BB;
-            const double *pl = bD + (size_t)(hl ? jl : i) * bsz + ocol, *pr = bD + (size_t)(hr ? jr : i) * bsz + ocol, *po = bD + (size_t)i * bsz + ocol;
-            // the block's own L_i (lanes 0 .. B-1) and U_i (lanes B .. 2B-1), a column per lane: their entries reach the update below as
-            // uniform values (v_readlane), not through the LDS -- the compiler hoists every LDS read of such a loop in front of it
-            // (2 B^2 registers: k_bcr_update<13> spills 800 bytes per lane for that)
-            const double* pown = (lane < B ? sL : sU) + (size_t)i * BB + (lane < B ? lane : lane - B);
-            const bool hown = lane < B ? hl : (lane < 2 * B && hr);
-            double Ml[B], Mr[B], out[B], own[B];
-#pragma unroll
-            for (int q = 0; q < B; q++) {
-                const double idn = (kind == 0 && q == cc) ? am : 0.0;   // (no neighbour: a diagonal of the matrix's scale goes through the elimination)
-                const double vl = kind < 4 ? pl[q * sd] : 0.0, vr = kind < 4 ? pr[q * sd] : 0.0, vo = (kind == 0 || kind == 3) ? po[q * sd] : 0.0;
-                Ml[q] = hl ? vl : idn;
-                Mr[q] = hr ? vr : idn;
-                out[q] = vo;
-                own[q] = (lane < 2 * B && hown) ? pown[q * B] : 0.0;
-            }
-            bad |= bcr_gj_pair<B>(Ml, Mr, tiny);
-            if (hr && kind >= 1 && kind <= 3) {   // what the way up needs of the right-hand neighbour
-                double* pe = (kind == 1 ? EL : kind == 2 ? EU : z) + (size_t)jr * bsz + ocol;
-#pragma unroll
-                for (int q = 0; q < B; q++) pe[q * sd] = Mr[q];
-            }
-            // the columns the rows of block i take in: D_i <- D_i - L_i (D^-1 U)_jl - U_i (D^-1 L)_jr, L_i <- -L_i (D^-1 L)_jl,
-            // U_i <- -U_i (D^-1 U)_jr, r_i <- r_i - L_i (D^-1 r)_jl - U_i (D^-1 r)_jr
-#pragma unroll
-            for (int q = 0; q < B; q++) {
-                const double ul = __shfl(Ml[q], 2 * B + cc), lr = __shfl(Mr[q], B + cc);
-                Ml[q] = !hl ? 0.0 : kind == 0 ? ul : (kind == 1 || kind == 3) ? Ml[q] : 0.0;
-                Mr[q] = !hr ? 0.0 : kind == 0 ? lr : (kind == 2 || kind == 3) ? Mr[q] : 0.0;
-            }
-#pragma unroll
-            for (int r = 0; r < B; r++) {
-                double a = out[r];
-#pragma unroll
-                for (int q = 0; q < B; q++) a = fma(-readlane_f64(own[r], q), Ml[q], fma(-readlane_f64(own[r], B + q), Mr[q], a));
-                out[r] = a;
-            }
-            if (kind < 4) {
-                double* pw = (kind == 0 ? D : kind == 1 ? L : kind == 2 ? U : rv) + (size_t)i * bsz + ocol;
-#pragma unroll
-                for (int r = 0; r < B; r++) pw[r * sd] = out[r];
-            }
+            double out[B];
+            bad |= bcr_level_block<B, true>(src, i, jl, jr, jl >= 0, jr < nbk, lane, kind, cc, am, tiny, out, EL, EU, z);
+            bcr_store_block<B>(L, D, U, rv, i, kind, cc, out);
         }
         smax = st;
         if (!grid_barrier(bar, gl, shu)) return;
@@ -1094,6 +1113,55 @@ __global__ void __launch_bounds__(256) k_bcr_resident(int nbk, const double* __r
             if (lane < B) rv[(size_t)j * B + lane] = a;
         }
     }
+}
+// Few blocks (one wavefront each fits the chip): PARALLEL cyclic reduction -- every block takes in its neighbours at every level, so
+// that after log2(nb) levels each one stands alone and is solved where it is: no way up, half the barriers (config 5's strip, 616
+// blocks: 10 instead of 21).  log2(nb) times the arithmetic of the reduction above, which is why it is for few blocks only.  Levels
+// alternate between two sets of arrays (A, Bq): a level reads what every block of the level before wrote.  x: the solution by blocks.
+template <int B>
+__global__ void __launch_bounds__(256) k_pcr_resident(int nbk, const double* __restrict__ L0, const double* __restrict__ D0,
+                                                      const double* __restrict__ U0, const double* __restrict__ r0, double* LA, double* DA,
+                                                      double* UA, double* rA, double* LB, double* DB, double* UB, double* rB, double* x,
+                                                      const double* __restrict__ amax, int* flag, GridBarrier bar)
+{
+    static_assert(3 * B + 1 <= 64, "[D L U r] of a block must fit one wavefront");
+    __shared__ unsigned shu[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int gw = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + wv), nw = (int)gridDim.x * 4;
+    GridBarrierLane gl = grid_barrier_census(bar, gridDim.x, shu);
+    const double am = *amax, tiny = 1e-6 * am;
+    const int kind = lane < B ? 0 : lane < 2 * B ? 1 : lane < 3 * B ? 2 : lane == 3 * B ? 3 : 4, cc = lane - B * (kind < 3 ? kind : 3);
+    bool bad = false;
+    int lvl = 0;
+    for (int st = 1;; st *= 2, lvl++) {
+        const bool last = st >= nbk;   // (no neighbour left at this distance: the blocks stand alone)
+        const BcrSrc src = lvl == 0 ? BcrSrc{L0, D0, U0, r0} : (lvl & 1) ? BcrSrc{LA, DA, UA, rA} : BcrSrc{LB, DB, UB, rB};
+        for (int i = gw; i < nbk; i += nw) {
+            double out[B];
+            if (!last) {
+                const long long jl = (long long)i - st, jr = (long long)i + st;
+                bad |= bcr_level_block<B, false>(src, i, jl, jr, jl >= 0, jr < nbk, lane, kind, cc, am, tiny, out, nullptr, nullptr, nullptr);
+            }
+            if (last || 2 * st >= nbk) {   // x_i = D_i^-1 r_i, from the registers where the level has just been taken in
+                double Ml[B], Mr[B];
+#pragma unroll
+                for (int q = 0; q < B; q++) {
+                    const double own = last ? (kind == 0 ? src.D[(size_t)i * B * B + q * B + cc] : kind == 3 ? src.r[(size_t)i * B + q] : 0.0) : out[q];
+                    Ml[q] = (kind == 0 || kind == 3) ? own : 0.0;
+                    Mr[q] = (kind == 0 && q == cc) ? am : 0.0;
+                }
+                bad |= bcr_gj_pair<B>(Ml, Mr, tiny);
+                if (kind == 3) {
+#pragma unroll
+                    for (int q = 0; q < B; q++) x[(size_t)i * B + q] = Ml[q];
+                }
+            } else if (lvl & 1) bcr_store_block<B>(LB, DB, UB, rB, i, kind, cc, out);
+            else bcr_store_block<B>(LA, DA, UA, rA, i, kind, cc, out);
+        }
+        if (last || 2 * st >= nbk) break;
+        if (!grid_barrier(bar, gl, shu)) return;
+    }
+    if (bad && lane == 0) atomicAdd(flag, 1);
 }
 // what a solve by the resident reduction needs in front of it, in one launch: the right-hand side in the band's numbering (twice: the
 // reduction overwrites one, the backward-error test reads the other), zeros in the rows past the matrix, the barrier's words and the
@@ -1407,12 +1475,20 @@ void BandLU::setup(fem_mat A_)
             for (DBuf<double>* a : {&cEL, &cEU}) if (a->n != nb2) a->alloc(nb2);
             if (cz.n != (size_t)nbk * kl) cz.alloc((size_t)nbk * kl);
             if (bcr_words.n != (size_t)GridBarrier::WORDS + 32) bcr_words.alloc((size_t)GridBarrier::WORDS + 32);
+            // few blocks (a wavefront each is resident at once): the parallel form of the reduction (FEM_AMD_LU_BCR_PCR=0: never)
+            const char* pe = std::getenv("FEM_AMD_LU_BCR_PCR");
+            int occ = 0;
+            const void* kp = kl == 5 ? (const void*)k_pcr_resident<5> : kl == 9 ? (const void*)k_pcr_resident<9> : kl == 13 ? (const void*)k_pcr_resident<13>
+                           : kl == 17 ? (const void*)k_pcr_resident<17> : (const void*)k_pcr_resident<21>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kp, 256, 0) != hipSuccess) { (void)hipGetLastError(); occ = 0; }
+            bcr_pcr = !(pe && std::atoi(pe) == 0) && !sym.pcr_failed && (long long)(nbk + 3) / 4 <= (long long)std::min(occ, 2) * ctx->num_cu;
+            if (bcr_pcr && pcr_extra.n != nb2 + 2 * (size_t)nbk * kl) pcr_extra.alloc(nb2 + 2 * (size_t)nbk * kl);
             bcr = true;
         } else
             bcr = bcr_reduce(false);
         if (std::getenv("FEM_AMD_DIRECT_VERBOSE"))
             fprintf(stderr, "[fem_amd lu] block cyclic reduction: %d blocks of %d rows: %s\n", nbk, kl,
-                    bcr_resident ? "used (one resident launch per solve, which also looks at the pivots)" : bcr ? "used" : "a small pivot on the way: band LU");
+                    bcr_resident ? (bcr_pcr ? "used (parallel cyclic reduction, one resident launch per solve, which also looks at the pivots)" : "used (one resident launch per solve, which also looks at the pivots)") : bcr ? "used" : "a small pivot on the way: band LU");
         if (bcr) { null_pivots = 0; failed = false; return; }
         flag.zero(s);
     }
@@ -1524,16 +1600,39 @@ void BandLU::solve(const double* b, double* x)
                            cr.p, v0.p, bcr_words.p, nwords);
         GridBarrier bar{bcr_words.p, reinterpret_cast<int*>(status)};
         int* pflag = reinterpret_cast<int*>(status + 1);
-        const unsigned nwg = (unsigned)std::min<long long>(((nbk + 1) / 2 + 3) / 4, std::max(ctx->num_cu, 1));
         const double* am = v0.p + n;
-        switch (kl) {
-        case 5: hipLaunchKernelGGL(k_bcr_resident<5>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
-        case 9: hipLaunchKernelGGL(k_bcr_resident<9>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
-        case 13: hipLaunchKernelGGL(k_bcr_resident<13>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
-        case 17: hipLaunchKernelGGL(k_bcr_resident<17>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
-        default: hipLaunchKernelGGL(k_bcr_resident<21>, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar); break;
+        const double* xblocks = cr.p;
+        if (bcr_pcr) {
+            // few blocks: parallel cyclic reduction, a wavefront per block at every level (k_pcr_resident)
+            const unsigned nwg = (unsigned)((nbk + 3) / 4);
+            const size_t nb2 = (size_t)nbk * kl * kl, nr = (size_t)nbk * kl;
+            double *DB = pcr_extra.p, *rA = DB + nb2, *rB = rA + nr;
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cr.p, cL.p, cD.p, cU.p, rA, cEL.p, DB, cEU.p, rB,
+                                   cz.p, am, pflag, bar);
+            };
+            switch (kl) {
+            case 5: go(k_pcr_resident<5>); break;
+            case 9: go(k_pcr_resident<9>); break;
+            case 13: go(k_pcr_resident<13>); break;
+            case 17: go(k_pcr_resident<17>); break;
+            default: go(k_pcr_resident<21>); break;
+            }
+            xblocks = cz.p;
+        } else {
+            const unsigned nwg = (unsigned)std::min<long long>(((nbk + 1) / 2 + 3) / 4, std::max(ctx->num_cu, 1));
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3(nwg), dim3(256), 0, s, nbk, cL0.p, cD0.p, cU0.p, cL.p, cD.p, cU.p, cEL.p, cEU.p, cz.p, cr.p, am, pflag, bar);
+            };
+            switch (kl) {
+            case 5: go(k_bcr_resident<5>); break;
+            case 9: go(k_bcr_resident<9>); break;
+            case 13: go(k_bcr_resident<13>); break;
+            case 17: go(k_bcr_resident<17>); break;
+            default: go(k_bcr_resident<21>); break;
+            }
         }
-        hipLaunchKernelGGL(k_band_backward_error, dim3(g), dim3(256), 0, s, n, kl, wb, ab.p, cr.p, v0.p,
+        hipLaunchKernelGGL(k_band_backward_error, dim3(g), dim3(256), 0, s, n, kl, wb, ab.p, xblocks, v0.p,
                            reinterpret_cast<unsigned long long*>(status + 2));
         FEM_HIP(hipGetLastError());
         unsigned h[4] = {0, 0, 0, 0};
@@ -1544,16 +1643,28 @@ void BandLU::solve(const double* b, double* x)
         const char* te = std::getenv("FEM_AMD_LU_BCR_TOL");
         const bool ok = h[0] == 0 && h[1] == 0 && err <= (te ? std::atof(te) : 1e-10);
         if (ok) {
-            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, cr.p, x);
+            hipLaunchKernelGGL(k_permute_out, dim3(g), dim3(256), 0, s, (size_t)n, perm_dof, xblocks, x);
             FEM_HIP(hipGetLastError());
             return;
         }
+        const bool from_pcr = bcr_pcr && !h[0];
         if (std::getenv("FEM_AMD_DIRECT_VERBOSE")) {
             if (h[0]) fprintf(stderr, "[fem_amd lu] block cyclic reduction: the grid barrier of the resident launch gave up: a launch per level from here on\n");
+            else if (from_pcr && h[1]) fprintf(stderr, "[fem_amd lu] block cyclic reduction, parallel form: small pivots on the way: the form with a way up on this sparsity from here on\n");
+            else if (from_pcr) fprintf(stderr, "[fem_amd lu] block cyclic reduction, parallel form: backward error %.2e: the form with a way up on this sparsity from here on\n", err);
             else if (h[1]) fprintf(stderr, "[fem_amd lu] block cyclic reduction: a small pivot on the way: band LU from here on\n");
             else fprintf(stderr, "[fem_amd lu] block cyclic reduction: backward error %.2e: band LU from here on\n", err);
         }
         if (h[0]) bcr_resident = false;      // (the reduction itself is sound: its launches, below)
+        else if (from_pcr) {
+            // every unknown of the parallel form comes out of the Schur complement of all the others onto its block (on a slender
+            // cantilever: pivots of the order (h / L)^3 of the entries); the reduction with a way up gets most unknowns from their
+            // neighbours' values: it is the more accurate of the two on such strips.  Remembered on the sparsity (a Newton loop builds a new factorisation per Jacobian).
+            bcr_pcr = false;
+            A->pat->lu_sym->pcr_failed = true;
+            solve(b, x);
+            return;
+        }
         else { bcr = false; if (!band_ready) factor_band(); }
     }
     if (bcr) {

@@ -239,9 +239,16 @@ def test_band_lu_by_one_wavefront_equals_the_column_walk(gpu_ctx, monkeypatch, c
     assert np.abs(xs["1"] - xs["0"]).max() <= 1e-9 * np.abs(xs["0"]).max()
 
 
-# (FEM_AMD_LU_BCR_RESIDENT: "1" = the reduction as one resident launch per solve, the default; "0" = a launch per level, with the trial
-# reduction at set-up -- what the resident launch falls back to when its grid barrier gives up)
-@pytest.mark.parametrize("resident", ["1", "0"])
+# The three forms of the reduction: "pcr" = one resident launch per solve, parallel cyclic reduction (the default where a wavefront per
+# block fits the chip: every mesh of these tests); "cr" = one resident launch, cyclic reduction with its way up (FEM_AMD_LU_BCR_PCR=0:
+# what long strips get); "0" = a launch per level with the trial reduction at set-up (FEM_AMD_LU_BCR_RESIDENT=0: what the resident
+# launches fall back to when their grid barrier gives up)
+def _bcr_form(monkeypatch, form):
+    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", "0" if form == "0" else "1")
+    monkeypatch.setenv("FEM_AMD_LU_BCR_PCR", "1" if form == "pcr" else "0")
+
+
+@pytest.mark.parametrize("resident", ["pcr", "cr", "0"])
 @pytest.mark.parametrize("name,mesh", [("quad_400x1", lambda: structured_quad(400, 1, jitter=0.1)),      # half bandwidth 7 (blocks of 9 rows)
                                        ("quad_300x2", lambda: structured_quad(300, 2, jitter=0.1)),      # 11 (13)
                                        ("quad_320x3", lambda: structured_quad(320, 3, jitter=0.1)),      # 15 (17)
@@ -255,7 +262,7 @@ def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, c
     import scipy.sparse.linalg as sla
     m = mesh()
     monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
-    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", resident)
+    _bcr_form(monkeypatch, resident)
     xs = {}
     for bcr in ("1", "0"):
         monkeypatch.setenv("FEM_AMD_LU_BCR", bcr)
@@ -278,7 +285,11 @@ def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, c
         xs[bcr] = prob.U.get_array()
         log = capfd.readouterr().err
         if bcr == "1":
-            assert "block cyclic reduction" in log and "used" in log and "backward error" not in log, log
+            assert "block cyclic reduction" in log and "used" in log, log
+            # (the parallel form may fail its backward-error test on these slender cantilevers -- quad_400x1 does, at 1.1e-10 -- and
+            # hand over to the form with a way up; that one, and the launches per level, must pass)
+            assert log.count("backward error") == log.count("parallel form: backward error"), log
+            assert log.count("parallel form:") <= (1 if resident == "pcr" else 0) and "band LU from here on" not in log, log
         else:
             assert "block cyclic reduction" not in log
         A = sp.csr_matrix((v, ci, rp))
@@ -294,7 +305,7 @@ def test_block_cyclic_reduction_on_a_stiffness_like_band(gpu_ctx, monkeypatch, c
     assert np.abs(xs["1"] - xs["0"]).max() <= 1e-5 * np.abs(xs["0"]).max()
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
+@pytest.mark.parametrize("resident", ["pcr", "cr", "0"])
 def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkeypatch, capfd, resident):
     """A free-floating strip (no Dirichlet condition: three rigid-body modes) with a self-equilibrated load: the factorisation
     meets pivots below 1e-6 of the largest entry and fixes those unknowns to zero (what MUMPS does under ICNTL(24) = 1,
@@ -310,7 +321,7 @@ def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkey
     m.fnode = np.array([left, right], dtype=np.int32)
     m.fval = np.array([[-1e6, 0.0, 0.0, m.t], [1e6, 0.0, 0.0, m.t]])
     monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
-    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", resident)
+    _bcr_form(monkeypatch, resident)
     xs = {}
     for name, env in (("wave", {"FEM_AMD_LU_WAVE": "1", "FEM_AMD_LU_BCR": "0"}), ("walk", {"FEM_AMD_LU_WAVE": "0", "FEM_AMD_LU_BCR": "0"}),
                       ("bcr", {"FEM_AMD_LU_WAVE": "1", "FEM_AMD_LU_BCR": "1"})):
@@ -342,14 +353,14 @@ def test_null_pivots_are_fixed_the_same_way_by_every_band_kernel(gpu_ctx, monkey
     assert np.abs(xs["bcr"] - xs["walk"]).max() <= 1e-6 * scale
 
 
-@pytest.mark.parametrize("resident", ["1", "0"])
+@pytest.mark.parametrize("resident", ["pcr", "cr", "0"])
 def test_a_solve_that_fails_the_backward_error_test_goes_to_the_band_lu(gpu_ctx, monkeypatch, capfd, resident):
     """The safety net of block cyclic reduction: a solve whose componentwise backward error exceeds the bound is repeated by the band
     LU (factorised then), and so is every later solve with that matrix.  The bound is set to 0 here (FEM_AMD_LU_BCR_TOL), so that
     the first solve takes that way: same answer as with the band LU from the start, and a second right-hand side is solved too."""
     m = structured_quad(300, 2, jitter=0.1)
     monkeypatch.setenv("FEM_AMD_DIRECT_VERBOSE", "1")
-    monkeypatch.setenv("FEM_AMD_LU_BCR_RESIDENT", resident)
+    _bcr_form(monkeypatch, resident)
     xs = {}
     for name, env in (("fallback", {"FEM_AMD_LU_BCR": "1", "FEM_AMD_LU_BCR_TOL": "0"}), ("band", {"FEM_AMD_LU_BCR": "0", "FEM_AMD_LU_BCR_TOL": "1e-10"})):
         for k, v in env.items():
@@ -369,7 +380,8 @@ def test_a_solve_that_fails_the_backward_error_test_goes_to_the_band_lu(gpu_ctx,
         xs[name] = (x1, prob.U.get_array())
         log = capfd.readouterr().err
         if name == "fallback":
-            assert "used" in log and log.count("backward error") == 1, log     # the second solve no longer tries the reduction
+            # the second solve no longer tries the reduction (the parallel form hands over to the form with a way up first)
+            assert "used" in log and log.count("band LU from here on") == 1 and log.count("parallel form:") == (1 if resident == "pcr" else 0), log
         prob.destroy()
     for a, b in zip(xs["fallback"], xs["band"]):
         assert np.array_equal(a, b)

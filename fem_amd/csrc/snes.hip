@@ -11,6 +11,7 @@
 // the library's device primitives (fem_mat_copy, fem_mat_add_cohesive, fem_vec_add_cohesive_traction, ...).
 // All vectors live on the device; the scalars of the line search are reduced there and read back -- a Newton
 // iteration costs a factorisation or a Krylov solve, the handful of round trips does not matter.
+#include <chrono>
 #include <cmath>
 #include <sstream>
 
@@ -43,7 +44,8 @@ struct fem_snes_s {
     double fnorm = 0.0;
     fem_vec Y = nullptr, W = nullptr, G = nullptr;
     DBuf<double> red;               // partials and results of dots3 (kept: no block request per line-search trial)
-    double* h_red = nullptr;        // pinned, 3 doubles
+    double* h_red = nullptr;        // pinned, coherent: 3 doubles and the ticket of the read-back that wrote them
+    unsigned long long red_ticket = 0;
 };
 
 // Vec helpers of ksp.hip / capi.cpp
@@ -77,7 +79,11 @@ __global__ void __launch_bounds__(256) k_dots3_partial(size_t n, int npairs, con
         if (threadIdx.x == 0) part[(size_t)q * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
     }
 }
-__global__ void __launch_bounds__(256) k_dots3_final(int nblocks, const double* __restrict__ part, double* __restrict__ out)
+// host_out (pinned, coherent host memory: 3 doubles and a ticket): the sums go straight to the host, the ticket behind a system-scope
+// fence -- the host polls the ticket instead of enqueueing a copy and waiting for the stream (a copy kernel, its completion signal and
+// the wake-up: 20-25 us of idle device per read-back of a line search that has two of them per trial point)
+__global__ void __launch_bounds__(256) k_dots3_final(int nblocks, const double* __restrict__ part, double* __restrict__ out,
+                                                     double* __restrict__ host_out, unsigned long long ticket)
 {
     __shared__ double sh[4];
     for (int q = 0; q < 3; q++) {
@@ -87,7 +93,15 @@ __global__ void __launch_bounds__(256) k_dots3_final(int nblocks, const double* 
         __syncthreads();
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = x;
         __syncthreads();
-        if (threadIdx.x == 0) out[q] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        if (threadIdx.x == 0) {
+            const double v = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+            out[q] = v;
+            if (host_out) host_out[q] = v;
+        }
+    }
+    if (host_out && threadIdx.x == 0) {
+        __threadfence_system();
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host_out + 3), ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -114,12 +128,31 @@ void dots3(fem_snes sn, int npairs, fem_vec a0, fem_vec b0, fem_vec a1, fem_vec 
     const size_t n = (size_t)a0->n;
     const int nb = (int)std::min<size_t>(256, std::max<size_t>(1, (n + 255) / 256));
     if (sn->red.n < (size_t)3 * 256 + 3) sn->red.alloc((size_t)3 * 256 + 3);
-    if (!sn->h_red) FEM_HIP(hipHostMalloc((void**)&sn->h_red, 3 * sizeof(double)));
+    if (!sn->h_red) {
+        FEM_HIP(hipHostMalloc((void**)&sn->h_red, 4 * sizeof(double)));
+        sn->h_red[3] = 0.0;   // (the ticket's bits: 0)
+    }
+    // FEM_AMD_SNES_POLL=0: the read-back as a copy and a stream synchronisation
+    static const bool poll = !(std::getenv("FEM_AMD_SNES_POLL") && std::atoi(std::getenv("FEM_AMD_SNES_POLL")) == 0);
     hipLaunchKernelGGL(k_dots3_partial, dim3(nb), dim3(256), 0, s, n, npairs, a0->d.p, b0->d.p, (a1 ? a1 : a0)->d.p, (b1 ? b1 : b0)->d.p,
                        (a2 ? a2 : a0)->d.p, (b2 ? b2 : b0)->d.p, sn->red.p);
-    hipLaunchKernelGGL(k_dots3_final, dim3(1), dim3(256), 0, s, nb, sn->red.p, sn->red.p + (size_t)3 * 256);
-    FEM_HIP(hipMemcpyAsync(sn->h_red, sn->red.p + (size_t)3 * 256, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
-    FEM_HIP(hipStreamSynchronize(s));
+    const unsigned long long ticket = ++sn->red_ticket;
+    hipLaunchKernelGGL(k_dots3_final, dim3(1), dim3(256), 0, s, nb, sn->red.p, sn->red.p + (size_t)3 * 256, poll ? sn->h_red : (double*)nullptr, ticket);
+    FEM_HIP(hipGetLastError());
+    bool got = false;
+    if (poll) {
+        const volatile unsigned long long* tk = reinterpret_cast<const volatile unsigned long long*>(sn->h_red + 3);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (long spins = 0;; spins++) {
+            if (__atomic_load_n(tk, __ATOMIC_ACQUIRE) == ticket) { got = true; break; }
+            // (a device error, or a platform whose host memory the device does not write through: the stream tells)
+            if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+    }
+    if (!got) {
+        FEM_HIP(hipMemcpyAsync(sn->h_red, sn->red.p + (size_t)3 * 256, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        FEM_HIP(hipStreamSynchronize(s));
+    }
     for (int q = 0; q < 3; q++) out[q] = sn->h_red[q];
 }
 

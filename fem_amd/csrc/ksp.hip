@@ -329,6 +329,7 @@ struct fem_ksp_s {
     std::unique_ptr<fem::BandLU> direct_lu;      // the same on a Mat flagged unsymmetric (Newton Jacobian)
     DBuf<double> bcgs_work;                      // -ksp_type bcgs: r, r', v, t, s, p, A*in scratch
     bool mg_additive = false;
+    bool mg_st_f32 = !(std::getenv("FEM_AMD_MG_ST_F32") && std::atoi(std::getenv("FEM_AMD_MG_ST_F32")) == 0);   // -pc_mg_stencil_f32 (mg.hip, setup_t)
     long long stream_min_dof = -1;           // -ksp_stream_min_dof n: streaming hints + stored z from n dofs per domain on; -1: FEM_AMD_STREAM_MIN_DOF / 8 M
     int halo_overlap = -1;                   // -ksp_halo_overlap 0|1: the exchange beside the interior tiles; -1: FEM_AMD_OVERLAP
     int fuse_allreduce = -1;                 // -ksp_fuse_allreduce 0|1: p.Kp all-reduce in the RCCL group of the halo exchange; -1: FEM_AMD_FUSE_ALLREDUCE
@@ -369,7 +370,7 @@ struct fem_ksp_s {
     fem_mat prev_A = nullptr;
     unsigned long long prev_state = 0;
     bool prev_seen = false, op_changes = false;
-    std::string method_key() const { return type + "/" + pc + "/" + mult_type + (mg_additive ? "/a" : "/m"); }
+    std::string method_key() const { return type + "/" + pc + "/" + mult_type + (mg_additive ? "/a" : "/m") + (mg_st_f32 ? "/s" : "/d"); }
     ~fem_ksp_s() {
         if (h_state) (void)hipHostFree(h_state);
         for (auto e : poll_ev) if (e) (void)hipEventDestroy(e);
@@ -403,6 +404,7 @@ void ksp_set_from_options_impl(fem_ksp k, const char* options)
         else if (key == "-pc_mg_alpha") { is >> k->mg_alpha; }     // coarse-correction scaling (over-correction)
         else if (key == "-pc_mg_box") { is >> k->mg_box; FEM_CHECK(k->mg_box >= 2.0 && k->mg_box <= 16.0, 6, "-pc_mg_box must lie in [2, 16]"); }
         else if (key == "-pc_mg_omega") { is >> k->mg_omega; }
+        else if (key == "-pc_mg_stencil_f32") { int v = 1; is >> v; k->mg_st_f32 = v != 0; }   // the cycle's copy of a large level's stencil in single precision
         else if (key == "-pc_mg_slice_min") { is >> k->mg_slice_min; }   // accepted and ignored (round 3's sliced level-1 residuals: the box levels are distributed now, mg.h)     // Jacobi damping of the smoother
         else if (key == "-mat_mult_type") {
             is >> val;
@@ -480,6 +482,7 @@ void ksp_set_up_impl(fem_ksp k)
         k->mg->alpha = (k->mg_alpha > 0.0) ? k->mg_alpha : (k->mg_additive ? 1.5 : 1.0);
         k->mg->omega = k->mg_omega;
         k->mg->box = k->mg_box;
+        k->mg->stencil_f32 = k->mg_st_f32;
         k->mg->setup(A);
         k->z.alloc(n);
     }

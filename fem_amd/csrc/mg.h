@@ -30,6 +30,7 @@ struct MgLevel {
     int nx = 0, ny = 0, nz = 0, nb = 0;
     double lo[3] = {0, 0, 0}, H = 1.0;   // box b = (ix,iy,iz) has its centre at lo + (idx + 0.5) * H
     DBuf<double> st;    // [27][cs*cs][nb]  stencil entries, box index fastest
+    DBuf<float> stf;    // the cycle's single-precision copy of st (large levels; see setup_t)
     DBuf<double> dinv;  // [cs*cs][nb]  inverse of the diagonal block of every box (block-Jacobi smoother)
     DBuf<double> x, r, t;   // [nb*cs] iterate, right-hand side, residual
     // partitioned mesh: nx x ny x nz is the sub-grid of the global box grid that this domain's nodes reach, `off` its origin in
@@ -67,6 +68,7 @@ struct Multigrid {
     double omega_fine = 0.7, lambda_fine = 0.0;   // damping actually used: min(omega, 1.6 / lambda_max estimate)
     double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
+    bool stencil_f32 = true;        // -pc_mg_stencil_f32: the cycle streams a single-precision copy of the large levels' stencils
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     std::shared_ptr<MgBoxes> bx;    // level-1 aggregates (shared with the mesh's pattern)
     DBuf<unsigned char> w;          // [nn*bs] 1 on free dofs, 0 on penalty dofs

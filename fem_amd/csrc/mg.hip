@@ -711,6 +711,56 @@ __global__ void k_set_omega(const double* __restrict__ n2, double* __restrict__ 
 }
 
 // ---- cycle kernels ------------------------------------------------------------------------------------
+// The cycle's copy of a large level's stencil in single precision (MgLevel::stf): k_box_residual is a stream of the stencil (400 MB in
+// doubles on level 1 of config 3, twice per application of the preconditioner).  Two entries of a block row per 8-byte word, box index
+// fastest -- the same bytes per load instruction as the doubles (4-byte loads, one entry each, left the kernel with half the bytes in
+// flight: 2x slower than the doubles it was meant to beat).  Arithmetic in doubles.
+template <int CS>
+__global__ void __launch_bounds__(256) k_stencil_to_float2(int nb, const double* __restrict__ st, float2* __restrict__ stf)
+{
+    constexpr int CC = CS * CS, HP = CC / 2;
+    const size_t n = (size_t)27 * HP * nb;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i % nb, sk = i / nb, s = sk / HP, k = sk % HP;
+        stf[i] = make_float2((float)st[(s * CC + 2 * k) * nb + b], (float)st[(s * CC + 2 * k + 1) * nb + b]);
+    }
+}
+template <int CS, bool OWN>
+__global__ void __launch_bounds__(256) k_box_residual_f2(Grid3 g, int b0, int b1, const float2* __restrict__ stf,
+                                                         const double* __restrict__ x, const double* __restrict__ r,
+                                                         double* __restrict__ t, const unsigned char* __restrict__ own)
+{
+    static_assert(CS % 2 == 0, "two entries of a block row per word");
+    constexpr int HP = CS * CS / 2, HR = CS / 2;
+    const int nb = g.nb();
+    const int b = b0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= b1) return;
+    double acc[CS];
+#pragma unroll
+    for (int q = 0; q < CS; q++) acc[q] = r[(size_t)b * CS + q];
+    const double keep = OWN ? (own[b] ? 1.0 : 0.0) : 1.0;
+    if constexpr (OWN) {
+#pragma unroll
+        for (int q = 0; q < CS; q++) acc[q] *= keep;
+    }
+    for (int s = 0; s < 27; s++) {
+        int c;
+        if (!neighbour_box(g, b, s, c)) continue;
+        // (every load of the slot first: the stream lives on the bytes in flight)
+        float2 v[HP];
+        double xc[CS];
+#pragma unroll
+        for (int k = 0; k < HP; k++) v[k] = stf[((size_t)s * HP + k) * nb + b];
+#pragma unroll
+        for (int p = 0; p < CS; p++) xc[p] = x[(size_t)c * CS + p];
+#pragma unroll
+        for (int q = 0; q < CS; q++)
+#pragma unroll
+            for (int h = 0; h < HR; h++) acc[q] -= (double)v[q * HR + h].x * xc[2 * h] + (double)v[q * HR + h].y * xc[2 * h + 1];
+    }
+#pragma unroll
+    for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = acc[q];
+}
 // t = r - A x on a box level (27-point block stencil, thread per box)
 // (OWN: partitioned mesh -- st is this domain's sub-assembled part of the operator and r counts on the owner of a shared box only,
 // so that the halo sum of t over the domains is r - A x.  A template parameter, not a nullable pointer: with the run-time test in
@@ -1501,6 +1551,18 @@ static bool setup_t(Multigrid& mg)
         }
         FEM_HIP(hipStreamSynchronize(s));   // rowk/colk go out of scope
     }
+    // The cycle reads the stencil of a large level twice per application and nothing else of that size: it gets a single-precision
+    // copy (the preconditioner is a fixed linear operator either way; set-up -- diagonal blocks, the next level's Galerkin product,
+    // the eigenvalue estimate -- has used the doubles).  -pc_mg_stencil_f32 0 / FEM_AMD_MG_ST_F32=0: doubles.
+    for (size_t l = 0; l + 1 < mg.lev.size(); l++) {
+        MgLevel& L = mg.lev[l];
+        if (mg.stencil_f32 && L.nb > 16384 && CS % 2 == 0) {
+            if (L.stf.n != L.st.n) L.stf.alloc(L.st.n);
+            if constexpr (CS % 2 == 0)
+                hipLaunchKernelGGL(k_stencil_to_float2<CS>, dim3((unsigned)std::min<size_t>(g1(L.st.n / 2), 8192)), dim3(256), 0, s, L.nb, L.st.p,
+                                   reinterpret_cast<float2*>(L.stf.p));
+        } else L.stf.release();
+    }
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
     if (getenv("FEM_AMD_MG_VERBOSE")) {
@@ -1544,6 +1606,12 @@ static void cycle_t(Multigrid& mg, size_t l)
         if (L.nb <= 16384) {
             if (own) hipLaunchKernelGGL((k_box_residual_slots<CS, true>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
             else hipLaunchKernelGGL((k_box_residual_slots<CS, false>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+        } else if (CS % 2 == 0 && L.stf.n == L.st.n) {
+            if constexpr (CS % 2 == 0) {
+                const float2* f2 = reinterpret_cast<const float2*>(L.stf.p);
+                if (own) hipLaunchKernelGGL((k_box_residual_f2<CS, true>), gbx, dim3(256), 0, s, g, 0, L.nb, f2, L.x.p, L.r.p, L.t.p, own);
+                else hipLaunchKernelGGL((k_box_residual_f2<CS, false>), gbx, dim3(256), 0, s, g, 0, L.nb, f2, L.x.p, L.r.p, L.t.p, own);
+            }
         } else {
             if (own) hipLaunchKernelGGL((k_box_residual<CS, true>), gbx, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
             else hipLaunchKernelGGL((k_box_residual<CS, false>), gbx, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
@@ -1647,7 +1715,7 @@ bool Multigrid::fuses_dots() const { return fine_additive; }
 size_t Multigrid::device_bytes() const
 {
     size_t b = omega_l.bytes() + wr.bytes() + (bx ? bx->agg.bytes() + bx->box_ptr.bytes() + bx->box_nodes.bytes() : 0) + w.bytes() + dinv0.bytes() + t0.bytes() + cinv.bytes();
-    for (auto& L : lev) b += L.st.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes() + L.diag.bytes();
+    for (auto& L : lev) b += L.st.bytes() + L.stf.bytes() + L.dinv.bytes() + L.x.bytes() + L.r.bytes() + L.t.bytes() + L.diag.bytes();
     return b;
 }
 

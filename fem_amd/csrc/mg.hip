@@ -795,6 +795,41 @@ __global__ void __launch_bounds__(256) k_box_residual(Grid3 g, int b0, int b1, c
     for (int q = 0; q < CS; q++) t[(size_t)b * CS + q] = acc[q];
 }
 
+// Middle levels (a few thousand boxes: too few for a thread per box, and the 32-lanes-per-box kernel below reads every 8-byte entry
+// from a line of its own -- lanes = slots, 36 nb entries apart): a thread per (row of the block, box), boxes along the lanes, so
+// every load instruction reads 512 contiguous bytes and a box's CS rows are CS wavefronts; slots outside the grid are read at the
+// box itself and weighted 0 (no branch around a load: nine slots' loads in flight)
+#ifndef FEM_EXP_ROWS_GROUP
+#define FEM_EXP_ROWS_GROUP 9   // slots whose loads are in flight together (27 = 3 x 9)
+#endif
+template <int CS, bool OWN>
+__global__ void __launch_bounds__(256) k_box_residual_rows(Grid3 g, int nbp, const double* __restrict__ st, const double* __restrict__ x,
+                                                           const double* __restrict__ r, double* __restrict__ t,
+                                                           const unsigned char* __restrict__ own)
+{
+    constexpr int CC = CS * CS;
+    const int nb = g.nb();
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int q = tid / nbp, b = tid % nbp;
+    if (q >= CS || b >= nb) return;
+    double acc = (!OWN || own[b]) ? r[(size_t)b * CS + q] : 0.0;
+    const int ix = b % g.nx, iy = (b / g.nx) % g.ny, iz = b / (g.nx * g.ny);
+#pragma unroll 1
+    for (int s0 = 0; s0 < 27; s0 += FEM_EXP_ROWS_GROUP)
+#pragma unroll
+    for (int s = s0; s < s0 + FEM_EXP_ROWS_GROUP; s++) {
+        const int jx = ix + s % 3 - 1, jy = iy + (s / 3) % 3 - 1, jz = iz + s / 9 - 1;
+        const bool in = jx >= 0 && jy >= 0 && jz >= 0 && jx < g.nx && jy < g.ny && jz < g.nz;
+        const int c = in ? jx + g.nx * (jy + g.ny * jz) : b;
+        const double wgt = in ? 1.0 : 0.0;
+        double a = 0.0;
+#pragma unroll
+        for (int p = 0; p < CS; p++) a += st[((size_t)s * CC + q * CS + p) * nb + b] * x[(size_t)c * CS + p];
+        acc -= wgt * a;
+    }
+    t[(size_t)b * CS + q] = acc;
+}
+
 // same for the small levels, which are latency-bound with one thread per box: 32 lanes per
 // box (one stencil slot each, 27 active), fixed shuffle tree over the slots
 template <int CS, bool OWN>
@@ -1601,9 +1636,14 @@ static void cycle_t(Multigrid& mg, size_t l)
     Halo* halo = mg.A->mesh->halo.get();
     Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
     const unsigned char* own = L.halo ? L.halo->owned.p : nullptr;
-    auto residual = [&] {   // small levels: 32 lanes per box (latency), large ones: one thread per box (bandwidth)
+    static const int rows_min = std::getenv("FEM_AMD_MG_ROWS_MIN") ? std::atoi(std::getenv("FEM_AMD_MG_ROWS_MIN")) : 2048;   // (a level with more boxes than this and at most 16384: k_box_residual_rows)
+    auto residual = [&] {   // small levels: 32 lanes per box (latency), middle ones: a thread per row and box, large ones: one thread per box (bandwidth)
         const dim3 gsl(g1((size_t)std::max(L.nb, 1) * 32)), gbx(g1(L.nb));
-        if (L.nb <= 16384) {
+        if (L.nb <= 16384 && L.nb > rows_min) {
+            const int nbp = (L.nb + 63) & ~63;
+            if (own) hipLaunchKernelGGL((k_box_residual_rows<CS, true>), dim3(g1((size_t)nbp * CS)), dim3(256), 0, s, g, nbp, L.st.p, L.x.p, L.r.p, L.t.p, own);
+            else hipLaunchKernelGGL((k_box_residual_rows<CS, false>), dim3(g1((size_t)nbp * CS)), dim3(256), 0, s, g, nbp, L.st.p, L.x.p, L.r.p, L.t.p, own);
+        } else if (L.nb <= 16384) {
             if (own) hipLaunchKernelGGL((k_box_residual_slots<CS, true>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
             else hipLaunchKernelGGL((k_box_residual_slots<CS, false>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
         } else if (CS % 2 == 0 && L.stf.n == L.st.n) {

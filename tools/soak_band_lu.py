@@ -18,7 +18,8 @@ from fem_amd.mesh import structured_hex, structured_quad  # noqa: E402
 lo, hi = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (0, 100)
 ctx = capi.Context(0)
 bad, paths = [], {"bcr": 0, "band": 0}
-os.environ.pop("FEM_AMD_DIRECT_VERBOSE", None)
+if os.environ.get("SOAK_VERBOSE") != "1":
+    os.environ.pop("FEM_AMD_DIRECT_VERBOSE", None)
 for seed in range(lo, hi):
     rng = np.random.default_rng(seed)
     kind = rng.integers(0, 5)

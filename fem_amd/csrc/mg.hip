@@ -743,10 +743,11 @@ __global__ void __launch_bounds__(256) k_box_residual_f2(Grid3 g, int b0, int b1
 #pragma unroll
         for (int q = 0; q < CS; q++) acc[q] *= keep;
     }
+    // (slot by slot, every load of the slot first.  Three slots' loads at a time, unconditional, measured 56 against 43 us on level 1 of
+    // config 3; a thread per block row and box, as on the middle levels, 61: the 6-fold re-read of x at a stride of 48 bytes)
     for (int s = 0; s < 27; s++) {
         int c;
         if (!neighbour_box(g, b, s, c)) continue;
-        // (every load of the slot first: the stream lives on the bytes in flight)
         float2 v[HP];
         double xc[CS];
 #pragma unroll
@@ -1203,6 +1204,7 @@ static BoxGeom geom_of(const MgLevel& L) { return BoxGeom{{L.lo[0], L.lo[1], L.l
 static Shift3 shift_of(const MgLevel& L) { return Shift3{L.sh[0], L.sh[1], L.sh[2]}; }
 
 // returns false when the box grid is too fine for the mesh (an element spans more than two boxes)
+template <int CS> static void level_residual(MgLevel& L, const Grid3& g, hipStream_t s);   // (below, with the cycle)
 template <int BS, int PD>
 static bool setup_t(Multigrid& mg)
 {
@@ -1503,6 +1505,18 @@ static bool setup_t(Multigrid& mg)
         }
         hipLaunchKernelGGL(k_level_dinv<CS>, dim3(g1(L.nb)), dim3(256), 0, s, L.nb, diag, L.dinv.p);
     }
+    // The cycle reads the stencil of a large level twice per application and nothing else of that size: it gets a single-precision
+    // copy (the preconditioner is a fixed linear operator either way; the diagonal blocks and the next level's Galerkin product have
+    // used the doubles, the eigenvalue estimate below runs on what the cycle will run on).  -pc_mg_stencil_f32 0 / FEM_AMD_MG_ST_F32=0: doubles.
+    for (size_t l = 0; l + 1 < mg.lev.size(); l++) {
+        MgLevel& L = mg.lev[l];
+        if (mg.stencil_f32 && L.nb > 16384 && CS % 2 == 0) {
+            if (L.stf.n != L.st.n) L.stf.alloc(L.st.n);
+            if constexpr (CS % 2 == 0)
+                hipLaunchKernelGGL(k_stencil_to_float2<CS>, dim3((unsigned)std::min<size_t>(g1(L.st.n / 2), 8192)), dim3(256), 0, s, L.nb, L.st.p,
+                                   reinterpret_cast<float2*>(L.stf.p));
+        } else L.stf.release();
+    }
     // damping of the block-Jacobi smoother on every smoothed level: power iteration on Dinv A
     mg.omega_l.alloc(mg.lev.size() + 2);
     for (size_t l = 0; l + 1 < mg.lev.size(); l++) {
@@ -1516,8 +1530,7 @@ static bool setup_t(Multigrid& mg)
         const int npow = 12;
         for (int it = 0; it < npow; it++) {
             if (it == npow - 1) hipLaunchKernelGGL(k_norm2_small, dim3(1), dim3(1024), 0, s, n, L.x.p, n2, own, CS);
-            if (own) hipLaunchKernelGGL((k_box_residual<CS, true>), dim3(g1(L.nb)), dim3(256), 0, s, gl, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
-            else hipLaunchKernelGGL((k_box_residual<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, gl, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+            level_residual<CS>(L, gl, s);
             halo_sum_h(L.halo.get(), L.t.p, CS, CS, 1, s, true);
             hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, (const double*)nullptr,
                                L.dinv.p, L.t.p, L.x.p);
@@ -1586,18 +1599,6 @@ static bool setup_t(Multigrid& mg)
         }
         FEM_HIP(hipStreamSynchronize(s));   // rowk/colk go out of scope
     }
-    // The cycle reads the stencil of a large level twice per application and nothing else of that size: it gets a single-precision
-    // copy (the preconditioner is a fixed linear operator either way; set-up -- diagonal blocks, the next level's Galerkin product,
-    // the eigenvalue estimate -- has used the doubles).  -pc_mg_stencil_f32 0 / FEM_AMD_MG_ST_F32=0: doubles.
-    for (size_t l = 0; l + 1 < mg.lev.size(); l++) {
-        MgLevel& L = mg.lev[l];
-        if (mg.stencil_f32 && L.nb > 16384 && CS % 2 == 0) {
-            if (L.stf.n != L.st.n) L.stf.alloc(L.st.n);
-            if constexpr (CS % 2 == 0)
-                hipLaunchKernelGGL(k_stencil_to_float2<CS>, dim3((unsigned)std::min<size_t>(g1(L.st.n / 2), 8192)), dim3(256), 0, s, L.nb, L.st.p,
-                                   reinterpret_cast<float2*>(L.stf.p));
-        } else L.stf.release();
-    }
     FEM_HIP(hipGetLastError());
     FEM_HIP(hipStreamSynchronize(s));
     if (getenv("FEM_AMD_MG_VERBOSE")) {
@@ -1618,6 +1619,34 @@ static bool setup_t(Multigrid& mg)
     return true;
 }
 
+// t = r - A x on a level, by the kernel its size asks for: small levels 32 lanes per box (latency), middle ones a thread per block row
+// and box, large ones one thread per box from the single-precision copy (or from the doubles where there is none)
+template <int CS>
+static void level_residual(MgLevel& L, const Grid3& g, hipStream_t s)
+{
+    static const int rows_min = std::getenv("FEM_AMD_MG_ROWS_MIN") ? std::atoi(std::getenv("FEM_AMD_MG_ROWS_MIN")) : 2048;   // (a level with more boxes than this: the row kernels)
+    const unsigned char* own = L.halo ? L.halo->owned.p : nullptr;
+    const dim3 gsl(g1((size_t)std::max(L.nb, 1) * 32)), gbx(g1(L.nb));
+    const int nbp = (L.nb + 63) & ~63;
+    const dim3 grw(g1((size_t)nbp * CS));
+    if (L.nb > 16384 && CS % 2 == 0 && L.stf.n == L.st.n) {
+        if constexpr (CS % 2 == 0) {
+            const float2* f2 = reinterpret_cast<const float2*>(L.stf.p);
+            if (own) hipLaunchKernelGGL((k_box_residual_f2<CS, true>), gbx, dim3(256), 0, s, g, 0, L.nb, f2, L.x.p, L.r.p, L.t.p, own);
+            else hipLaunchKernelGGL((k_box_residual_f2<CS, false>), gbx, dim3(256), 0, s, g, 0, L.nb, f2, L.x.p, L.r.p, L.t.p, own);
+        }
+    } else if (L.nb > 16384) {
+        if (own) hipLaunchKernelGGL((k_box_residual<CS, true>), gbx, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+        else hipLaunchKernelGGL((k_box_residual<CS, false>), gbx, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+    } else if (L.nb > rows_min) {
+        if (own) hipLaunchKernelGGL((k_box_residual_rows<CS, true>), grw, dim3(256), 0, s, g, nbp, L.st.p, L.x.p, L.r.p, L.t.p, own);
+        else hipLaunchKernelGGL((k_box_residual_rows<CS, false>), grw, dim3(256), 0, s, g, nbp, L.st.p, L.x.p, L.r.p, L.t.p, own);
+    } else {
+        if (own) hipLaunchKernelGGL((k_box_residual_slots<CS, true>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+        else hipLaunchKernelGGL((k_box_residual_slots<CS, false>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
+    }
+}
+
 template <int CS>
 static void cycle_t(Multigrid& mg, size_t l)
 {
@@ -1635,28 +1664,7 @@ static void cycle_t(Multigrid& mg, size_t l)
     // exchange on a level with an eighth of the boxes), before the second smoothing step it is (one neighbour exchange).
     Halo* halo = mg.A->mesh->halo.get();
     Comm* comm = (halo && halo->comm->size > 1) ? halo->comm : nullptr;
-    const unsigned char* own = L.halo ? L.halo->owned.p : nullptr;
-    static const int rows_min = std::getenv("FEM_AMD_MG_ROWS_MIN") ? std::atoi(std::getenv("FEM_AMD_MG_ROWS_MIN")) : 2048;   // (a level with more boxes than this and at most 16384: k_box_residual_rows)
-    auto residual = [&] {   // small levels: 32 lanes per box (latency), middle ones: a thread per row and box, large ones: one thread per box (bandwidth)
-        const dim3 gsl(g1((size_t)std::max(L.nb, 1) * 32)), gbx(g1(L.nb));
-        if (L.nb <= 16384 && L.nb > rows_min) {
-            const int nbp = (L.nb + 63) & ~63;
-            if (own) hipLaunchKernelGGL((k_box_residual_rows<CS, true>), dim3(g1((size_t)nbp * CS)), dim3(256), 0, s, g, nbp, L.st.p, L.x.p, L.r.p, L.t.p, own);
-            else hipLaunchKernelGGL((k_box_residual_rows<CS, false>), dim3(g1((size_t)nbp * CS)), dim3(256), 0, s, g, nbp, L.st.p, L.x.p, L.r.p, L.t.p, own);
-        } else if (L.nb <= 16384) {
-            if (own) hipLaunchKernelGGL((k_box_residual_slots<CS, true>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
-            else hipLaunchKernelGGL((k_box_residual_slots<CS, false>), gsl, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
-        } else if (CS % 2 == 0 && L.stf.n == L.st.n) {
-            if constexpr (CS % 2 == 0) {
-                const float2* f2 = reinterpret_cast<const float2*>(L.stf.p);
-                if (own) hipLaunchKernelGGL((k_box_residual_f2<CS, true>), gbx, dim3(256), 0, s, g, 0, L.nb, f2, L.x.p, L.r.p, L.t.p, own);
-                else hipLaunchKernelGGL((k_box_residual_f2<CS, false>), gbx, dim3(256), 0, s, g, 0, L.nb, f2, L.x.p, L.r.p, L.t.p, own);
-            }
-        } else {
-            if (own) hipLaunchKernelGGL((k_box_residual<CS, true>), gbx, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
-            else hipLaunchKernelGGL((k_box_residual<CS, false>), gbx, dim3(256), 0, s, g, 0, L.nb, L.st.p, L.x.p, L.r.p, L.t.p, own);
-        }
-    };
+    auto residual = [&] { level_residual<CS>(L, g, s); };
     MgLevel& C = mg.lev[l + 1];
     const Grid3 gc = grid_of(C);
     hipLaunchKernelGGL((k_block_smooth<CS, false>), dim3(g1(L.nb)), dim3(256), 0, s, L.nb, 0, L.nb, mg.omega_l.p + l, L.dinv.p,

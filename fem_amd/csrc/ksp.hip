@@ -483,6 +483,7 @@ void ksp_set_up_impl(fem_ksp k)
         k->mg->omega = k->mg_omega;
         k->mg->box = k->mg_box;
         k->mg->stencil_f32 = k->mg_st_f32;
+        k->mg->float_offsets = !(std::getenv("FEM_AMD_MG_FLOAT_OFFSETS") && std::atoi(std::getenv("FEM_AMD_MG_FLOAT_OFFSETS")) == 0);
         k->mg->setup(A);
         k->z.alloc(n);
     }

@@ -58,6 +58,7 @@ struct MgBoxes {
     // level-1 Galerkin product with full-line reads (mg.hip, k_galerkin_fine_quad): the groups of four consecutive boxes that
     // qualify -- first box, slot in gnodes, their 256 nodes sorted by id -- and the boxes that keep the wavefront-per-box kernel
     DBuf<int> gnodes, group_box0, group_slot, rest_boxes;
+    DBuf<float> drel_v, drel_p;     // [nn][3] offsets of the nodes from their box centres, by node and in box-list order (the cycle's transfer kernels)
     int ngroups = 0, nrest = 0;
 };
 
@@ -68,6 +69,7 @@ struct Multigrid {
     double omega_fine = 0.7, lambda_fine = 0.0;   // damping actually used: min(omega, 1.6 / lambda_max estimate)
     double box = 4.0;               // level-1 box edge in mean node spacings (-pc_mg_box)
     bool fine_additive = false;     // -pc_mg_type additive: z = D^-1 r + P V(P^T r), no fine-level product
+    bool float_offsets = true;      // the cycle's transfer kernels read MgBoxes::drel_* (FEM_AMD_MG_FLOAT_OFFSETS=0: the coordinates)
     bool stencil_f32 = true;        // -pc_mg_stencil_f32: the cycle streams a single-precision copy of the large levels' stencils
     std::vector<MgLevel> lev;       // lev[0] = level 1 (first coarse grid)
     std::shared_ptr<MgBoxes> bx;    // level-1 aggregates (shared with the mesh's pattern)

@@ -880,13 +880,39 @@ __global__ void __launch_bounds__(256) k_fine_post(size_t n, double omega, const
     for (; i < n; i += st) z[i] += omega * dinv[i] * (r[i] - kz[i]);
 }
 
+// offsets of the nodes from the centres of their boxes, single precision: by node (prolongation) and in the order of the box lists
+// (restriction) -- geometry alone, kept with the aggregates on the mesh's pattern
+template <int PD>
+__global__ void __launch_bounds__(256) k_node_offsets(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
+                                                      const int* __restrict__ agg, float* __restrict__ drel_v)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nn) return;
+    double c[3], d[3];
+    box_centre(g, geo, agg[v], c);
+    node_offset<PD>(coords, v, c, d);
+    for (int q = 0; q < 3; q++) drel_v[(size_t)v * 3 + q] = (float)d[q];
+}
+__global__ void __launch_bounds__(256) k_node_offsets_by_list(int nn, const int* __restrict__ box_nodes, const float* __restrict__ drel_v,
+                                                              float* __restrict__ drel_p)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nn) return;
+    const int v = box_nodes[p];
+    for (int q = 0; q < 3; q++) drel_p[(size_t)p * 3 + q] = drel_v[(size_t)v * 3 + q];
+}
+
 // r_1[B] = sum_{i in B} P_i^T w_i (r_i - (K z)_i)      one wavefront per box, lanes over the box's
 // nodes (ascending), fixed shuffle tree -> bitwise reproducible
-template <int BS, int CS, int PD>
+// FD: the nodes' offsets from their box centres come from MgBoxes::drel_p (single precision, in the order of the box lists: one
+// contiguous 12-byte read per lane) instead of the coordinates (24 bytes behind the node id) -- the transfer operators of the cycle
+// are a fixed pair P, P^T either way; set-up (the Galerkin products) keeps the coordinates
+template <int BS, int CS, int PD, bool FD = false>
 __global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, const double* __restrict__ coords,
                                                        const int* __restrict__ box_ptr, const int* __restrict__ box_nodes,
                                                        const unsigned char* __restrict__ w, const double* __restrict__ r,
-                                                       const double* __restrict__ kz, double* __restrict__ rc)
+                                                       const double* __restrict__ kz, double* __restrict__ rc,
+                                                       const float* __restrict__ drel = nullptr)
 {
     const int nb = g.nb();
     const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -901,7 +927,8 @@ __global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, con
         double f[BS], d[3], m[CS];
 #pragma unroll
         for (int q = 0; q < BS; q++) f[q] = w[i + q] ? (kz ? r[i + q] - kz[i + q] : r[i + q]) : 0.0;
-        node_offset<PD>(coords, v, cB, d);
+        if constexpr (FD) { d[0] = drel[(size_t)p * 3]; d[1] = drel[(size_t)p * 3 + 1]; d[2] = drel[(size_t)p * 3 + 2]; }
+        else node_offset<PD>(coords, v, cB, d);
         rbm_apply_t<BS, CS>(d, f, m);
 #pragma unroll
         for (int q = 0; q < CS; q++) acc[q] += m[q];
@@ -916,18 +943,18 @@ __global__ void __launch_bounds__(256) k_restrict_fine(Grid3 g, BoxGeom geo, con
 }
 
 // z_i += alpha * w_i * (P_i x_1[agg(i)])
-template <int BS, int CS, int PD>
+template <int BS, int CS, int PD, bool FD = false>
 __global__ void __launch_bounds__(256) k_prolong_fine(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
                                                       double alpha, const int* __restrict__ agg,
                                                       const unsigned char* __restrict__ w, const double* __restrict__ xc,
-                                                      double* __restrict__ z)
+                                                      double* __restrict__ z, const float* __restrict__ drel = nullptr)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= nn) return;
     const int b = agg[v];
     double c[3], d[3], u[BS];
-    box_centre(g, geo, b, c);
-    node_offset<PD>(coords, v, c, d);
+    if constexpr (FD) { d[0] = drel[(size_t)v * 3]; d[1] = drel[(size_t)v * 3 + 1]; d[2] = drel[(size_t)v * 3 + 2]; }
+    else { box_centre(g, geo, b, c); node_offset<PD>(coords, v, c, d); }
     rbm_apply<BS, CS>(d, xc + (size_t)b * CS, u);
     const size_t i = (size_t)v * BS;
 #pragma unroll
@@ -937,13 +964,14 @@ __global__ void __launch_bounds__(256) k_prolong_fine(int nn, Grid3 g, BoxGeom g
 
 // additive fine level, one pass: z_i = dinv_i r_i + alpha w_i (P_i x_1[agg(i)]), plus the partials of
 // z.z and z.r that the CG needs next (same fixed-order two-stage reduction as the Jacobi path)
-template <int BS, int CS, int PD>
+template <int BS, int CS, int PD, bool FD = false>
 __global__ void __launch_bounds__(256) k_additive_finish(int nn, Grid3 g, BoxGeom geo, const double* __restrict__ coords,
                                                          double alpha, const int* __restrict__ agg,
                                                          const unsigned char* __restrict__ w, const double* __restrict__ dinv,
                                                          const double* __restrict__ r, const double* __restrict__ xc,
                                                          double* __restrict__ z, double* __restrict__ pzz,
-                                                         double* __restrict__ pzr, const int* __restrict__ done)
+                                                         double* __restrict__ pzr, const int* __restrict__ done,
+                                                         const float* __restrict__ drel = nullptr)
 {
     if (done && *done) return;
     __shared__ double sh[2][4];
@@ -951,8 +979,8 @@ __global__ void __launch_bounds__(256) k_additive_finish(int nn, Grid3 g, BoxGeo
     for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < nn; v += gridDim.x * blockDim.x) {
         const int b = agg[v];
         double c[3], d[3], u[BS];
-        box_centre(g, geo, b, c);
-        node_offset<PD>(coords, v, c, d);
+        if constexpr (FD) { d[0] = drel[(size_t)v * 3]; d[1] = drel[(size_t)v * 3 + 1]; d[2] = drel[(size_t)v * 3 + 2]; }
+        else { box_centre(g, geo, b, c); node_offset<PD>(coords, v, c, d); }
         rbm_apply<BS, CS>(d, xc + (size_t)b * CS, u);
         const size_t i = (size_t)v * BS;
 #pragma unroll
@@ -1332,6 +1360,9 @@ static bool setup_t(Multigrid& mg)
         bx->box_nodes.alloc((size_t)nn);
         hipLaunchKernelGGL(k_fill_boxes, dim3(g1(nn)), dim3(256), 0, s, nn, bx->agg.p, bx->box_ptr.p, cursor.p, bx->box_nodes.p);
         hipLaunchKernelGGL(k_sort_boxes, dim3(g1(nb)), dim3(256), 0, s, nb, bx->box_ptr.p, bx->box_nodes.p);
+        bx->drel_v.alloc((size_t)nn * 3); bx->drel_p.alloc((size_t)nn * 3);
+        hipLaunchKernelGGL(k_node_offsets<PD>, dim3(g1(nn)), dim3(256), 0, s, nn, g1l, geom_of(L1), mesh->coords.p, bx->agg.p, bx->drel_v.p);
+        hipLaunchKernelGGL(k_node_offsets_by_list, dim3(g1(nn)), dim3(256), 0, s, nn, bx->box_nodes.p, bx->drel_v.p, bx->drel_p.p);
         // the groups of four boxes whose rows the level-1 product can read in whole lines (k_galerkin_fine_quad); once per mesh
         static const bool quad_env = !(std::getenv("FEM_AMD_MG_GALERKIN_QUAD") && std::atoi(std::getenv("FEM_AMD_MG_GALERKIN_QUAD")) == 0);
         const int gpr = L1.nx / MG_GROUP, ncand = gpr * L1.ny * L1.nz;
@@ -1702,13 +1733,22 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     // each node once (owner weights), the sum over the sharers of a box (one neighbour exchange) makes the
     // level-1 residual whole on every domain that holds the box, and the prolongation is local again
     const unsigned char* wr = comm ? mg.wr.p : mg.w.p;
+    const bool fd = mg.float_offsets && mg.bx->drel_v.n == (size_t)nn * 3;
     auto restrict_to_level1 = [&](const double* kz) {
-        hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
-                           mg.bx->box_ptr.p, mg.bx->box_nodes.p, wr, r, kz, L1.r.p);
+        if (fd) hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD, true>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
+                                   mg.bx->box_ptr.p, mg.bx->box_nodes.p, wr, r, kz, L1.r.p, mg.bx->drel_p.p);
+        else hipLaunchKernelGGL((k_restrict_fine<BS, CS, PD>), dim3(g1((size_t)L1.nb * 64)), dim3(256), 0, s, g, geo, coords,
+                                mg.bx->box_ptr.p, mg.bx->box_nodes.p, wr, r, kz, L1.r.p, (const float*)nullptr);
         if (comm) {
             if (mg.lev.size() == 1) comm->allreduce_sum(L1.r.p, L1.nb * CS, s);   // (level 1 is the replicated coarsest one)
             else halo_sum_h(L1.halo.get(), L1.r.p, CS, CS, 1, s, true);
         }
+    };
+    auto prolong_from_level1 = [&] {
+        if (fd) hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD, true>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.bx->agg.p,
+                                   mg.w.p, L1.x.p, z, mg.bx->drel_v.p);
+        else hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.bx->agg.p,
+                                mg.w.p, L1.x.p, z, (const float*)nullptr);
     };
     if (mg.fine_additive) {
         // fine level additive (Jacobi + coarse-grid correction of the un-smoothed residual): the
@@ -1716,12 +1756,13 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
         restrict_to_level1(nullptr);
         cycle_t<CS>(mg, 0);
         if (pzz) {   // the caller wants z.z and z.r as well: one fused pass (single domain)
-            hipLaunchKernelGGL((k_additive_finish<BS, CS, PD>), dim3(npart), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
-                               mg.bx->agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done);
+            if (fd) hipLaunchKernelGGL((k_additive_finish<BS, CS, PD, true>), dim3(npart), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
+                                       mg.bx->agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done, mg.bx->drel_v.p);
+            else hipLaunchKernelGGL((k_additive_finish<BS, CS, PD>), dim3(npart), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
+                                    mg.bx->agg.p, mg.w.p, mg.dinv0.p, r, L1.x.p, z, pzz, pzr, done, (const float*)nullptr);
         } else {
             hipLaunchKernelGGL(k_smooth_first, dim3(gs(ndof)), dim3(256), 0, s, ndof, 1.0, mg.dinv0.p, r, z);
-            hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha,
-                               mg.bx->agg.p, mg.w.p, L1.x.p, z);
+            prolong_from_level1();
         }
         return;
     }
@@ -1730,8 +1771,7 @@ static void apply_t(Multigrid& mg, const double* r, double* z, const int* done, 
     halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
     restrict_to_level1(mg.t0.p);
     cycle_t<CS>(mg, 0);
-    hipLaunchKernelGGL((k_prolong_fine<BS, CS, PD>), dim3(g1(nn)), dim3(256), 0, s, nn, g, geo, coords, mg.alpha, mg.bx->agg.p,
-                       mg.w.p, L1.x.p, z);
+    prolong_from_level1();
     mat_mult_raw(A, z, mg.t0.p, nullptr, done);
     halo_sum(A->mesh, mg.t0.p, BS, BS, 1);
     hipLaunchKernelGGL(k_fine_post, dim3(gs(ndof)), dim3(256), 0, s, ndof, mg.omega_fine, mg.dinv0.p, r, mg.t0.p, z);

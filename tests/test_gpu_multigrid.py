@@ -36,6 +36,22 @@ def test_mg_solution_matches_oracle(gpu_ctx, oracle, name, mgtype):
         assert res.its[-1] * 2 < jac.its[-1]
 
 
+@pytest.mark.parametrize("mgtype", ["multiplicative", "additive"])
+def test_mg_transfer_kernels_with_coordinates_or_kept_offsets(gpu_ctx, monkeypatch, mgtype):
+    """The cycle's fine-level transfer kernels read the nodes' offsets from their box centres in single precision (kept with the
+    aggregates); FEM_AMD_MG_FLOAT_OFFSETS=0 makes them read the coordinates as set-up does: the same preconditioner to 6e-8 --
+    iteration counts within one of each other, the same field."""
+    out = {}
+    for m in (structured_hex(12, 10, 9, jitter=0.2), structured_quad(40, 33, jitter=0.2)):
+        for fo in ("1", "0"):
+            monkeypatch.setenv("FEM_AMD_MG_FLOAT_OFFSETS", fo)
+            res = driver.run(m, f"-pc_type mg -pc_mg_type {mgtype} -ksp_rtol 1e-13", ctx=gpu_ctx, recover_stress=False)
+            assert res.reasons[-1] == 2
+            out[fo] = (res.aggregate_u, res.its[-1])
+        assert abs(out["1"][1] - out["0"][1]) <= 1
+        assert np.abs(out["1"][0] - out["0"][0]).max() <= 1e-10 * np.abs(out["0"][0]).max()
+
+
 def test_mg_is_deterministic_and_gamg_alias(gpu_ctx):
     m = structured_hex(10, jitter=0.2)
     prob = driver.Problem(gpu_ctx, m, "-pc_type gamg -ksp_rtol 1e-12")

@@ -1049,28 +1049,30 @@ __global__ void __launch_bounds__(256) k_prolong_box(Grid3 gf, BoxGeom geof, Gri
 template <int CS>
 __global__ void __launch_bounds__(256) k_dense_from_stencil(Grid3 g, const double* __restrict__ st, double* __restrict__ M)
 {
+    // one workgroup per box: its CS rows of [A | I] (2n wide) are zeroed and filled by itself (a single workgroup for the whole
+    // 9 MB matrix of config 3's coarsest level took 0.27 ms of every set-up)
     constexpr int CC = CS * CS;
-    const int nb = g.nb(), n = nb * CS;
-    for (int idx = threadIdx.x; idx < n * 2 * n; idx += blockDim.x) M[idx] = 0.0;
+    const int nb = g.nb(), n = nb * CS, b = blockIdx.x;
+    if (b >= nb) return;
+    double* rows = M + (size_t)b * CS * 2 * n;
+    for (int idx = threadIdx.x; idx < CS * 2 * n; idx += blockDim.x) rows[idx] = 0.0;
     __syncthreads();
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-        for (int s = 0; s < 27; s++) {
-            int c;
-            if (!neighbour_box(g, b, s, c)) continue;
-            for (int q = 0; q < CS; q++)
-                for (int p = 0; p < CS; p++)
-                    M[(size_t)(b * CS + q) * 2 * n + c * CS + p] += st[((size_t)s * CC + q * CS + p) * nb + b];
-        }
-        for (int q = 0; q < CS; q++) {
-            const int i = b * CS + q;
-            double& dii = M[(size_t)i * 2 * n + i];
-            // a box with fewer than three non-collinear free nodes cannot carry all its rigid-body
-            // modes: its rows are rank deficient (the right-hand sides P^T r stay consistent).  A
-            // relative diagonal shift keeps the pivots of the unpivoted elimination away from zero;
-            // the null-space components it lets through prolong to nothing.
-            dii = (dii == 0.0) ? 1.0 : dii * (1.0 + 1e-10);  // == 0: empty / fully constrained box
-            M[(size_t)i * 2 * n + n + i] = 1.0;
-        }
+    for (int e = threadIdx.x; e < 27 * CC; e += blockDim.x) {   // (a box's 27 neighbours are distinct: one writer per entry)
+        const int s = e / CC, q = (e % CC) / CS, p = e % CS;
+        int c;
+        if (!neighbour_box(g, b, s, c)) continue;
+        rows[(size_t)q * 2 * n + c * CS + p] += st[((size_t)s * CC + q * CS + p) * nb + b];
+    }
+    __syncthreads();
+    if (threadIdx.x < CS) {
+        const int q = threadIdx.x, i = b * CS + q;
+        double& dii = rows[(size_t)q * 2 * n + i];
+        // a box with fewer than three non-collinear free nodes cannot carry all its rigid-body
+        // modes: its rows are rank deficient (the right-hand sides P^T r stay consistent).  A
+        // relative diagonal shift keeps the pivots of the unpivoted elimination away from zero;
+        // the null-space components it lets through prolong to nothing.
+        dii = (dii == 0.0) ? 1.0 : dii * (1.0 + 1e-10);  // == 0: empty / fully constrained box
+        rows[(size_t)q * 2 * n + n + i] = 1.0;
     }
 }
 
@@ -1150,6 +1152,10 @@ __global__ void __launch_bounds__(256) k_gj_resident(int n, double* __restrict__
     GridBarrierLane lane = grid_barrier_census(bar, (unsigned)nbk, shu);
     for (int kb = 0; kb < nbk; kb++) {
         const int k0 = kb * CS;
+        // Columns that matter at step k: the pivot row is zero right of column k0 + CS of the identity half, and what it holds left of
+        // k0 (the residue of the blocks already eliminated, ~1e-16) only ever reaches columns that are not read again -- the
+        // inverse comes out of the right half bit for bit as before, from n + CS columns per step instead of 2n
+        const int t_lo = k0, t_hi = n + k0 + CS;
         double* rowk = rowbuf + (size_t)(kb & 1) * CS * n2;
         if (b == kb) {
             double D[CS][2 * CS];   // [D | I] -> [I | D^-1], every thread for itself (as k_gj_pivot)
@@ -1171,7 +1177,7 @@ __global__ void __launch_bounds__(256) k_gj_resident(int n, double* __restrict__
                 }
             }
             __syncthreads();   // (every thread has read the pivot block before the rows change)
-            for (int t = threadIdx.x; t < n2; t += 256) {
+            for (int t = t_lo + threadIdx.x; t < t_hi; t += 256) {
                 double m[CS];
 #pragma unroll
                 for (int p = 0; p < CS; p++) m[p] = R[p * n2 + t];
@@ -1193,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_gj_resident(int n, double* __restrict__
 #pragma unroll
                 for (int p = 0; p < CS; p++) c[q][p] = R[q * n2 + k0 + p];
             __syncthreads();
-            for (int t = threadIdx.x; t < n2; t += 256) {
+            for (int t = t_lo + threadIdx.x; t < t_hi; t += 256) {
                 double rk[CS];
 #pragma unroll
                 for (int p = 0; p < CS; p++) rk[p] = rowk[(size_t)p * n2 + t];
@@ -1598,7 +1604,7 @@ static bool setup_t(Multigrid& mg)
     const Grid3 gcoarse = grid_of(mg.lev.back());
     mg.ncoarse = gcoarse.nb() * CS;
     mg.cinv.alloc((size_t)mg.ncoarse * 2 * mg.ncoarse);
-    hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
+    hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(std::max(gcoarse.nb(), 1)), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
     // one resident launch where the block rows fit the LDS and the chip (FEM_AMD_MG_GJ_RESIDENT=0: the two launches per block)
     static const bool gj_env = !(std::getenv("FEM_AMD_MG_GJ_RESIDENT") && std::atoi(std::getenv("FEM_AMD_MG_GJ_RESIDENT")) == 0);
     bool gj_done = false;
@@ -1617,7 +1623,7 @@ static bool setup_t(Multigrid& mg)
             FEM_HIP(hipStreamSynchronize(s));
             gj_done = herr == 0;
             if (!gj_done)   // (the barrier gave up: the matrix is half eliminated -- build it again for the launches below)
-                hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(1), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
+                hipLaunchKernelGGL(k_dense_from_stencil<CS>, dim3(std::max(gcoarse.nb(), 1)), dim3(256), 0, s, gcoarse, mg.lev.back().st.p, mg.cinv.p);
         }
     }
     if (!gj_done) {

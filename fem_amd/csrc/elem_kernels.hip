@@ -589,9 +589,32 @@ __device__ __forceinline__ void row_blocks(const AsmGroup& gv, const double* __r
 // hex8 grids, against eight-way with the rows innermost), and the write-out, which walks the rows, is conflict free.
 // Lanes of one wave-instruction hold different rows, or the same row and different local columns b -- which are
 // different slots unless the slice is flagged `serial`, where the lanes of a row take turns.
-template <int PD, int NPE, int NIP, int TYPE, int LPR>
+// MODE (meshes whose elements are all the same element -- config 3's bricks -- need the blocks of ONE element, whichever row asks):
+//   0  every lane computes its element's blocks (row_blocks)
+//   1  the same, and compares them bit for bit with the table of the group's first element (AsmUniform::ke); a difference raises
+//      *diff.  This is the first assembly on a mesh: it decides whether the later ones may take mode 2
+//   2  the blocks come from the table: the kernel is slot look-ups, LDS adds and the write-out -- and writes the same bits
+struct AsmUniform {
+    const double* ke;   // [NPE][NPE][PD][PD] blocks K_ab of the group's first element
+    int* diff;
+};
+template <int NPE>
+__device__ __forceinline__ void row_slots(const AsmGroup& gv, size_t e, int a, uint2& s01, uint2& s23)
+{
+    const uint16_t* sp = gv.slot + (e * NPE + a) * NPE;
+    if constexpr (NPE == 8) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(sp));   // (read once: streaming load)
+        s01 = make_uint2(q.x, q.y); s23 = make_uint2(q.z, q.w);
+    } else if constexpr (NPE == 4) {
+        s01 = *reinterpret_cast<const uint2*>(sp);
+    } else {
+        s01 = make_uint2((unsigned)sp[0] | ((unsigned)sp[1] << 16), (unsigned)sp[2]);
+    }
+}
+template <int PD, int NPE, int NIP, int TYPE, int LPR, int MODE>
 __device__ __forceinline__ void rows_add(bool mine, unsigned code, const AsmGroup& gv, const double* __restrict__ coords,
-                                         double* __restrict__ accrow, int k, int j0, int ww, bool serial)
+                                         double* __restrict__ accrow, int k, int j0, int ww, bool serial, const AsmUniform& uni)
 {
     constexpr int BB = PD * PD;
     double K[NPE][PD][PD];
@@ -599,7 +622,30 @@ __device__ __forceinline__ void rows_add(bool mine, unsigned code, const AsmGrou
     if (mine) {
         const size_t e = (size_t)((code & 0x3fffffffu) >> 3);
         const int a = (int)(code & 7u);
-        row_blocks<PD, NPE, NIP, TYPE>(gv, coords, e, a, K, s01, s23);
+        if constexpr (MODE == 2) {
+            row_slots<NPE>(gv, e, a, s01, s23);
+            const double* t = uni.ke + (size_t)a * NPE * BB;
+#pragma unroll
+            for (int b = 0; b < NPE; b++)
+#pragma unroll
+                for (int i = 0; i < PD; i++)
+#pragma unroll
+                    for (int j = 0; j < PD; j++) K[b][i][j] = t[(b * PD + i) * PD + j];
+        } else {
+            row_blocks<PD, NPE, NIP, TYPE>(gv, coords, e, a, K, s01, s23);
+            if constexpr (MODE == 1) {
+                const double* t = uni.ke + (size_t)a * NPE * BB;
+                bool same = true;
+#pragma unroll
+                for (int b = 0; b < NPE; b++)
+#pragma unroll
+                    for (int i = 0; i < PD; i++)
+#pragma unroll
+                        for (int j = 0; j < PD; j++)
+                            same &= __double_as_longlong(K[b][i][j]) == __double_as_longlong(t[(b * PD + i) * PD + j]);
+                if (!same) *uni.diff = 1;
+            }
+        }
     }
     const unsigned sw[4] = {s01.x, s01.y, s23.x, s23.y};
     auto add_all = [&] {
@@ -624,11 +670,12 @@ __device__ __forceinline__ void rows_add(bool mine, unsigned code, const AsmGrou
 }
 
 // ROWS block rows per workgroup (a 64-row slice is shared by 64/ROWS workgroups), LPR lanes per row.
-template <int PD, int LPR, int ROWS>
+template <int PD, int LPR, int ROWS, int MODE = 0>
 __global__ void __launch_bounds__(ROWS* LPR, 2)   // two waves per SIMD: at most 256 registers per lane
     k_assemble_rows(int nn, int nparts_real, int npass, const int* __restrict__ boff, const int* __restrict__ n2e_ptr,
                     const unsigned* __restrict__ n2e, AsmGroups gs, const double* __restrict__ coords,
-                    const unsigned char* __restrict__ slice_serial, int wcap, int rs_pad, int add, double* __restrict__ val)
+                    const unsigned char* __restrict__ slice_serial, int wcap, int rs_pad, int add, double* __restrict__ val,
+                    AsmUniform uni)
 {
     constexpr int BB = PD * PD, TPB = ROWS * LPR, PARTS = 64 / ROWS;
     extern __shared__ double acc[];   // [ROWS][RS]: the image of this workgroup's rows of the slice
@@ -663,11 +710,11 @@ __global__ void __launch_bounds__(ROWS* LPR, 2)   // two waves per SIMD: at most
                 const AsmGroup& gv = gs.g[g];
                 double* accrow = acc + rl * RS;
                 if constexpr (PD == 3) {
-                    if (gv.type == FEM_HEX) rows_add<3, 8, 8, FEM_HEX, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
-                    else rows_add<3, 4, 1, FEM_TET, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
+                    if (gv.type == FEM_HEX) rows_add<3, 8, 8, FEM_HEX, LPR, MODE>(mine, code, gv, coords, accrow, k, j0, ww, serial, uni);
+                    else rows_add<3, 4, 1, FEM_TET, LPR, MODE>(mine, code, gv, coords, accrow, k, j0, ww, serial, uni);
                 } else {
-                    if (gv.type == FEM_QUA) rows_add<2, 4, 4, FEM_QUA, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
-                    else rows_add<2, 3, 1, FEM_TRI, LPR>(mine, code, gv, coords, accrow, k, j0, ww, serial);
+                    if (gv.type == FEM_QUA) rows_add<2, 4, 4, FEM_QUA, LPR, MODE>(mine, code, gv, coords, accrow, k, j0, ww, serial, uni);
+                    else rows_add<2, 3, 1, FEM_TRI, LPR, MODE>(mine, code, gv, coords, accrow, k, j0, ww, serial, uni);
                 }
             }
         }
@@ -688,6 +735,20 @@ __global__ void __launch_bounds__(ROWS* LPR, 2)   // two waves per SIMD: at most
     }
 }
 
+// the blocks of the group's first element, row by row (one lane per local node), by the code the assembly runs
+template <int PD, int NPE, int NIP, int TYPE>
+__global__ void __launch_bounds__(64) k_ke_ref(AsmGroup gv, const double* __restrict__ coords, double* __restrict__ ke)
+{
+    const int a = threadIdx.x;
+    if (a >= NPE) return;
+    double K[NPE][PD][PD];
+    uint2 s01, s23;
+    row_blocks<PD, NPE, NIP, TYPE>(gv, coords, 0, a, K, s01, s23);
+    for (int b = 0; b < NPE; b++)
+        for (int i = 0; i < PD; i++)
+            for (int j = 0; j < PD; j++) ke[(((size_t)a * NPE + b) * PD + i) * PD + j] = K[b][i][j];
+}
+
 }  // namespace fem
 
 void mat_assemble_elements_impl(fem_mat A)
@@ -705,6 +766,7 @@ void mat_assemble_elements_impl(fem_mat A)
         gs.g[i] = AsmGroup{g.conn.p, g.E.p, g.nu.p, g.slot.p, g.type, g.npe};
     }
     const int add = A->lazy_zero ? 0 : 1;
+    AsmUniform uni{nullptr, nullptr};
     constexpr int LDS_BUDGET = 76 * 1024;   // two workgroups per CU (160 KiB)
     // FEM_AMD_ASM_WCAP (tests): a smaller accumulator window, so that small decks exercise the multi-window path
     // a slice wider than the LDS image takes
@@ -722,10 +784,46 @@ void mat_assemble_elements_impl(fem_mat A)
         const int npass = std::max(1, (P.max_valence + lpr - 1) / lpr);
         const int grid = ((nparts + 7) / 8) * 8;   // the XCD-wise part map wants a multiple of 8
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(tpb), shmem, s, m->nnds, nparts, npass, A->boff.p,
-                           A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p);
+                           A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p, uni);
     };
-    if (m->pdim == 3) launch(k_assemble_rows<3, 8, 32>, 9, 32, 256);   // (16 rows per workgroup, four per CU: 3.55 against 3.31 ms, round 6)
-    else launch(k_assemble_rows<2, 4, 64>, 4, 64, 256);
+    // A mesh of one group whose elements all have the blocks of its first one, bit for bit (config 3: bricks of one size and material
+    // at coordinates that are exact): found out by the first assembly on the mesh (mode 1: the general kernel, comparing as it goes),
+    // used by the later ones (mode 2).  Coordinates and materials of a mesh do not change after fem_mesh_create.
+    // FEM_AMD_ASM_UNIFORM=0: always mode 0.
+    static const bool uni_env = !(std::getenv("FEM_AMD_ASM_UNIFORM") && std::atoi(std::getenv("FEM_AMD_ASM_UNIFORM")) == 0);
+    int mode = 0;
+    if (uni_env && gs.ng == 1 && m->groups[0].nel > 0) {
+        auto& g = m->groups[0];
+        if (g.ke_state == 1) {   // the verdict of the first assembly
+            int h = 1;
+            g.ke_diff.download(&h, 1, s);
+            FEM_HIP(hipStreamSynchronize(s));
+            g.ke_state = h ? 3 : 2;
+        }
+        if (g.ke_state == 0) {
+            const int bb = m->pdim * m->pdim;
+            g.ke_ref.alloc((size_t)g.npe * g.npe * bb);
+            g.ke_diff.alloc(1); g.ke_diff.zero(s);
+            switch (g.type) {
+            case FEM_HEX: hipLaunchKernelGGL((k_ke_ref<3, 8, 8, FEM_HEX>), dim3(1), dim3(64), 0, s, gs.g[0], m->coords.p, g.ke_ref.p); break;
+            case FEM_TET: hipLaunchKernelGGL((k_ke_ref<3, 4, 1, FEM_TET>), dim3(1), dim3(64), 0, s, gs.g[0], m->coords.p, g.ke_ref.p); break;
+            case FEM_QUA: hipLaunchKernelGGL((k_ke_ref<2, 4, 4, FEM_QUA>), dim3(1), dim3(64), 0, s, gs.g[0], m->coords.p, g.ke_ref.p); break;
+            default: hipLaunchKernelGGL((k_ke_ref<2, 3, 1, FEM_TRI>), dim3(1), dim3(64), 0, s, gs.g[0], m->coords.p, g.ke_ref.p); break;
+            }
+            g.ke_state = 1;
+            mode = 1;
+        } else if (g.ke_state == 2) mode = 2;
+        uni = AsmUniform{g.ke_ref.p, g.ke_diff.p};
+    }
+    if (m->pdim == 3) {   // (16 rows per workgroup, four per CU: 3.55 against 3.31 ms, round 6)
+        if (mode == 2) launch(k_assemble_rows<3, 8, 32, 2>, 9, 32, 256);   // (16 rows per workgroup: 2.89 against 2.81 ms)
+        else if (mode == 1) launch(k_assemble_rows<3, 8, 32, 1>, 9, 32, 256);
+        else launch(k_assemble_rows<3, 8, 32, 0>, 9, 32, 256);
+    } else {
+        if (mode == 2) launch(k_assemble_rows<2, 4, 64, 2>, 4, 64, 256);
+        else if (mode == 1) launch(k_assemble_rows<2, 4, 64, 1>, 4, 64, 256);
+        else launch(k_assemble_rows<2, 4, 64, 0>, 4, 64, 256);
+    }
     A->lazy_zero = false;
     FEM_HIP(hipGetLastError());
 }

@@ -14,6 +14,11 @@ struct TypeGroup {
     DBuf<int> elem_id;       // [nel] position in the caller's element list
     DBuf<double> E, nu;      // [nel] material per element (mat(el%mat,1:2), src/m_global.F90:254-255)
     DBuf<uint16_t> slot;     // [nel*npe*npe] block-column slot of (node a, node b) in row a; filled by the Mat
+    // assembly of a mesh whose elements all have the blocks of the first one, bit for bit (elem_kernels.hip, AsmUniform):
+    // 0 not looked at yet, 1 the first assembly is comparing, 2 uniform, 3 not
+    int ke_state = 0;
+    DBuf<double> ke_ref;     // [npe][npe][pd][pd]
+    DBuf<int> ke_diff;       // [1]
 };
 
 struct Comm;  // comm.h

@@ -60,7 +60,19 @@ def _meshes():
         "quad9_jitter": structured_quad(9, 7, jitter=0.2),
         "tet": hex_to_tets(structured_hex(4, 3, 3, jitter=0.15)),
         "mixed_tri_qua": quad_to_mixed(structured_quad(8, 5, jitter=0.1)),
+        # every element the same element, bit for bit (exact coordinates, one material): the second and later assemblies on such a
+        # mesh take the blocks from a table of the first element's (elem_kernels.hip, AsmUniform)
+        "hex_uniform": structured_hex(9, 7, 5),
+        "quad_uniform": structured_quad(21, 13),
+        "hex_one_element_stiffer": _one_element_stiffer(structured_hex(7, 5, 4)),   # ... and must not where a single element differs
     }
+
+
+def _one_element_stiffer(m):
+    m.mats = np.vstack([m.mats, m.mats[0] * np.array([1.5, 1.0, 1.0, 1.0, 1.0])])   # a second material, E x 1.5
+    m.mat_id = m.mat_id.copy()
+    m.mat_id[m.nels // 2] = 1
+    return m
 
 
 @pytest.mark.parametrize("name", list(_meshes()))
@@ -71,6 +83,7 @@ def test_assembled_matrix_matches_oracle(gpu_ctx, oracle, name):
     dm = capi.DeviceMesh(gpu_ctx, m)
     K = capi.Mat(dm)
     K.assemble_elements()
+    K.zero_entries(); K.assemble_elements()      # (the second assembly on a mesh: from the table where the first found it uniform)
     K.apply_kbc()
     grp, gci, gv = K.get_csr()
     assert np.array_equal(grp, rp) and np.array_equal(gci, ci)

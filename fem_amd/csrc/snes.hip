@@ -133,7 +133,9 @@ void dots3(fem_snes sn, int npairs, fem_vec a0, fem_vec b0, fem_vec a1, fem_vec 
         sn->h_red[3] = 0.0;   // (the ticket's bits: 0)
     }
     // FEM_AMD_SNES_POLL=0: the read-back as a copy and a stream synchronisation
-    static const bool poll = !(std::getenv("FEM_AMD_SNES_POLL") && std::atoi(std::getenv("FEM_AMD_SNES_POLL")) == 0);
+    static const bool poll_env = !(std::getenv("FEM_AMD_SNES_POLL") && std::atoi(std::getenv("FEM_AMD_SNES_POLL")) == 0);
+    static bool poll_works = true;   // (a ticket that did not arrive once: the copy and the stream from then on, not 200 ms per read-back)
+    const bool poll = poll_env && poll_works;
     hipLaunchKernelGGL(k_dots3_partial, dim3(nb), dim3(256), 0, s, n, npairs, a0->d.p, b0->d.p, (a1 ? a1 : a0)->d.p, (b1 ? b1 : b0)->d.p,
                        (a2 ? a2 : a0)->d.p, (b2 ? b2 : b0)->d.p, sn->red.p);
     const unsigned long long ticket = ++sn->red_ticket;
@@ -150,6 +152,7 @@ void dots3(fem_snes sn, int npairs, fem_vec a0, fem_vec b0, fem_vec a1, fem_vec 
         }
     }
     if (!got) {
+        if (poll) poll_works = false;
         FEM_HIP(hipMemcpyAsync(sn->h_red, sn->red.p + (size_t)3 * 256, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
         FEM_HIP(hipStreamSynchronize(s));
     }

@@ -787,8 +787,8 @@ void mat_assemble_elements_impl(fem_mat A)
                            A->n2e_ptr.p, A->n2e.p, gs, m->coords.p, P.slice_serial.p, wcap, rs_pad, add, A->val.p, uni);
     };
     // A mesh of one group whose elements all have the blocks of its first one, bit for bit (config 3: bricks of one size and material
-    // at coordinates that are exact): found out by the first assembly on the mesh (mode 1: the general kernel, comparing as it goes),
-    // used by the later ones (mode 2).  Coordinates and materials of a mesh do not change after fem_mesh_create.
+    // at coordinates that are exact): found out by the SECOND assembly on the mesh (mode 1: the general kernel, comparing as it goes),
+    // used from the third on (mode 2).  Coordinates and materials of a mesh do not change after fem_mesh_create.
     // FEM_AMD_ASM_UNIFORM=0: always mode 0.
     static const bool uni_env = !(std::getenv("FEM_AMD_ASM_UNIFORM") && std::atoi(std::getenv("FEM_AMD_ASM_UNIFORM")) == 0);
     int mode = 0;
@@ -800,7 +800,8 @@ void mat_assemble_elements_impl(fem_mat A)
             FEM_HIP(hipStreamSynchronize(s));
             g.ke_state = h ? 3 : 2;
         }
-        if (g.ke_state == 0) {
+        if (g.ke_state == 0) g.ke_state = 4;   // (the first assembly on a mesh is not burdened with the comparison: a host that assembles once pays nothing for it)
+        else if (g.ke_state == 4) {
             const int bb = m->pdim * m->pdim;
             g.ke_ref.alloc((size_t)g.npe * g.npe * bb);
             g.ke_diff.alloc(1); g.ke_diff.zero(s);

@@ -15,7 +15,7 @@ struct TypeGroup {
     DBuf<double> E, nu;      // [nel] material per element (mat(el%mat,1:2), src/m_global.F90:254-255)
     DBuf<uint16_t> slot;     // [nel*npe*npe] block-column slot of (node a, node b) in row a; filled by the Mat
     // assembly of a mesh whose elements all have the blocks of the first one, bit for bit (elem_kernels.hip, AsmUniform):
-    // 0 not looked at yet, 1 the first assembly is comparing, 2 uniform, 3 not
+    // 0 no assembly yet, 4 one assembly done, 1 the second assembly is comparing, 2 uniform, 3 not
     int ke_state = 0;
     DBuf<double> ke_ref;     // [npe][npe][pd][pd]
     DBuf<int> ke_diff;       // [1]

@@ -73,8 +73,8 @@ struct BandLU {
     // a matrix made of small independent blocks (connected components of at most 64 dofs): dense LU per block
     bool batched = false;
     int ncomp = 0;
-    DBuf<int> comp_ptr, comp_nodes, node_loc;   // component -> its nodes (ascending); node -> position in its component
-    DBuf<long long> fac_off;                    // component -> offset of its m x m factor in fac
+    const int *comp_ptr = nullptr, *comp_nodes = nullptr, *node_loc = nullptr;   // component -> its nodes (ascending); node -> position in its component (kept on the sparsity's LuSymbolic)
+    const long long* fac_off = nullptr;         // component -> offset of its m x m factor in fac
     DBuf<double> fac;
     void setup(fem_mat A);
     void solve(const double* b, double* x);

@@ -1381,21 +1381,24 @@ void BandLU::setup(fem_mat A_)
     if (batched) {
         const int nc = sym.nc;
         ncomp = nc;
-        comp_ptr.alloc(sym.cptr.size()); comp_ptr.upload(sym.cptr.data(), sym.cptr.size(), s);
-        comp_nodes.alloc(sym.cnodes.size()); comp_nodes.upload(sym.cnodes.data(), sym.cnodes.size(), s);
-        node_loc.alloc(sym.loc.size()); node_loc.upload(sym.loc.data(), sym.loc.size(), s);
-        fac_off.alloc(sym.foff.size()); fac_off.upload(sym.foff.data(), sym.foff.size(), s);
+        if (sym.d_cptr.n != sym.cptr.size()) {   // (once per sparsity: four uploads and their waits in front of every Jacobian's factorisation otherwise)
+            sym.d_cptr.alloc(sym.cptr.size()); sym.d_cptr.upload(sym.cptr.data(), sym.cptr.size(), s);
+            sym.d_cnodes.alloc(sym.cnodes.size()); sym.d_cnodes.upload(sym.cnodes.data(), sym.cnodes.size(), s);
+            sym.d_loc.alloc(sym.loc.size()); sym.d_loc.upload(sym.loc.data(), sym.loc.size(), s);
+            sym.d_foff.alloc(sym.foff.size()); sym.d_foff.upload(sym.foff.data(), sym.foff.size(), s);
+        }
+        comp_ptr = sym.d_cptr.p; comp_nodes = sym.d_cnodes.p; node_loc = sym.d_loc.p; fac_off = sym.d_foff.p;
         fac.alloc((size_t)std::max<long long>(sym.foff[(size_t)nc], 1));
         ipiv.alloc((size_t)n); flag.alloc(2); flag.zero(s);
         DBuf<unsigned long long> amax(1);
         amax.zero(s);
         hipLaunchKernelGGL(k_val_amax, dim3(std::min<unsigned>(cdiv(A->val.n, 256), 1024)), dim3(256), 0, s, A->val.n, A->values(), amax.p);
         if (bs == 3)
-            hipLaunchKernelGGL(k_comp_lu<3>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
-                               A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
+            hipLaunchKernelGGL(k_comp_lu<3>, dim3(nc), dim3(64), 0, s, nc, comp_ptr, comp_nodes, node_loc, A->boff.p, A->bcol.p,
+                               A->values(), A->rowlen.p, amax.p, fac_off, fac.p, ipiv.p, flag.p);
         else
-            hipLaunchKernelGGL(k_comp_lu<2>, dim3(nc), dim3(64), 0, s, nc, comp_ptr.p, comp_nodes.p, node_loc.p, A->boff.p, A->bcol.p,
-                               A->values(), A->rowlen.p, amax.p, fac_off.p, fac.p, ipiv.p, flag.p);
+            hipLaunchKernelGGL(k_comp_lu<2>, dim3(nc), dim3(64), 0, s, nc, comp_ptr, comp_nodes, node_loc, A->boff.p, A->bcol.p,
+                               A->values(), A->rowlen.p, amax.p, fac_off, fac.p, ipiv.p, flag.p);
         FEM_HIP(hipGetLastError());
         int hflag[2] = {0, 0};
         flag.download(hflag, 2, s);
@@ -1585,8 +1588,8 @@ void BandLU::solve(const double* b, double* x)
     ctx->bind();
     hipStream_t s = ctx->stream;
     if (batched) {
-        if (bs == 3) hipLaunchKernelGGL(k_comp_solve<3>, dim3(ncomp), dim3(64), 0, s, ncomp, comp_ptr.p, comp_nodes.p, fac_off.p, fac.p, ipiv.p, b, x);
-        else hipLaunchKernelGGL(k_comp_solve<2>, dim3(ncomp), dim3(64), 0, s, ncomp, comp_ptr.p, comp_nodes.p, fac_off.p, fac.p, ipiv.p, b, x);
+        if (bs == 3) hipLaunchKernelGGL(k_comp_solve<3>, dim3(ncomp), dim3(64), 0, s, ncomp, comp_ptr, comp_nodes, fac_off, fac.p, ipiv.p, b, x);
+        else hipLaunchKernelGGL(k_comp_solve<2>, dim3(ncomp), dim3(64), 0, s, ncomp, comp_ptr, comp_nodes, fac_off, fac.p, ipiv.p, b, x);
         FEM_HIP(hipGetLastError());
         return;
     }

@@ -94,6 +94,8 @@ struct LuSymbolic {
     std::vector<int> perm;
     long long bwn = 0;
     bool pcr_failed = false;                  // a solve by parallel cyclic reduction has failed its backward-error test on this sparsity
+    DBuf<int> d_cptr, d_cnodes, d_loc;        // the components on the device (batched factorisation)
+    DBuf<long long> d_foff;
     DBuf<int> d_perm, d_perm_dof;             // the numbering on the device (node, dof): uploaded by the first set-up on this sparsity
 };
 

@@ -1392,7 +1392,7 @@ void BandLU::setup(fem_mat A_)
         ipiv.alloc((size_t)n); flag.alloc(2); flag.zero(s);
         DBuf<unsigned long long> amax(1);
         amax.zero(s);
-        hipLaunchKernelGGL(k_val_amax, dim3(std::min<unsigned>(cdiv(A->val.n, 256), 1024)), dim3(256), 0, s, A->val.n, A->values(), amax.p);
+        hipLaunchKernelGGL(k_val_amax, dim3(std::min<unsigned>(cdiv(A->val.n, 256), 128)), dim3(256), 0, s, A->val.n, A->values(), amax.p);   // (one atomic per wavefront on one word: 4096 of them took 47 us)
         if (bs == 3)
             hipLaunchKernelGGL(k_comp_lu<3>, dim3(nc), dim3(64), 0, s, nc, comp_ptr, comp_nodes, node_loc, A->boff.p, A->bcol.p,
                                A->values(), A->rowlen.p, amax.p, fac_off, fac.p, ipiv.p, flag.p);
